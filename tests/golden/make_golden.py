@@ -1,0 +1,332 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference.
+
+Run in the build container only (the reference does not travel to the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference/src \
+        python3 /root/repo/tests/golden/make_golden.py
+
+Every file holds seeded float64 inputs and the outputs the reference produced
+for them.  Only data is written: no reference
+source text is stored.  Keys are documented next to each block.
+"""
+
+import os
+from functools import partial
+
+import numpy as np
+import scipy.signal as sps
+
+from openseize import producer
+from openseize.core import numerical as nm
+from openseize.filtering import fir as ref_fir
+from openseize.filtering import iir as ref_iir
+from openseize.resampling import resampling as ref_rs
+from openseize.spectra import estimators as ref_est
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1e3:.0f} kB, {len(arrays)} arrays")
+
+
+def lengths(pro, axis=-1):
+    return np.array([a.shape[axis] for a in pro], dtype=np.int64)
+
+
+# --------------------------------------------------------------------------
+# G1 producers (rows a1-a4): chunk-length lists + bit-exact contents
+# --------------------------------------------------------------------------
+def g1_producer():
+    rng = np.random.default_rng(101)
+    x = rng.standard_normal((3, 10007))
+    out = {"x": x}
+    for cs in (1000, 1024, 10007, 20000):
+        out[f"array_len_cs{cs}"] = lengths(producer(x, cs, axis=-1))
+
+    # generator of ragged pieces -> GenProducer re-chunking (a2)
+    cuts = np.array([0, 13, 700, 701, 2900, 2900, 6000, 9999, 10007])
+
+    def ragged(arr, cuts):
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                yield arr[:, a:b]
+
+    out["gen_cuts"] = cuts
+    for cs in (1000, 4096, 20000):
+        pro = producer(ragged, cs, axis=-1, shape=x.shape, arr=x, cuts=cuts)
+        out[f"gen_len_cs{cs}"] = lengths(pro)
+        if cs == 1000:
+            out[f"gen_cat_cs{cs}"] = np.concatenate(list(pro), axis=-1)
+
+    # masked producers (a3): random mask, an all-False chunk, a short mask
+    m1 = rng.random(10007) < 0.2
+    m2 = m1.copy()
+    m2[2000:3000] = False
+    m3 = rng.random(7000) < 0.5
+    for name, m in (("rand", m1), ("hole", m2), ("short", m3)):
+        out[f"mask_{name}"] = m
+        for cs in (1000, 1024):
+            pro = producer(x, cs, axis=-1, mask=m)
+            out[f"masked_{name}_len_cs{cs}"] = lengths(pro)
+            if cs == 1000:
+                out[f"masked_{name}_cat_cs{cs}"] = np.concatenate(
+                    list(pro), axis=-1)
+            out[f"masked_{name}_shape_cs{cs}"] = np.array(pro.shape)
+    # sample axis first (axis=0) masked producer
+    xt = np.ascontiguousarray(x.T)
+    pro = producer(xt, 1000, axis=0, mask=m1)
+    out["masked_axis0_cat"] = np.concatenate(list(pro), axis=0)
+    save("g1_producer.npz", **out)
+
+
+# --------------------------------------------------------------------------
+# G2 oaconvolve (row a5) + class API (row a13)
+# --------------------------------------------------------------------------
+def g2_fir():
+    rng = np.random.default_rng(202)
+    x = rng.standard_normal((2, 5004))
+    out = {"x": x}
+    # Reference quirk (found while generating): when the nfft fallback picks
+    # nfft = N (numerical.py:210-211) and N is odd, np.fft.irfft returns N-1
+    # samples and the overlap add raises a broadcasting ValueError.  Recorded
+    # here as a flag; the even-N case below is the one with golden outputs.
+    try:
+        list(nm.oaconvolve(producer(x[:, :5003], 1000, axis=-1),
+                           sps.firwin(1024, 0.2), -1, "same"))
+        out["quirk_odd_fallback_raises"] = np.array(False)
+    except ValueError:
+        out["quirk_odd_fallback_raises"] = np.array(True)
+    for taps in (76, 255, 256, 1024):
+        h = sps.firwin(taps, 0.2)
+        out[f"h{taps}"] = h
+        for mode in ("full", "same", "valid"):
+            pro = producer(x, 1000, axis=-1)
+            pieces = list(nm.oaconvolve(pro, h, -1, mode))
+            out[f"y_t{taps}_{mode}"] = np.concatenate(pieces, axis=-1)
+            out[f"pieces_t{taps}_{mode}"] = np.array(
+                [p.shape[-1] for p in pieces], dtype=np.int64)
+    # long input: the non-fallback nfft (= 8*128*32 = 32768 for 76 taps)
+    xl = rng.standard_normal((2, 70001))
+    h = out["h76"]
+    out["x_long"] = xl
+    for mode in ("full", "same", "valid"):
+        pro = producer(xl, 16384, axis=-1)
+        pieces = list(nm.oaconvolve(pro, h, -1, mode))
+        # decimated + head/tail keeps the file small; lengths pin the indexing
+        y = np.concatenate(pieces, axis=-1)
+        out[f"ylong_{mode}_head"] = y[:, :400]
+        out[f"ylong_{mode}_tail"] = y[:, -400:]
+        out[f"ylong_{mode}_dec"] = y[:, ::37]
+        out[f"ylong_{mode}_pieces"] = np.array(
+            [p.shape[-1] for p in pieces], dtype=np.int64)
+    # GenProducer-wrapped lengths through the class API, ndarray and producer
+    kais = ref_fir.Kaiser(fpass=200, fstop=400, fs=5000, gpass=0.5, gstop=40)
+    out["kaiser_h"] = kais.coeffs
+    xk = rng.standard_normal((2, 6001))
+    out["xk"] = xk
+    for mode in ("full", "same", "valid"):
+        out[f"kaiser_arr_{mode}"] = kais(xk, chunksize=2000, axis=-1, mode=mode)
+        res = kais(producer(xk, 2000, axis=-1), chunksize=2000, axis=-1, mode=mode)
+        out[f"kaiser_pro_len_{mode}"] = lengths(res)
+        out[f"kaiser_pro_shape_{mode}"] = np.array(res.shape)
+    # sample axis not last (axis=1 of a 3-D array), as tests/test_oaconvolve.py
+    x3 = rng.standard_normal((2, 2001, 3))
+    out["x3"] = x3
+    # (FIR.__call__ itself raises IndexError for 0 < axis: bases.py:411 indexes
+    # the 1-D window's shape with the data axis; the generator is used directly)
+    out["kaiser_axis1_same"] = np.concatenate(list(nm.oaconvolve(
+        producer(x3, 700, axis=1), kais.coeffs, 1, "same")), axis=1)
+    save("g2_fir.npz", **out)
+
+
+# --------------------------------------------------------------------------
+# G3 sosfilt (a6) and G4 sosfiltfilt (a7)
+# --------------------------------------------------------------------------
+def filters():
+    f = {}
+    f["butter_lp"] = ref_iir.Butter(fpass=100, fstop=200, fs=500).coeffs
+    f["butter_bp6"] = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    f["cheby1_bp"] = ref_iir.Cheby1(
+        fpass=[200, 600], fstop=[150, 650], fs=2500).coeffs
+    f["butter_cls6"] = ref_iir.Butter(
+        fpass=[8, 30], fstop=[3, 60], fs=500, gpass=1, gstop=40).coeffs
+    return f
+
+
+def g3_sosfilt():
+    rng = np.random.default_rng(303)
+    x = rng.standard_normal((2, 6007))
+    out = {"x": x}
+    for name, sos in filters().items():
+        out[f"sos_{name}"] = sos
+        for cs in (1000, 4096):
+            pro = producer(x, cs, axis=-1)
+            out[f"y_{name}_cs{cs}"] = np.concatenate(
+                list(nm.sosfilt(pro, sos, -1)), axis=-1)
+        zi = rng.standard_normal((sos.shape[0], 2, 2))
+        out[f"zi_{name}"] = zi
+        pro = producer(x, 1000, axis=-1)
+        out[f"yzi_{name}"] = np.concatenate(
+            list(nm.sosfilt(pro, sos, -1, zi=zi)), axis=-1)
+    # sample axis in the middle: shape (3, L, 6), axis=1 as tests/test_iir.py
+    x3 = rng.standard_normal((3, 2001, 2))
+    out["x3"] = x3
+    sos = out["sos_butter_lp"]
+    out["y3_butter_lp"] = np.concatenate(
+        list(nm.sosfilt(producer(x3, 1000, axis=1), sos, 1)), axis=1)
+    save("g3_sosfilt.npz", **out)
+
+
+def g4_sosfiltfilt():
+    rng = np.random.default_rng(404)
+    x = rng.standard_normal((2, 6007))
+    out = {"x": x}
+    for name, sos in filters().items():
+        out[f"sos_{name}"] = sos
+        for cs in (200, 1000, 4096, 6007):
+            pro = producer(x, cs, axis=-1)
+            out[f"y_{name}_cs{cs}"] = np.concatenate(
+                list(nm.sosfiltfilt(pro, sos, -1)), axis=-1)
+    # class API, ndarray in -> ndarray out, and causal variant
+    butter = ref_iir.Butter(fpass=[8, 30], fstop=[3, 60], fs=500, gpass=1, gstop=40)
+    out["cls_dephase"] = butter(x, chunksize=2000, axis=-1, dephase=True)
+    out["cls_causal"] = butter(x, chunksize=2000, axis=-1, dephase=False)
+    save("g4_sosfiltfilt.npz", **out)
+
+
+# --------------------------------------------------------------------------
+# G5 polyphase resampling (a8)
+# --------------------------------------------------------------------------
+def g5_resample():
+    rng = np.random.default_rng(505)
+    x = rng.standard_normal((2, 9011))
+    out = {"x": x}
+    fs = 5000
+    for (L, M) in ((1, 5), (3, 1), (3, 2), (2, 7), (3, 11)):
+        for cs in (3000, 7001):
+            y = ref_rs.resample(x, L, M, fs, chunksize=cs, axis=-1)
+            out[f"y_L{L}_M{M}_cs{cs}"] = y
+        pro = ref_rs.resample(producer(x, 3000, axis=-1), L, M, fs, 3000, axis=-1)
+        out[f"len_L{L}_M{M}"] = lengths(pro)
+        out[f"shape_L{L}_M{M}"] = np.array(pro.shape)
+        cutoff = fs / (2 * max(L, M))
+        h = ref_fir.Kaiser(cutoff - cutoff / 10, cutoff + cutoff / 10, fs,
+                           gpass=0.1, gstop=40).coeffs
+        out[f"h_L{L}_M{M}"] = h
+    out["down5"] = ref_rs.downsample(x, 5, fs, chunksize=4000, axis=-1)
+    out["up3"] = ref_rs.upsample(x[:, :6000], 3, fs, chunksize=2000, axis=-1)
+    # sample axis first
+    xt = np.ascontiguousarray(x[:2, :5000].T)
+    out["down5_axis0"] = ref_rs.downsample(xt, 5, fs, chunksize=1000, axis=0)
+    save("g5_resample.npz", **out)
+
+
+# --------------------------------------------------------------------------
+# G6 periodogram / modified_dft (a9, a10); G7 welch / psd; G8 stft (a11, a12)
+# --------------------------------------------------------------------------
+def g6_periodogram():
+    rng = np.random.default_rng(606)
+    x = rng.standard_normal((3, 1024)) + np.linspace(0, 3, 1024)
+    out = {"x": x}
+    fs = 500
+    for window in ("hann", "hamming", "boxcar", "blackman"):
+        for detrend in ("constant", "linear"):
+            for scaling in ("density", "spectrum"):
+                f, p = nm.periodogram(x, fs, None, window, -1, detrend, scaling)
+                out[f"p_{window}_{detrend}_{scaling}"] = p
+                out["freqs"] = f
+    f, X = nm.modified_dft(x, fs, 1024, "hann", -1, "constant", "density")
+    out["dft_hann"] = X
+    # odd nfft, zero-padded nfft, cropped nfft
+    f, p = nm.periodogram(x[:, :1023], fs, None, "hann", -1, "constant", "density")
+    out["p_odd"], out["freqs_odd"] = p, f
+    f, p = nm.periodogram(x, fs, 2048, "hann", -1, "constant", "density")
+    out["p_pad2048"], out["freqs_pad2048"] = p, f
+    f, p = nm.periodogram(x, fs, 512, "hann", -1, "linear", "spectrum")
+    out["p_crop512"] = p
+    save("g6_periodogram.npz", **out)
+
+
+def g7_welch():
+    rng = np.random.default_rng(707)
+    x = rng.standard_normal((3, 20000))
+    out = {"x": x}
+    fs = 1024
+    for overlap in (0.0, 0.5, 0.6):
+        cnt, f, p = ref_est.psd(x, fs, axis=-1, resolution=1.0, overlap=overlap)
+        out[f"psd_ov{overlap}"] = p
+        out[f"cnt_ov{overlap}"] = np.array(cnt)
+        out["freqs"] = f
+    cnt, f, p = ref_est.psd(x, fs, axis=-1, resolution=0.5, window="hamming",
+                            detrend="linear", scaling="spectrum")
+    out["psd_hamming_linear_spectrum"] = p
+    out["cnt_hamming"] = np.array(cnt)
+    out["freqs_hamming"] = f
+    # the per-segment producer: lengths, reported shape (quirk Q7) and segments
+    pro = producer(x, 5000, axis=-1)
+    f, wp = nm.welch(pro, fs, 1024, "hann", 0.5, -1, "constant", "density")
+    segs = list(wp)
+    out["welch_shape"] = np.array(wp.shape)
+    out["welch_nseg"] = np.array(len(segs))
+    out["welch_seg0"], out["welch_seg_last"] = segs[0], segs[-1]
+    # non power-of-two nfft and sample axis first
+    cnt, f, p = ref_est.psd(np.ascontiguousarray(x[:2].T), 1000, axis=0,
+                            resolution=2.0)
+    out["psd_axis0_nfft500"], out["cnt_axis0"] = p, np.array(cnt)
+    save("g7_welch.npz", **out)
+
+
+def g8_stft():
+    rng = np.random.default_rng(808)
+    x = rng.standard_normal((2, 6100))
+    out = {"x": x}
+    fs = 256
+    for boundary in (True, False):
+        for padded in (True, False):
+            for scaling in ("density", "spectrum"):
+                f, t, X = ref_est.stft(x, fs, axis=-1, resolution=1.0,
+                                       boundary=boundary, padded=padded,
+                                       scaling=scaling, asarray=True)
+                key = f"b{int(boundary)}_p{int(padded)}_{scaling}"
+                out[f"X_{key}"], out[f"t_{key}"] = X, t
+                out["freqs"] = f
+    f, t, pro = ref_est.stft(producer(x, 1000, axis=-1), fs, axis=-1,
+                             resolution=0.5, overlap=0.75, detrend="linear",
+                             window="hamming", asarray=False)
+    out["pro_shape"] = np.array(pro.shape)
+    out["pro_t"] = t
+    out["pro_X"] = np.stack(list(pro), axis=-1)
+    save("g8_stft.npz", **out)
+
+
+# --------------------------------------------------------------------------
+# G9 design constants
+# --------------------------------------------------------------------------
+def g9_design():
+    out = {}
+    for name, sos in filters().items():
+        out[f"sos_{name}"] = sos
+        out[f"zi_{name}"] = sps.sosfilt_zi(sos)
+    cutoff = 5000 / 10
+    out["kaiser_down5_fs5000"] = ref_fir.Kaiser(
+        cutoff - cutoff / 10, cutoff + cutoff / 10, 5000, gpass=0.1, gstop=40).coeffs
+    out["cheby2_lp"] = ref_iir.Cheby2(fpass=100, fstop=150, fs=1000).coeffs
+    out["ellip_hp"] = ref_iir.Ellip(fpass=200, fstop=150, fs=1000).coeffs
+    out["hamming_bp"] = ref_fir.Hamming(
+        fpass=[100, 200], fstop=[50, 250], fs=1000).coeffs
+    save("g9_design.npz", **out)
+
+
+if __name__ == "__main__":
+    g1_producer()
+    g2_fir()
+    g3_sosfilt()
+    g4_sosfiltfilt()
+    g5_resample()
+    g6_periodogram()
+    g7_welch()
+    g8_stft()
+    g9_design()

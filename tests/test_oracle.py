@@ -1,0 +1,165 @@
+"""Pins the CPU oracle (oracle/) against the golden vectors the reference
+produced (tests/golden/make_golden.py).  CPU only."""
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+RTOL = 1e-9   # oracle vs reference: same algorithm, only summation order differs
+
+
+def close(a, b, rtol=RTOL):
+    scale = max(1.0, float(np.max(np.abs(b))))
+    return np.max(np.abs(a - b)) <= rtol * scale
+
+
+def test_producer_lengths(golden):
+    g = golden("g1_producer.npz")
+    x = g["x"]
+    for cs in (1000, 1024, 10007, 20000):
+        assert orc.array_chunk_lengths(x.shape[-1], cs) == list(g[f"array_len_cs{cs}"])
+    for cs in (1000, 4096, 20000):
+        assert orc.rechunk_lengths(x.shape[-1], cs) == list(g[f"gen_len_cs{cs}"])
+    assert np.array_equal(g["gen_cat_cs1000"], x)
+
+
+@pytest.mark.parametrize("name", ["rand", "hole", "short"])
+def test_masked(golden, name):
+    g = golden("g1_producer.npz")
+    x, m = g["x"], g[f"mask_{name}"]
+    for cs in (1000, 1024):
+        y = orc.masked_stream(x, m, cs)
+        assert orc.rechunk_lengths(y.shape[-1], cs) == list(g[f"masked_{name}_len_cs{cs}"])
+    assert np.array_equal(orc.masked_stream(x, m, 1000), g[f"masked_{name}_cat_cs1000"])
+
+
+@pytest.mark.parametrize("taps", [76, 255, 256, 1024])
+@pytest.mark.parametrize("mode", ["full", "same", "valid"])
+def test_oaconvolve(golden, taps, mode):
+    g = golden("g2_fir.npz")
+    x, h = g["x"], g[f"h{taps}"]
+    pieces = orc.oaconvolve(x, h, mode)
+    assert [p.shape[-1] for p in pieces] == list(g[f"pieces_t{taps}_{mode}"])
+    y = np.concatenate(pieces, axis=-1)
+    assert close(y, g[f"y_t{taps}_{mode}"], 1e-12)
+    # and the segmentation-independent meaning: np.convolve
+    assert close(orc.convolve_direct(x, h, mode), g[f"y_t{taps}_{mode}"], 1e-12)
+
+
+def test_oaconvolve_long_and_quirk(golden):
+    g = golden("g2_fir.npz")
+    x, h = g["x_long"], g["h76"]
+    for mode in ("full", "same", "valid"):
+        pieces = orc.oaconvolve(x, h, mode)
+        assert [p.shape[-1] for p in pieces] == list(g[f"ylong_{mode}_pieces"])
+        y = np.concatenate(pieces, axis=-1)
+        assert close(y[:, :400], g[f"ylong_{mode}_head"], 1e-12)
+        assert close(y[:, -400:], g[f"ylong_{mode}_tail"], 1e-12)
+        assert close(y[:, ::37], g[f"ylong_{mode}_dec"], 1e-12)
+    assert bool(g["quirk_odd_fallback_raises"])
+    with pytest.raises(ValueError):
+        orc.oaconvolve(g["x"][:, :5003], g["h1024"], "same")
+
+
+FILTERS = ["butter_lp", "butter_bp6", "cheby1_bp", "butter_cls6"]
+
+
+@pytest.mark.parametrize("name", FILTERS)
+def test_sosfilt(golden, name):
+    g = golden("g3_sosfilt.npz")
+    x, sos = g["x"], g[f"sos_{name}"]
+    for cs in (1000, 4096):
+        y, _ = orc.sosfilt(x, sos, cs)
+        assert np.array_equal(y, g[f"y_{name}_cs{cs}"])      # bit-exact DF2T
+    zi = g[f"zi_{name}"]
+    y, _ = orc.sosfilt(x, sos, 1000, zi=zi)
+    assert np.array_equal(y, g[f"yzi_{name}"])
+
+
+@pytest.mark.parametrize("name", FILTERS)
+def test_sosfilt_zi(golden, name):
+    g = golden("g9_design.npz")
+    assert np.allclose(orc.sosfilt_zi(g[f"sos_{name}"]), g[f"zi_{name}"],
+                       rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", FILTERS)
+@pytest.mark.parametrize("cs", [200, 1000, 4096, 6007])
+def test_sosfiltfilt(golden, name, cs):
+    g = golden("g4_sosfiltfilt.npz")
+    y = orc.sosfiltfilt(g["x"], g[f"sos_{name}"], cs)
+    assert close(y, g[f"y_{name}_cs{cs}"], 1e-9)
+
+
+@pytest.mark.parametrize("LM", [(1, 5), (3, 1), (3, 2), (2, 7), (3, 11)])
+def test_resample(golden, LM):
+    g = golden("g5_resample.npz")
+    L, M = LM
+    x = g["x"]
+    h = orc.resample_filter(L, M, 5000)
+    assert np.allclose(h, g[f"h_L{L}_M{M}"], rtol=0, atol=1e-15)
+    y = orc.polyphase_resample(x, L, M, h)
+    for cs in (3000, 7001):
+        ref = g[f"y_L{L}_M{M}_cs{cs}"]
+        assert y.shape == ref.shape
+        assert close(y, ref, 1e-12)
+    assert orc.rechunk_lengths(y.shape[-1], 3000) == list(g[f"len_L{L}_M{M}"])
+    assert tuple(g[f"shape_L{L}_M{M}"]) == y.shape
+
+
+def test_periodogram(golden):
+    g = golden("g6_periodogram.npz")
+    x = g["x"]
+    for window in ("hann", "hamming", "boxcar", "blackman"):
+        for detrend in ("constant", "linear"):
+            for scaling in ("density", "spectrum"):
+                f, p = orc.periodogram(x, 500, None, window, detrend, scaling)
+                assert close(p, g[f"p_{window}_{detrend}_{scaling}"], 1e-10)
+    assert np.array_equal(f, g["freqs"])
+    _, X = orc.modified_dft(x, 500, 1024, "hann", "constant", "density")
+    assert close(np.abs(X - g["dft_hann"]), 0 * np.abs(X), 1e-12)
+    f, p = orc.periodogram(x[:, :1023], 500)
+    assert close(p, g["p_odd"], 1e-10) and np.array_equal(f, g["freqs_odd"])
+    f, p = orc.periodogram(x, 500, 2048)
+    assert close(p, g["p_pad2048"], 1e-10)
+    f, p = orc.periodogram(x, 500, 512, "hann", "linear", "spectrum")
+    assert close(p, g["p_crop512"], 1e-10)
+    with pytest.raises(ValueError):
+        orc.modified_dft(x, 500, 1024, "hann", "constant", "power")
+
+
+def test_welch_psd(golden):
+    g = golden("g7_welch.npz")
+    x = g["x"]
+    for ov in (0.0, 0.5, 0.6):
+        cnt, f, p = orc.psd(x, 1024, resolution=1.0, overlap=ov)
+        assert cnt == int(g[f"cnt_ov{ov}"])
+        assert close(p, g[f"psd_ov{ov}"], 1e-10)
+    assert np.array_equal(f, g["freqs"])
+    cnt, f, p = orc.psd(x, 1024, resolution=0.5, window="hamming",
+                        detrend="linear", scaling="spectrum")
+    assert cnt == int(g["cnt_hamming"]) and close(p, g["psd_hamming_linear_spectrum"], 1e-10)
+    f, segs = orc.welch_segments(x, 1024, 1024, "hann", 0.5, "constant", "density")
+    assert len(segs) == int(g["welch_nseg"])
+    assert close(segs[0], g["welch_seg0"], 1e-10) and close(segs[-1], g["welch_seg_last"], 1e-10)
+    assert orc.welch_reported_nsegs(x.shape[-1], 1024, 0.5) == int(g["welch_shape"][-1])
+    cnt, f, p = orc.psd(np.ascontiguousarray(x[:2]), 1000, resolution=2.0)
+    assert cnt == int(g["cnt_axis0"]) and close(p.T, g["psd_axis0_nfft500"], 1e-10)
+
+
+def test_stft(golden):
+    g = golden("g8_stft.npz")
+    x = g["x"]
+    for b in (True, False):
+        for p in (True, False):
+            for scaling in ("density", "spectrum"):
+                f, t, X = orc.stft(x, 256, resolution=1.0, boundary=b, padded=p,
+                                   scaling=scaling)
+                key = f"b{int(b)}_p{int(p)}_{scaling}"
+                assert X.shape == g[f"X_{key}"].shape
+                assert np.allclose(t, g[f"t_{key}"], rtol=0, atol=1e-12)
+                assert np.max(np.abs(X - g[f"X_{key}"])) < 1e-12
+    f, t, X = orc.stft(x, 256, resolution=0.5, overlap=0.75, detrend="linear",
+                       window="hamming")
+    assert np.allclose(t, g["pro_t"]) and np.max(np.abs(X - g["pro_X"])) < 1e-12
