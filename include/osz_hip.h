@@ -1,0 +1,213 @@
+/*
+ * osz_hip.h -- C ABI of libosz_hip.so: the MI355X (gfx950) implementation of
+ * Openseize's chunked DSP hot path.
+ *
+ * The reference (mscaudill/openseize, 100 % Python) has no FFI of its own: its
+ * hot loops are calls into SciPy/NumPy compiled code from
+ * src/openseize/core/numerical.py.  Each entry point below replaces one of
+ * those call sites (cited per function) and is what a ctypes binding inside
+ * the reference would bind -- see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - plain C, no exceptions, no ownership crossing the ABI;
+ *   - every function returns 0 on success and a negative osz_status otherwise;
+ *     osz_last_error() gives a thread-local message;
+ *   - all signal data is float64, device resident, laid out (channels, samples)
+ *     row-major with a row pitch `ld` given in ELEMENTS.  Complex outputs are
+ *     interleaved (re, im) float64 pairs; their pitch is in complex elements;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls
+ *     only enqueue work unless documented otherwise;
+ *   - one opaque handle per ITERATOR (the reference's generators each own
+ *     their carried state); handles are not thread-safe.
+ */
+#ifndef OSZ_HIP_H
+#define OSZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    OSZ_OK = 0,
+    OSZ_ERR_INVALID = -1,   /* bad argument            -> ValueError   */
+    OSZ_ERR_HIP = -2,       /* HIP / rocFFT failure    -> RuntimeError */
+    OSZ_ERR_NOMEM = -3,     /* allocation failure      -> MemoryError  */
+    OSZ_ERR_STATE = -4,     /* call order violated     -> RuntimeError */
+    OSZ_ERR_UNSUPPORTED = -5
+} osz_status;
+
+typedef struct osz_sos_s *osz_sos_t;
+typedef struct osz_fir_s *osz_fir_t;
+typedef struct osz_poly_s *osz_poly_t;
+typedef struct osz_spec_s *osz_spec_t;
+
+/* ---- library / device ------------------------------------------------- */
+int osz_version(void);
+const char *osz_last_error(void);
+/* name may be NULL; reports the current HIP device. */
+int osz_device_info(int *cu_count, size_t *hbm_bytes, char *name, int name_len);
+
+/* Memory and stream helpers so that a host without PyTorch can drive the
+ * library (the Python host uses torch tensors' data_ptr() instead). */
+int osz_malloc(void **dptr, size_t bytes);
+int osz_free(void *dptr);
+int osz_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int osz_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int osz_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int osz_memset(void *dst, int value, size_t bytes, void *stream);
+int osz_stream_sync(void *stream);
+/* HIP-event timing on `stream` (torch.cuda.Event only sees torch's stream). */
+int osz_event_create(void **ev);
+int osz_event_destroy(void *ev);
+int osz_event_record(void *ev, void *stream);
+int osz_event_elapsed_ms(void *start, void *stop, float *ms); /* syncs stop */
+
+/* Per-kernel timing with HIP events on the launch stream.  While enabled every
+ * kernel launch of the library is bracketed by two events; query syncs and
+ * returns the launches and summed milliseconds recorded under `name`
+ * ("fir_oa", "fir_seam", "sos_fwd", "sos_warmup", "sos_bwd", "poly",
+ * "spec_prep", "spec_rocfft", "spec_post"). */
+int osz_profile_enable(int on);
+int osz_profile_reset(void);
+int osz_profile_query(const char *name, int64_t *launches, double *total_ms);
+
+/* ---- K2/K3: cascaded second-order sections ---------------------------- */
+/*
+ * Replaces scipy.signal.sosfilt as called by the reference at
+ *   core/numerical.py:334        (sosfilt: forward, zi carried per chunk)
+ *   core/numerical.py:399,402,410 (sosfiltfilt: backward passes on flips)
+ * sos: nsec x 6 host doubles (b0 b1 b2 a0 a1 a2; a0 is divided out).
+ * The handle owns the carried state z (nsec, nch, 2) on the device.
+ */
+int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch);
+int osz_sos_destroy(osz_sos_t h);
+/* zi/zf host arrays laid out (nsec, nch, 2) like the reference's zi argument
+ * (core/numerical.py:313-329).  zi == NULL zeroes the state. Synchronous. */
+int osz_sos_set_state(osz_sos_t h, const double *zi, void *stream);
+int osz_sos_get_state(osz_sos_t h, double *zf, void *stream);
+/* zi_unit (nsec, 2) is the steady-state unit-step state the reference gets from
+ * scipy.signal.sosfilt_zi at core/numerical.py:378.  The library derives it
+ * from the coefficients at create time; this call overrides it (host doubles).
+ * Synchronous. */
+int osz_sos_set_zi_unit(osz_sos_t h, const double *zi_unit);
+/* state[s, c, :] = zi_unit[s, :] * x[c, col]  -- the steady-state start the
+ * reference builds at core/numerical.py:374-386 (zi * x0). x: device. */
+int osz_sos_set_state_scaled(osz_sos_t h, const double *x, int64_t ldx,
+                             int64_t col, void *stream);
+/* y[c, 0:n] = cascade(x[c, 0:n]) continuing from the carried state, which is
+ * advanced (core/numerical.py:332-335). x == y (in place) is allowed. */
+int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y,
+                    int64_t ldy, int64_t n, void *stream);
+/*
+ * Backward sweep of sosfiltfilt for one chunk (core/numerical.py:390-411).
+ *   fa (nch, na): forward-filtered chunk i;  fb (nch, nb): forward-filtered
+ *   chunk i+1 or NULL for the last chunk.
+ * fb != NULL: warm-up = back-filter fb from zi_unit * fb[:, nb-1], keep only
+ * its final state (:397-399), then back-filter fa from that state (:401-403).
+ * fb == NULL: back-filter fa from zi_unit * fa[:, na-1] (:408-411).
+ * y (nch, na) receives the result in natural sample order. The handle's
+ * carried forward state is not touched.
+ */
+int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa,
+                          int64_t na, const double *fb, int64_t ldfb,
+                          int64_t nb, double *y, int64_t ldy, void *stream);
+
+/* ---- K1: streaming FFT overlap-add FIR -------------------------------- */
+/*
+ * Replaces the np.fft.rfft / irfft circular convolution and overlap add of
+ * oaconvolve (core/numerical.py:229-251, hot loop :254-298).  The handle
+ * carries the (nch, ntaps-1) overlap tail.  The stream of FULL linear
+ * convolution samples is produced; boundary modes (:143-150) are applied by
+ * the caller through `skip` (left cut) and by trimming the flush.
+ */
+int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch);
+int osz_fir_destroy(osz_fir_t h);
+int osz_fir_reset(osz_fir_t h, void *stream);
+/* Consumes x (nch, n) and writes the n next samples of the full convolution,
+ * minus the first `skip` of them, to y (nch, n - skip); 0 <= skip <= n. */
+int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n,
+                 double *y, int64_t ldy, int64_t skip, void *stream);
+/* Writes tail[skip : ntaps-1-drop] (the samples after the last input) to y.
+ * Does not modify the carried tail. */
+int osz_fir_flush(osz_fir_t h, double *y, int64_t ldy, int64_t skip,
+                  int64_t drop, void *stream);
+
+/* ---- K4: polyphase rational resampler --------------------------------- */
+/*
+ * Replaces scipy.signal.resample_poly(padded, L, M, window=h) as called at
+ * core/numerical.py:610,631 together with the overhang bookkeeping :590-632.
+ * Output sample j of the whole stream is
+ *    sum_k L*h[k] * xup[j*M + half - k],  half = (ntaps-1)/2
+ * The handle carries the input history it still needs.
+ */
+int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M,
+                    int nch);
+int osz_poly_destroy(osz_poly_t h);
+int osz_poly_reset(osz_poly_t h, void *stream);
+/* Number of output samples a push of n more input samples will produce
+ * (final != 0: the stream ends with this push, total = ceil(N*L/M)). */
+int64_t osz_poly_out_count(osz_poly_t h, int64_t n, int final);
+int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n,
+                  int final, double *y, int64_t ldy, int64_t *n_out,
+                  void *stream);
+
+/* ---- K5/K6: segmenter + detrend + window + rFFT (+ power, + average) -- */
+/*
+ * Replaces _spectra_estimatives' FIFO segmenter (core/numerical.py:799-849),
+ * modified_dft (:635-718: scipy.signal.detrend, get_window, np.fft.rfft,
+ * scaling) and periodogram (:721-796), and the running segment average of
+ * spectra/estimators.py:149-152.
+ */
+typedef enum {
+    OSZ_SPEC_PSD_MEAN = 0,     /* accumulate sum of periodograms (psd)        */
+    OSZ_SPEC_PSD_SEGMENTS = 1, /* one (nch, nfreq) f64 periodogram / segment  */
+    OSZ_SPEC_DFT_SEGMENTS = 2  /* one (nch, nfreq) c128 modified DFT / segment */
+} osz_spec_mode;
+enum { OSZ_DETREND_CONSTANT = 0, OSZ_DETREND_LINEAR = 1 };
+
+/* Segments are nwin samples long, `stride` apart, zero-padded to nfft >= nwin
+ * (welch/stft: nwin == nfft; periodogram with nfft > samples: :697-699).
+ * window: nwin host doubles (scipy.signal.get_window, periodic);
+ * scale: sqrt(norm) of core/numerical.py:703-716, computed by the caller. */
+int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride,
+                    const double *window, double scale, int detrend, int mode,
+                    int nch);
+int osz_spec_destroy(osz_spec_t h);
+int osz_spec_reset(osz_spec_t h, void *stream);
+/* Number of complete segments a push of n more samples will emit. */
+int64_t osz_spec_seg_count(osz_spec_t h, int64_t n);
+/* Consumes x (nch, n).  SEGMENTS modes: writes nseg estimates to out laid out
+ * (nseg, nch, nfreq) contiguous (f64 or interleaved c128).  PSD_MEAN: out is
+ * ignored and the handle's accumulator advances. */
+int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n,
+                  void *out, int64_t *nseg, void *stream);
+/* PSD_MEAN: raw sum of periodograms (nch, nfreq) f64 on the device and the
+ * segment count so far -- a multi-GPU time split reduces these (RCCL) before
+ * dividing.  The pointer stays owned by the handle. */
+int osz_spec_sum(osz_spec_t h, double **dsum, int64_t *count);
+/* PSD_MEAN: mean = sum / count into host array (nch, nfreq). Synchronous. */
+int osz_spec_mean(osz_spec_t h, double *mean, int64_t *count, void *stream);
+
+/* ---- K7: mask compaction ---------------------------------------------- */
+/* y[c, j] = x[c, idx[j]], j < nidx: np.take(arr, np.flatnonzero(mask), axis)
+ * of MaskedProducer.__iter__ (core/producer.py:432). idx: device int64. */
+int osz_take(const double *x, int64_t ldx, int nch, const int64_t *idx,
+             int64_t nidx, double *y, int64_t ldy, void *stream);
+
+/* ---- synthetic device-resident source (benchmarks, tests) ------------- */
+/* x[c, j] = N(0,1) keyed by (seed, ch0 + c, n0 + j): counter-based, so any
+ * shard or chunk is reproducible on CPU and GPU alike. */
+int osz_synth_normal(double *x, int64_t ldx, int nch, int64_t n, uint64_t seed,
+                     int64_t ch0, int64_t n0, void *stream);
+/* 64-bit order-independent checksum of a (nch, n) block: sum of the bit
+ * patterns, plus the float sum; both written to host. Synchronous. */
+int osz_checksum(const double *x, int64_t ldx, int nch, int64_t n,
+                 uint64_t *bits, double *fsum, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSZ_HIP_H */

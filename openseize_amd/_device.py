@@ -1,0 +1,321 @@
+"""Device plumbing: array-kind helpers and thin owners of the C-ABI handles.
+
+PyTorch is used here only for device memory and the current HIP stream; all
+numerics are the HIP kernels behind ``_lib``.  Host ndarrays go to the device
+chunk by chunk and results come back as ndarrays; CUDA(HIP) tensors stay
+resident end to end (a device-resident producer chain never touches the host).
+"""
+
+import ctypes
+
+import numpy as np
+
+from openseize_amd import _lib
+
+try:  # torch is plumbing; the import itself works without a GPU
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def is_tensor(a):
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+def is_arraylike(a):
+    return isinstance(a, np.ndarray) or is_tensor(a)
+
+
+def concatenate(arrs, axis):
+    """np.concatenate for ndarrays, torch.cat for device tensors."""
+    if arrs and is_tensor(arrs[0]):
+        return torch.cat(list(arrs), dim=axis)
+    return np.concatenate(arrs, axis=axis)
+
+
+def stack(arrs, axis):
+    if arrs and is_tensor(arrs[0]):
+        return torch.stack(list(arrs), dim=axis)
+    return np.stack(arrs, axis=axis)
+
+
+def size(a):
+    return a.numel() if is_tensor(a) else a.size
+
+
+def zeros_like_kind(ref, shape, value=0.0):
+    """Constant array of `shape` of the same kind (host/device) as `ref`."""
+    if is_tensor(ref):
+        return torch.full(tuple(shape), float(value), dtype=ref.dtype,
+                          device=ref.device)
+    return value * np.ones(shape)
+
+
+def require_gpu():
+    lib = _lib.load()          # raises OszLibraryError when the .so is missing
+    if torch is None or not torch.cuda.is_available():
+        raise RuntimeError(
+            "openseize_amd needs a HIP device (MI355X): no GPU is visible. "
+            "There is no CPU fallback.")
+    return lib
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def host_dp(a):
+    return a.ctypes.data_as(_lib.c_dp)
+
+
+class Layout:
+    """Maps an N-D chunk with a sample axis to the (channels, samples)
+    row-major layout of the C ABI and back.  (The reference's functions take
+    any axis: core/numerical.py passes ``axis`` straight to SciPy.)"""
+
+    def __init__(self, shape, axis):
+        shape = tuple(int(s) for s in shape)
+        self.ndim = len(shape)
+        self.axis = axis % self.ndim
+        self.other = shape[:self.axis] + shape[self.axis + 1:]
+        self.nch = int(np.prod(self.other)) if self.other else 1
+
+    def to2d(self, arr):
+        """-> (float64 CUDA tensor (nch, n), was_host)."""
+        if is_tensor(arr):
+            host = False
+            t = arr
+            if t.dtype != torch.float64:
+                t = t.to(torch.float64)
+            if not t.is_cuda:
+                t = t.cuda()
+                host = True
+        else:
+            host = True
+            a = np.asarray(arr, dtype=np.float64)
+            t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        t = torch.movedim(t, self.axis, -1)
+        n = t.shape[-1]
+        return t.reshape(self.nch, n).contiguous(), host
+
+    def from2d(self, t, host):
+        """(nch, m) tensor -> array of the original kind with the sample axis
+        restored."""
+        m = t.shape[-1]
+        out = t.reshape(self.other + (m,))
+        out = torch.movedim(out, -1, self.axis)
+        if host:
+            return out.cpu().numpy()
+        return out.contiguous()
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self.h = ctypes.c_void_p()
+        self.lib = require_gpu()
+
+    def close(self):
+        if self.h:
+            getattr(self.lib, self._destroy)(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):  # pragma: no cover - interpreter teardown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SosStream(_Handle):
+    """One iterator's cascade state (C ABI: osz_sos_*)."""
+    _destroy = "osz_sos_destroy"
+
+    def __init__(self, sos, nch):
+        super().__init__()
+        sos = np.ascontiguousarray(sos, dtype=np.float64)
+        if sos.ndim != 2 or sos.shape[1] != 6:
+            raise ValueError("sos array must be shape (n_sections, 6)")
+        self.nsec, self.nch = sos.shape[0], nch
+        _lib.check(self.lib.osz_sos_create(ctypes.byref(self.h), host_dp(sos),
+                                           self.nsec, nch))
+
+    def set_state(self, zi):
+        """zi: None or host array (nsec, nch, 2)."""
+        if zi is None:
+            _lib.check(self.lib.osz_sos_set_state(self.h, None, stream_ptr()))
+            return
+        zi = np.ascontiguousarray(zi, dtype=np.float64)
+        if zi.shape != (self.nsec, self.nch, 2):
+            raise ValueError(
+                f"Invalid zi shape. Expected {(self.nsec, self.nch, 2)}, "
+                f"got {zi.shape}")
+        _lib.check(self.lib.osz_sos_set_state(self.h, host_dp(zi), stream_ptr()))
+
+    def get_state(self):
+        zf = np.empty((self.nsec, self.nch, 2))
+        _lib.check(self.lib.osz_sos_get_state(self.h, host_dp(zf), stream_ptr()))
+        return zf
+
+    def set_zi_unit(self, zi_unit):
+        zi_unit = np.ascontiguousarray(zi_unit, dtype=np.float64)
+        _lib.check(self.lib.osz_sos_set_zi_unit(self.h, host_dp(zi_unit)))
+
+    def set_state_scaled(self, x2d, col):
+        _lib.check(self.lib.osz_sos_set_state_scaled(
+            self.h, ptr(x2d), x2d.stride(0), col, stream_ptr()))
+
+    def forward(self, x2d, out=None):
+        y = torch.empty_like(x2d) if out is None else out
+        _lib.check(self.lib.osz_sos_forward(
+            self.h, ptr(x2d), x2d.stride(0), ptr(y), y.stride(0),
+            x2d.shape[1], stream_ptr()))
+        return y
+
+    def backward(self, fa, fb=None, out=None):
+        """Chunk-local backward sweep (osz_sosfiltfilt_chunk)."""
+        y = torch.empty_like(fa) if out is None else out
+        _lib.check(self.lib.osz_sosfiltfilt_chunk(
+            self.h, ptr(fa), fa.stride(0), fa.shape[1],
+            ptr(fb) if fb is not None else None,
+            fb.stride(0) if fb is not None else 0,
+            fb.shape[1] if fb is not None else 0,
+            ptr(y), y.stride(0), stream_ptr()))
+        return y
+
+
+class FirStream(_Handle):
+    """One iterator's overlap-add state (C ABI: osz_fir_*)."""
+    _destroy = "osz_fir_destroy"
+
+    def __init__(self, taps, nch):
+        super().__init__()
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        self.ntaps, self.nch = len(taps), nch
+        _lib.check(self.lib.osz_fir_create(ctypes.byref(self.h), host_dp(taps),
+                                           self.ntaps, nch))
+
+    def push(self, x2d, skip=0, out=None):
+        n = x2d.shape[1]
+        y = out if out is not None else torch.empty(
+            (self.nch, n - skip), dtype=torch.float64, device=x2d.device)
+        _lib.check(self.lib.osz_fir_push(
+            self.h, ptr(x2d), x2d.stride(0), n, ptr(y), max(y.stride(0), 1),
+            skip, stream_ptr()))
+        return y
+
+    def flush(self, device, skip=0, drop=0):
+        cnt = self.ntaps - 1 - skip - drop
+        y = torch.empty((self.nch, max(cnt, 0)), dtype=torch.float64,
+                        device=device)
+        if cnt > 0:
+            _lib.check(self.lib.osz_fir_flush(self.h, ptr(y), y.stride(0), skip,
+                                              drop, stream_ptr()))
+        return y
+
+
+class PolyStream(_Handle):
+    """One iterator's polyphase resampler state (C ABI: osz_poly_*)."""
+    _destroy = "osz_poly_destroy"
+
+    def __init__(self, taps, L, M, nch):
+        super().__init__()
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        self.nch = nch
+        _lib.check(self.lib.osz_poly_create(ctypes.byref(self.h), host_dp(taps),
+                                            len(taps), L, M, nch))
+
+    def push(self, x2d, final):
+        n = x2d.shape[1]
+        cnt = self.lib.osz_poly_out_count(self.h, n, int(final))
+        y = torch.empty((self.nch, max(cnt, 0)), dtype=torch.float64,
+                        device=x2d.device)
+        nout = ctypes.c_int64()
+        _lib.check(self.lib.osz_poly_push(
+            self.h, ptr(x2d), x2d.stride(0), n, int(final), ptr(y),
+            max(y.stride(0), 1), ctypes.byref(nout), stream_ptr()))
+        return y
+
+
+class SpecStream(_Handle):
+    """One iterator's segmenter / windowed-DFT state (C ABI: osz_spec_*)."""
+    _destroy = "osz_spec_destroy"
+
+    def __init__(self, nwin, nfft, stride, window, scale, detrend, mode, nch):
+        super().__init__()
+        window = np.ascontiguousarray(window, dtype=np.float64)
+        if detrend not in _lib.DETREND:
+            raise ValueError("Trend type must be 'linear' or 'constant'.")
+        self.nfreq, self.nch, self.mode = nfft // 2 + 1, nch, mode
+        _lib.check(self.lib.osz_spec_create(
+            ctypes.byref(self.h), nwin, nfft, stride, host_dp(window),
+            float(scale), _lib.DETREND[detrend], mode, nch))
+
+    def push(self, x2d):
+        """Returns a (nseg, nch, nfreq) tensor (f64 or c128) or None in
+        PSD_MEAN mode."""
+        n = x2d.shape[1]
+        nseg = self.lib.osz_spec_seg_count(self.h, n)
+        out = None
+        if self.mode == _lib.SPEC_PSD_SEGMENTS:
+            out = torch.empty((nseg, self.nch, self.nfreq), dtype=torch.float64,
+                              device=x2d.device)
+        elif self.mode == _lib.SPEC_DFT_SEGMENTS:
+            out = torch.empty((nseg, self.nch, self.nfreq),
+                              dtype=torch.complex128, device=x2d.device)
+        got = ctypes.c_int64()
+        _lib.check(self.lib.osz_spec_push(
+            self.h, ptr(x2d), x2d.stride(0), n,
+            ptr(out) if out is not None else None, ctypes.byref(got),
+            stream_ptr()))
+        return out
+
+    def sum_tensor(self):
+        """(device tensor view of the running periodogram sum, count)."""
+        dsum, cnt = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(self.lib.osz_spec_sum(self.h, ctypes.byref(dsum),
+                                         ctypes.byref(cnt)))
+        return dsum, cnt.value
+
+    def mean(self):
+        out = np.empty((self.nch, self.nfreq))
+        cnt = ctypes.c_int64()
+        _lib.check(self.lib.osz_spec_mean(self.h, host_dp(out),
+                                          ctypes.byref(cnt), stream_ptr()))
+        return cnt.value, out
+
+
+def take(x2d, idx):
+    """osz_take: y[c, j] = x[c, idx[j]] (idx: int64 CUDA tensor)."""
+    lib = require_gpu()
+    y = torch.empty((x2d.shape[0], idx.numel()), dtype=torch.float64,
+                    device=x2d.device)
+    _lib.check(lib.osz_take(ptr(x2d), x2d.stride(0), x2d.shape[0], ptr(idx),
+                            idx.numel(), ptr(y), max(y.stride(0), 1),
+                            stream_ptr()))
+    return y
+
+
+def synth_normal(nch, n, seed=0, ch0=0, n0=0, out=None, device="cuda"):
+    """Device-resident synthetic float64 N(0,1) block keyed by
+    (seed, channel, sample) -- osz_synth_normal."""
+    lib = require_gpu()
+    x = out if out is not None else torch.empty((nch, n), dtype=torch.float64,
+                                                device=device)
+    _lib.check(lib.osz_synth_normal(ptr(x), x.stride(0), nch, n, seed, ch0, n0,
+                                    stream_ptr()))
+    return x
+
+
+def checksum(x2d):
+    lib = require_gpu()
+    bits, fsum = ctypes.c_uint64(), ctypes.c_double()
+    _lib.check(lib.osz_checksum(ptr(x2d), x2d.stride(0), x2d.shape[0],
+                                x2d.shape[1], ctypes.byref(bits),
+                                ctypes.byref(fsum), stream_ptr()))
+    return bits.value, fsum.value

@@ -1,0 +1,430 @@
+"""The chunked numerics behind the Producer iterator -- host side.
+
+Same generator functions, argument meaning, shapes and exceptions as the
+reference's ``core/numerical.py`` (cited per function), but every sample is
+processed by the HIP kernels of ``libosz_hip.so`` through the C ABI
+(``include/osz_hip.h``); nothing here computes on the CPU and nothing falls
+back to SciPy/NumPy for the filtering or transforms.  SciPy is used only for
+design-time constants (window coefficients), as the reference does.
+
+Each generator owns one C-ABI handle (the iterator's carried state: overlap
+tail, zi, resampler history, segment FIFO) created when iteration starts, so
+producers stay re-iterable and picklable.  Chunks that arrive as ndarrays are
+sent to the device and results come back as ndarrays; chunks that arrive as
+CUDA tensors stay in HBM.
+"""
+
+import math
+from functools import partial
+
+import numpy as np
+import scipy.signal as sps
+
+from openseize_amd import _device as dev
+from openseize_amd import _lib
+from openseize_amd.core import protools
+from openseize_amd.core.arraytools import normalize_axis, slice_along_axis
+from openseize_amd.core.producer import producer
+
+
+# ---------------------------------------------------------------------------
+# overlap-add FIR (reference core/numerical.py:19-298)
+# ---------------------------------------------------------------------------
+def optimal_nffts(arr):
+    """FFT length the reference would pick per segment
+    (core/numerical.py:19-38).  Kept for API parity: the device kernel uses a
+    fixed on-chip 4096-point transform, which gives the same linear
+    convolution (the result does not depend on the segmentation)."""
+    return int(8 * 2 ** np.ceil(np.log2(len(arr))))
+
+
+def convolved_shape(shape1, shape2, mode, axis):
+    """Shape of the convolution of arrays of shape1 and shape2 along axis
+    (core/numerical.py:41-73).  A 1-D second shape is taken as the window
+    length whatever ``axis`` is (the reference indexes it with ``axis`` and
+    raises IndexError for 0 < axis, filtering/bases.py:411)."""
+    m = shape1[axis]
+    n = shape2[0] if len(shape2) == 1 else shape2[axis]
+    p, q = max(m, n), min(m, n)
+    outshape = sorted([list(shape1), list(shape2)], key=len)[-1]
+    if mode == "full":
+        outshape[axis] = m + n - 1
+    elif mode == "same":
+        outshape[axis] = p
+    elif mode == "valid":
+        outshape[axis] = m + n - 1 - 2 * (q - 1)
+    return tuple(outshape)
+
+
+def convolve_slicer(arr, shape1, shape2, mode, axis):
+    """Applies a numpy convolve mode to a full convolution
+    (core/numerical.py:76-116)."""
+    m = shape1[axis]
+    n = shape2[0] if len(shape2) == 1 else shape2[axis]
+    p, q = max(m, n), min(m, n)
+    if mode == "full":
+        return arr
+    if mode == "same":
+        start = (q - 1) // 2
+        return slice_along_axis(arr, start, start + p, axis=axis)
+    if mode == "valid":
+        return slice_along_axis(arr, q - 1, (n + m - 1) - (q - 1), axis=axis)
+    raise ValueError(f"unknown mode {mode!r}")
+
+
+def _oa_cuts(wlen, mode):
+    """Samples dropped left of the first and right of the last segment
+    (core/numerical.py:143-150)."""
+    if mode == "full":
+        return 0, 0
+    if mode == "same":
+        return (wlen - 1) // 2, int(math.ceil((wlen - 1) / 2))
+    if mode == "valid":
+        return wlen - 1, wlen - 1
+    raise KeyError(mode)
+
+
+def oaconvolve(pro, window, axis, mode, nfft_factor=32):
+    """Streaming overlap-add convolution of a producer with a 1-D window
+    (core/numerical.py:158-298) on the device (K1, ``osz_fir_*``).
+
+    Yields one piece per produced chunk plus the final overhang; concatenated
+    they are the ``np.convolve(x, window, mode)`` of every channel, i.e. what
+    the reference yields in ``step``-sized pieces.  ``nfft_factor`` is accepted
+    for signature parity and ignored (see ``optimal_nffts``).
+
+    Differences from the reference, both on inputs where it misbehaves: data
+    shorter than the window raises a clear ValueError (the reference fails
+    with a broadcasting ValueError), and the lengths ``N == nfft-wlen+1`` /
+    odd fallback nfft (where the reference skips the left cut or raises) give
+    the plain ``np.convolve`` answer.
+    """
+    window = np.asarray(window, dtype=np.float64)
+    if window.ndim != 1:
+        raise ValueError("window must be 1-D")
+    wlen = len(window)
+    lcut, rcut = _oa_cuts(wlen, mode)
+    nsamples = pro.shape[axis]
+    if nsamples < wlen:
+        raise ValueError(
+            f"operands could not be convolved: data has {nsamples} samples "
+            f"along axis {axis}, fewer than the {wlen} window taps")
+    layout = dev.Layout(pro.shape, axis)
+    fir = dev.FirStream(window, layout.nch)
+    pos, host, device = 0, True, "cuda"
+    try:
+        for arr in pro:
+            x2d, host = layout.to2d(arr)
+            device = x2d.device
+            n = x2d.shape[1]
+            if n == 0:
+                continue
+            skip = min(max(lcut - pos, 0), n)
+            y = fir.push(x2d, skip)
+            pos += n
+            if y.shape[1] > 0:
+                yield layout.from2d(y, host)
+        if pos > 0:
+            tail = fir.flush(device, skip=min(max(lcut - pos, 0), wlen - 1),
+                             drop=rcut)
+            if tail.shape[1] > 0:
+                yield layout.from2d(tail, host)
+    finally:
+        fir.close()
+
+
+# ---------------------------------------------------------------------------
+# SOS IIR (reference core/numerical.py:301-411)
+# ---------------------------------------------------------------------------
+def _zi_to_2d(zi, nsec, layout):
+    """User zi of shape (nsec, ..., 2 on axis, ...) -> (nsec, nch, 2)."""
+    zi = np.asarray(zi, dtype=np.float64)
+    want = list(layout.other)
+    want.insert(layout.axis, 2)
+    if zi.shape != (nsec, *want):
+        raise ValueError(
+            f"Invalid zi shape. With axis={layout.axis} and sos of {nsec} "
+            f"sections, expected {(nsec, *want)}, got {zi.shape}.")
+    zi = np.moveaxis(zi, layout.axis + 1, -1)
+    return np.ascontiguousarray(zi.reshape(nsec, layout.nch, 2))
+
+
+def sosfilt(pro, sos, axis, zi=None):
+    """Forward cascaded-biquad filter with the state carried from chunk to
+    chunk (core/numerical.py:301-335) on the device (K2,
+    ``osz_sos_forward``).  ``zi``: None (zeros) or an array of shape
+    (nsections, ..., 2 along axis, ...)."""
+    sos = np.atleast_2d(np.asarray(sos, dtype=np.float64))
+    layout = dev.Layout(pro.shape, axis)
+    stream = dev.SosStream(sos, layout.nch)
+    try:
+        if zi is not None:
+            stream.set_state(_zi_to_2d(zi, sos.shape[0], layout))
+        for subarr in pro:
+            x2d, host = layout.to2d(subarr)
+            if x2d.shape[1] == 0:
+                continue
+            yield layout.from2d(stream.forward(x2d), host)
+    finally:
+        stream.close()
+
+
+def sosfiltfilt(pro, sos, axis):
+    """Forward-backward (zero-phase) cascaded-biquad filter
+    (core/numerical.py:338-411) on the device (K2 + K3).
+
+    Reproduces the reference's chunk-local scheme exactly: the forward pass
+    starts from ``sosfilt_zi * x[0]`` (:374-386); the backward pass of chunk i
+    starts from the state left by back-filtering forward chunk i+1 alone,
+    itself started at ``sosfilt_zi * (its last sample)`` (:397-403); the last
+    chunk starts at ``sosfilt_zi * (its own last sample)`` (:408-411).  Hence,
+    like the reference, the result depends on ``pro.chunksize``.  The forward
+    pass of every chunk is computed once and reused (the reference runs it
+    twice, quirk Q11).
+    """
+    sos = np.atleast_2d(np.asarray(sos, dtype=np.float64))
+    layout = dev.Layout(pro.shape, axis)
+    stream = dev.SosStream(sos, layout.nch)
+    try:
+        chunks = iter(pro)
+        first = next(chunks, None)
+        if first is None:
+            return
+        x2d, host = layout.to2d(first)
+        stream.set_state_scaled(x2d, 0)
+        fa = stream.forward(x2d)
+        n = int(np.ceil(pro.shape[axis] / pro.chunksize))
+        idx = 1
+        while True:
+            # one-chunk lookahead: the forward pass runs over every chunk in
+            # order, the backward pass of chunk idx needs forward chunk idx+1
+            nxt = next(chunks, None)
+            fb, host_b = None, host
+            if nxt is not None:
+                b2d, host_b = layout.to2d(nxt)
+                fb = stream.forward(b2d)
+            if idx < n and fb is not None:
+                y = stream.backward(fa, fb)
+            else:
+                # last chunk (the reference takes this branch for idx >= n)
+                y = stream.backward(fa, None)
+            yield layout.from2d(y, host)
+            if fb is None:
+                break
+            fa, host = fb, host_b
+            idx += 1
+    finally:
+        stream.close()
+
+
+def lfilter(pro, coeffs, axis, zi=None):
+    """Transfer-function (b, a) forward filter (core/numerical.py:414-446).
+    Scheduled after the SOS path; not on the device yet."""
+    raise NotImplementedError(
+        "ba-format filtering is not implemented on the device yet; design the "
+        "filter with fmt='sos'")
+
+
+def filtfilt(pro, coeffs, axis):
+    """Transfer-function forward-backward filter (core/numerical.py:449-520).
+    See ``lfilter``."""
+    raise NotImplementedError(
+        "ba-format filtering is not implemented on the device yet; design the "
+        "filter with fmt='sos'")
+
+
+# ---------------------------------------------------------------------------
+# polyphase resampling (reference core/numerical.py:523-632)
+# ---------------------------------------------------------------------------
+def polyphase_resample(pro, L, M, fs, fir, axis, **kwargs):
+    """Rational L/M resampling of a producer (core/numerical.py:523-632) on
+    the device (K4, ``osz_poly_*``).
+
+    The reference resamples chunk by chunk with overhangs borrowed from the
+    neighbouring chunks, which reproduces
+    ``scipy.signal.resample_poly(x, L, M, window=h)`` of the whole stream; the
+    device kernel evaluates that definition directly and carries the input
+    history it needs.  Kept from the reference: the ``M >= N`` ValueError
+    (:569-571), the chunksize clamp to ``N // 3`` and rounding up to a
+    multiple of M (:574-587, applied to ``pro`` in place like
+    ``producer(pro, csize, axis)`` at :590), and the default Kaiser low-pass
+    (:579-583) built through ``fir``.
+    """
+    if M >= pro.shape[axis]:
+        msg = "Decimation factor must M={} be < pro.shape[{}] = {}"
+        raise ValueError(msg.format(M, axis, pro.shape[axis]))
+
+    csize = pro.chunksize
+    if csize > pro.shape[axis] // 3:
+        csize = pro.shape[axis] // 3
+
+    cutoff = fs / (2 * max(L, M))
+    fstop = kwargs.pop("fstop", cutoff + cutoff / 10)
+    fpass = kwargs.pop("fpass", cutoff - cutoff / 10)
+    gpass, gstop = kwargs.pop("gpass", 0.1), kwargs.pop("gstop", 40)
+    h = fir(fpass, fstop, fs, gpass, gstop).coeffs
+
+    if csize % M > 0:
+        csize = int(np.ceil(csize / M) * M)
+    pro = producer(pro, max(csize, 1), axis)
+
+    layout = dev.Layout(pro.shape, axis)
+    stream = dev.PolyStream(h, int(L), int(M), layout.nch)
+    try:
+        chunks = iter(pro)
+        cur = next(chunks, None)
+        while cur is not None:
+            nxt = next(chunks, None)
+            x2d, host = layout.to2d(cur)
+            y = stream.push(x2d, final=nxt is None)
+            if y.shape[1] > 0:
+                yield layout.from2d(y, host)
+            cur = nxt
+    finally:
+        stream.close()
+
+
+# ---------------------------------------------------------------------------
+# windowed DFT / periodogram / Welch / STFT
+# (reference core/numerical.py:635-1087)
+# ---------------------------------------------------------------------------
+def _window_and_scale(window, nwin, fs, scaling):
+    """Window coefficients (periodic, scipy.signal.get_window) and
+    sqrt(norm) exactly as core/numerical.py:694, :703-716."""
+    coeffs = sps.get_window(window, nwin)
+    if scaling == "spectrum":
+        norm = 1 / np.sum(coeffs) ** 2
+    elif scaling == "density":
+        norm = 1 / (fs * np.sum(coeffs ** 2))
+    else:
+        raise ValueError("Unknown scaling: {}".format(scaling))
+    return coeffs, float(np.sqrt(norm))
+
+
+def _one_shot(arr, fs, nfft, window, axis, detrend, scaling, mode):
+    axis = normalize_axis(axis, arr.ndim)
+    nsamples = arr.shape[axis]
+    if nsamples == 0 or nfft < 1:
+        raise ValueError(
+            f"Invalid number of FFT data points ({min(nsamples, nfft)}) "
+            "specified.")
+    if detrend not in _lib.DETREND:
+        raise ValueError("Trend type must be 'linear' or 'constant'.")
+    if nfft < nsamples:
+        # the reference crops along axis=-1 whatever `axis` is
+        # (core/numerical.py:688); the sample axis is used here
+        arr = slice_along_axis(arr, 0, nfft, axis=axis)
+        nsamples = nfft
+    coeffs, scale = _window_and_scale(window, nsamples, fs, scaling)
+    layout = dev.Layout(arr.shape, axis)
+    spec = dev.SpecStream(nsamples, nfft, nsamples, coeffs, scale, detrend,
+                          mode, layout.nch)
+    try:
+        x2d, host = layout.to2d(arr)
+        out = spec.push(x2d)          # (1, nch, nfreq)
+        res = layout.from2d(out[0], host)
+    finally:
+        spec.close()
+    return np.fft.rfftfreq(nfft, d=1 / fs), res
+
+
+def modified_dft(arr, fs, nfft, window, axis, detrend, scaling):
+    """Windowed DFT of a real array along axis (core/numerical.py:635-718):
+    detrend, window, rFFT to ``nfft`` points (cropping or zero padding), scale
+    by sqrt(norm).  Returns (freqs, complex array with nfft//2+1 along axis)."""
+    return _one_shot(arr, fs, int(nfft), window, axis, detrend, scaling,
+                     _lib.SPEC_DFT_SEGMENTS)
+
+
+def periodogram(arr, fs, nfft=None, window="hann", axis=-1,
+                detrend="constant", scaling="density"):
+    """Windowed periodogram (core/numerical.py:721-796): |modified DFT|^2 with
+    every bin but DC (and Nyquist for even nfft) doubled."""
+    nfft = arr.shape[axis] if not nfft else int(nfft)
+    return _one_shot(arr, fs, nfft, window, axis, detrend, scaling,
+                     _lib.SPEC_PSD_SEGMENTS)
+
+
+def _spectra_estimatives(pro, fs, nfft, window, overlap, axis, detrend,
+                         scaling, func, **kwargs):
+    """One estimate per nfft-sample segment, ``stride = nfft - int(nfft *
+    overlap)`` apart; a trailing partial segment is dropped
+    (core/numerical.py:799-849).  ``func`` selects the estimate: periodogram
+    -> PSD, modified_dft -> complex DFT.  The reference's FIFO lives on the
+    device inside the ``osz_spec`` handle."""
+    noverlap = int(nfft * overlap)
+    stride = nfft - noverlap
+    mode = (_lib.SPEC_PSD_SEGMENTS if func is periodogram
+            else _lib.SPEC_DFT_SEGMENTS)
+    coeffs, scale = _window_and_scale(window, nfft, fs, scaling)
+    layout = dev.Layout(pro.shape, axis)
+    spec = dev.SpecStream(nfft, nfft, stride, coeffs, scale, detrend, mode,
+                          layout.nch)
+    try:
+        for arr in pro:
+            x2d, host = layout.to2d(arr)
+            if x2d.shape[1] == 0:
+                continue
+            out = spec.push(x2d)               # (nseg, nch, nfreq)
+            nseg = out.shape[0]
+            if nseg == 0:
+                continue
+            out = out.reshape((nseg,) + layout.other + (out.shape[-1],))
+            out = out.movedim(-1, layout.axis + 1)
+            out = out.cpu().numpy() if host else out
+            for s in range(nseg):
+                yield out[s]
+    finally:
+        spec.close()
+
+
+def welch(pro, fs, nfft, window, overlap, axis, detrend, scaling):
+    """Producer of per-segment PS(D) estimates (core/numerical.py:852-947).
+    Returns (freqs, producer); the producer's ``shape[axis]`` reports the
+    segment count in the reference's float arithmetic (:941) although every
+    yielded array has nfft//2+1 entries along axis (quirk Q7)."""
+    if scaling not in ("spectrum", "density"):
+        raise ValueError("Unknown scaling: {}".format(scaling))
+    genfunc = partial(_spectra_estimatives, pro, fs, nfft, window, overlap,
+                      axis, detrend, scaling, func=periodogram)
+    freqs = np.fft.rfftfreq(nfft, 1 / fs)
+    nsegs = int((pro.shape[axis] - nfft) // (nfft * (1 - overlap)) + 1)
+    shape = list(pro.shape)
+    shape[axis] = nsegs
+    result = producer(genfunc, chunksize=len(freqs), axis=axis, shape=shape)
+    return freqs, result
+
+
+def stft(pro, fs, nfft, window, overlap, axis, detrend, scaling, boundary,
+         padded):
+    """Producer of per-segment modified DFTs (core/numerical.py:950-1087).
+    ``boundary`` zero-extends nfft//2 both sides (:1041-1044); ``padded``
+    appends a whole stride of zeros when N % stride != 0 (:1046-1051, quirk
+    Q8); segment times as :1076-1083.  Returns (freqs, time, producer)."""
+    if scaling not in ("spectrum", "density"):
+        raise ValueError("Unknown scaling: {}".format(scaling))
+    noverlap = int(nfft * overlap)
+    stride = nfft - noverlap
+    data = pro
+    if boundary:
+        data = protools.pad(data, nfft // 2, axis=pro.axis)
+    if padded:
+        nsamples = pro.shape[axis]
+        amt = stride if nsamples % stride else 0
+        data = protools.pad(data, [0, amt], axis=pro.axis)
+
+    genfunc = partial(_spectra_estimatives, data, fs, nfft, window, overlap,
+                      axis, detrend, scaling, func=modified_dft)
+    freqs = np.fft.rfftfreq(nfft, 1 / fs)
+    nsegs = int((data.shape[axis] - nfft) // (nfft * (1 - overlap)) + 1)
+    shape = list(data.shape)
+    shape[axis] = nsegs
+    if boundary:
+        time = 1 / fs * np.arange(0, data.shape[axis] - nfft + 1,
+                                  nfft - noverlap)
+    else:
+        time = 1 / fs * np.arange(nfft // 2,
+                                  data.shape[axis] + 1 - nfft // 2,
+                                  nfft - noverlap)
+    result = producer(genfunc, chunksize=len(freqs), axis=axis, shape=shape)
+    return freqs, time, result

@@ -1,0 +1,52 @@
+// common.h -- shared host-side plumbing for libosz_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/osz_hip.h"
+
+namespace osz {
+
+// thread-local last-error text behind osz_last_error()
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+#define OSZ_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess)                                                \
+            return osz::fail(OSZ_ERR_HIP, "%s: %s (%s:%d)", #call,           \
+                             hipGetErrorString(e_), __FILE__, __LINE__);     \
+    } while (0)
+
+#define OSZ_REQUIRE(cond, ...)                                               \
+    do {                                                                     \
+        if (!(cond)) return osz::fail(OSZ_ERR_INVALID, __VA_ARGS__);         \
+    } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+// Optional per-kernel timing with HIP events on the launch stream
+// (osz_profile_enable / osz_profile_query): bench.py uses it to get each
+// kernel's average duration live, inside the timed region.
+bool profile_on();
+void profile_begin(const char *name, hipStream_t st);
+void profile_end(hipStream_t st);
+struct KernelTimer {
+    hipStream_t st;
+    bool on;
+    KernelTimer(const char *name, hipStream_t s) : st(s), on(profile_on()) {
+        if (on) profile_begin(name, st);
+    }
+    ~KernelTimer() {
+        if (on) profile_end(st);
+    }
+};
+
+}  // namespace osz

@@ -1,0 +1,258 @@
+// fft4096.h -- a 4096-point complex float64 FFT for one 256-thread workgroup,
+// 16 points per thread in registers, three radix-16 passes with two LDS
+// exchanges.  Used by K1 (overlap-add FIR: two real blocks ride one complex
+// transform) and K5 (Welch/STFT: two real segments per transform).
+//
+// Index algebra (n = 256 n2 + 16 n1 + n0,  k = k0 + 16 k1 + 256 k2):
+//   X[k] = sum_n0 W16^(n0 k2) W256^(n0 k1) W4096^(n0 k0)
+//          sum_n1 W16^(n1 k1) W256^(n1 k0)  sum_n2 W16^(n2 k0) x[n]
+//   pass 1  layout A: thread t = n0 + 16 n1, register j = n2 -> k0
+//           twiddle T1[k0][t] = W4096^(t k0)          (= W256^(n1 k0) W4096^(n0 k0))
+//   pass 2  layout B: thread t = k0 + 16 n0, register j = n1 -> k1
+//           twiddle T2[n0][k1] = W256^(n0 k1)
+//   pass 3  layout C: thread t = k0 + 16 k1, register j = n0 -> k2
+//   so input x[256 j + t] and output X[256 j + t] are both read/written with
+//   consecutive lanes on consecutive elements (coalesced), no bit reversal.
+// The inverse runs the same passes backwards with conjugated twiddles
+// (1/4096 is folded into the caller's spectrum).
+//
+// LDS: separate re/im planes of doubles (ds_read/write_b64).  Exchange 1 uses
+// slot1 = k0*258 + n1*16 + n0, exchange 2 uses slot2 = n0*272 + k1*16 + k0:
+// the writer side is always lane-contiguous, the reader side strides 258
+// (= 2 mod 32) resp. 272 (= 16 mod 32) doubles, which keeps the 32-lane b64
+// read groups conflict free.
+//
+// The phase functions are __host__ __device__ so tests/fft_host_check.cpp can
+// replay the 256 threads on the CPU and pin the index math without a GPU.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define OSZ_HD __host__ __device__ __forceinline__
+#else
+#define OSZ_HD inline
+#endif
+
+namespace osz {
+namespace fft {
+
+constexpr int N = 4096;
+constexpr int NT = 256;          // threads per transform
+constexpr int S1 = 258;          // exchange-1 row stride (doubles)
+constexpr int S2 = 272;          // exchange-2 row stride (doubles)
+constexpr int PLANE = 16 * S2;   // doubles per plane (>= 16*S1)
+
+// after fwd16 register r holds logical index dr(r); inv16 expects the same
+OSZ_HD constexpr int dr(int r) { return (r >> 2) | ((r & 3) << 2); }
+
+constexpr double C1 = 0.92387953251128673848;  // cos(pi/8)
+constexpr double S1_ = 0.38268343236508978178; // sin(pi/8)
+constexpr double R2 = 0.70710678118654752440;  // sqrt(1/2)
+
+// multiply (re, im) by W16^E (forward) or its conjugate (INV)
+template <int E, bool INV>
+OSZ_HD void tw16(double &re, double &im) {
+    constexpr int e = E % 16;
+    if constexpr (e == 0) {
+        return;
+    } else if constexpr (e == 4) {  // -i (fwd) / +i (inv)
+        const double r = re;
+        if constexpr (!INV) { re = im; im = -r; } else { re = -im; im = r; }
+    } else if constexpr (e == 2) {  // (1 - i)/sqrt2  /  (1 + i)/sqrt2
+        const double r = re, i = im;
+        if constexpr (!INV) { re = (r + i) * R2; im = (i - r) * R2; }
+        else { re = (r - i) * R2; im = (i + r) * R2; }
+    } else if constexpr (e == 6) {  // (-1 - i)/sqrt2  /  (-1 + i)/sqrt2
+        const double r = re, i = im;
+        if constexpr (!INV) { re = (i - r) * R2; im = -(r + i) * R2; }
+        else { re = -(r + i) * R2; im = (r - i) * R2; }
+    } else {
+        // generic: W16^e = (c, -s) forward
+        constexpr double c = (e == 1) ? C1 : (e == 3) ? S1_ : (e == 9) ? -C1 : 0.0;
+        constexpr double s = (e == 1) ? S1_ : (e == 3) ? C1 : (e == 9) ? -S1_ : 0.0;
+        static_assert(e == 1 || e == 3 || e == 9, "unexpected radix-16 twiddle");
+        const double r = re, i = im;
+        if constexpr (!INV) { re = r * c + i * s; im = i * c - r * s; }
+        else { re = r * c - i * s; im = i * c + r * s; }
+    }
+}
+
+template <bool INV>
+OSZ_HD void dft4(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2,
+                 double &r3, double &i3) {
+    const double t0r = r0 + r2, t0i = i0 + i2;
+    const double t1r = r0 - r2, t1i = i0 - i2;
+    const double t2r = r1 + r3, t2i = i1 + i3;
+    const double t3r = r1 - r3, t3i = i1 - i3;
+    r0 = t0r + t2r; i0 = t0i + t2i;
+    r2 = t0r - t2r; i2 = t0i - t2i;
+    if constexpr (!INV) {  // X1 = t1 - i t3, X3 = t1 + i t3
+        r1 = t1r + t3i; i1 = t1i - t3r;
+        r3 = t1r - t3i; i3 = t1i + t3r;
+    } else {
+        r1 = t1r - t3i; i1 = t1i + t3r;
+        r3 = t1r + t3i; i3 = t1i - t3r;
+    }
+}
+
+// Forward 16-point DFT in place: input logical n at register n, output
+// logical k at register dr(k).
+OSZ_HD void fwd16(double *re, double *im) {
+#define OSZ_D4(a, b, c, d) dft4<false>(re[a], im[a], re[b], im[b], re[c], im[c], re[d], im[d])
+    // stage 1: over a' (n = 4a' + b): registers {b, b+4, b+8, b+12}, output c at b + 4c
+    OSZ_D4(0, 4, 8, 12); OSZ_D4(1, 5, 9, 13); OSZ_D4(2, 6, 10, 14); OSZ_D4(3, 7, 11, 15);
+    // twiddle W16^(b c) on register b + 4c
+    tw16<1, false>(re[5], im[5]);   tw16<2, false>(re[9], im[9]);   tw16<3, false>(re[13], im[13]);
+    tw16<2, false>(re[6], im[6]);   tw16<4, false>(re[10], im[10]); tw16<6, false>(re[14], im[14]);
+    tw16<3, false>(re[7], im[7]);   tw16<6, false>(re[11], im[11]); tw16<9, false>(re[15], im[15]);
+    // stage 2: over b for fixed c: registers {4c..4c+3}, output d at 4c + d (k = c + 4d)
+    OSZ_D4(0, 1, 2, 3); OSZ_D4(4, 5, 6, 7); OSZ_D4(8, 9, 10, 11); OSZ_D4(12, 13, 14, 15);
+#undef OSZ_D4
+}
+
+// Inverse (unnormalised) 16-point DFT in place: input logical k at register
+// dr(k), output logical n at register n.
+OSZ_HD void inv16(double *re, double *im) {
+#define OSZ_D4(a, b, c, d) dft4<true>(re[a], im[a], re[b], im[b], re[c], im[c], re[d], im[d])
+    OSZ_D4(0, 1, 2, 3); OSZ_D4(4, 5, 6, 7); OSZ_D4(8, 9, 10, 11); OSZ_D4(12, 13, 14, 15);
+    tw16<1, true>(re[5], im[5]);   tw16<2, true>(re[9], im[9]);   tw16<3, true>(re[13], im[13]);
+    tw16<2, true>(re[6], im[6]);   tw16<4, true>(re[10], im[10]); tw16<6, true>(re[14], im[14]);
+    tw16<3, true>(re[7], im[7]);   tw16<6, true>(re[11], im[11]); tw16<9, true>(re[15], im[15]);
+    OSZ_D4(0, 4, 8, 12); OSZ_D4(1, 5, 9, 13); OSZ_D4(2, 6, 10, 14); OSZ_D4(3, 7, 11, 15);
+#undef OSZ_D4
+}
+
+struct Tables {
+    const double *t1;  // [16][256][2]  W4096^(t k0)  (re, im)
+    const double *t2;  // [16][16][2]   W256^(n0 k1)
+};
+
+// ---- forward phases ----------------------------------------------------
+// F1: registers hold x[256 j + t] at register j (layout A).  Pass 1, twiddle,
+// store to exchange 1.
+OSZ_HD void f1(int t, double *re, double *im, const Tables &tb, double *pr, double *pi) {
+    fwd16(re, im);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k0 = dr(r);
+        if (k0 != 0) {
+            const double wr = tb.t1[(k0 * 256 + t) * 2], wi = tb.t1[(k0 * 256 + t) * 2 + 1];
+            const double a = re[r], b = im[r];
+            re[r] = a * wr - b * wi;
+            im[r] = a * wi + b * wr;
+        }
+        pr[k0 * S1 + t] = re[r];
+        pi[k0 * S1 + t] = im[r];
+    }
+}
+
+// F2: load layout B (register j = n1), pass 2, twiddle, (caller barriers), store exchange 2.
+OSZ_HD void f2_load(int t, double *re, double *im, const double *pr, const double *pi) {
+    const int k0 = t & 15, n0 = t >> 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        re[j] = pr[k0 * S1 + j * 16 + n0];
+        im[j] = pi[k0 * S1 + j * 16 + n0];
+    }
+}
+
+OSZ_HD void f2_compute(int t, double *re, double *im, const Tables &tb) {
+    const int n0 = t >> 4;
+    fwd16(re, im);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k1 = dr(r);
+        if (k1 != 0) {
+            const double wr = tb.t2[(n0 * 16 + k1) * 2], wi = tb.t2[(n0 * 16 + k1) * 2 + 1];
+            const double a = re[r], b = im[r];
+            re[r] = a * wr - b * wi;
+            im[r] = a * wi + b * wr;
+        }
+    }
+}
+
+OSZ_HD void f2_store(int t, const double *re, const double *im, double *pr, double *pi) {
+    const int k0 = t & 15, n0 = t >> 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k1 = dr(r);
+        pr[n0 * S2 + k1 * 16 + k0] = re[r];
+        pi[n0 * S2 + k1 * 16 + k0] = im[r];
+    }
+}
+
+// F3: load layout C (register j = n0), pass 3.  Afterwards register r holds
+// X[t + 256 dr(r)].
+OSZ_HD void f3(int t, double *re, double *im, const double *pr, const double *pi) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        re[j] = pr[j * S2 + t];
+        im[j] = pi[j * S2 + t];
+    }
+    fwd16(re, im);
+}
+
+// ---- inverse phases ----------------------------------------------------
+// I3: registers hold Y[t + 256 dr(r)] at register r.  Inverse pass 3, store.
+OSZ_HD void i3(int t, double *re, double *im, double *pr, double *pi) {
+    inv16(re, im);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        pr[j * S2 + t] = re[j];
+        pi[j * S2 + t] = im[j];
+    }
+}
+
+// I2: load layout B with logical k1 at register dr(k1), conj twiddle, inverse pass 2.
+OSZ_HD void i2_load(int t, double *re, double *im, const Tables &tb, const double *pr,
+                    const double *pi) {
+    const int k0 = t & 15, n0 = t >> 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k1 = dr(r);
+        double a = pr[n0 * S2 + k1 * 16 + k0], b = pi[n0 * S2 + k1 * 16 + k0];
+        if (k1 != 0) {
+            const double wr = tb.t2[(n0 * 16 + k1) * 2], wi = -tb.t2[(n0 * 16 + k1) * 2 + 1];
+            const double a2 = a * wr - b * wi;
+            b = a * wi + b * wr;
+            a = a2;
+        }
+        re[r] = a;
+        im[r] = b;
+    }
+}
+
+OSZ_HD void i2_compute_store(int t, double *re, double *im, double *pr, double *pi,
+                             bool do_store) {
+    inv16(re, im);
+    if (!do_store) return;
+    const int k0 = t & 15, n0 = t >> 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {  // register j = n1
+        pr[k0 * S1 + j * 16 + n0] = re[j];
+        pi[k0 * S1 + j * 16 + n0] = im[j];
+    }
+}
+
+// I1: load layout A with logical k0 at register dr(k0), conj twiddle, inverse
+// pass 1.  Afterwards register j holds y[256 j + t] (times 4096).
+OSZ_HD void i1(int t, double *re, double *im, const Tables &tb, const double *pr,
+               const double *pi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k0 = dr(r);
+        double a = pr[k0 * S1 + t], b = pi[k0 * S1 + t];
+        if (k0 != 0) {
+            const double wr = tb.t1[(k0 * 256 + t) * 2], wi = -tb.t1[(k0 * 256 + t) * 2 + 1];
+            const double a2 = a * wr - b * wi;
+            b = a * wi + b * wr;
+            a = a2;
+        }
+        re[r] = a;
+        im[r] = b;
+    }
+    inv16(re, im);
+}
+
+}  // namespace fft
+}  // namespace osz

@@ -1,0 +1,464 @@
+// sos.hip -- K2/K3: cascaded second-order sections (DF2T biquads) on gfx950.
+//
+// Replaces scipy.signal.sosfilt as called by the reference at
+// src/openseize/core/numerical.py:334 (forward, carried zi) and
+// :399/:402/:410 (backward sweeps of sosfiltfilt on flipped chunks).
+//
+// Parallel decomposition (time-parallel linear recurrence, exact):
+//   one workgroup per channel, NW waves; a "tile" is NW*64*T consecutive
+//   samples (in processing order), every lane owns T consecutive samples.
+//   Per section s (state z in R^2, z' = A z + B x, y = b0 x + z0):
+//     1. each lane filters its T samples from ZERO state, in registers;
+//        this yields y_zs[0..T) and the end state e_l;
+//     2. in-wave Kogge-Stone scan over lanes with the constant 2x2 matrices
+//        A^(T*2^k) gives the state at the end of every lane's block;
+//        wave aggregates go through LDS and every wave replays the (<= NW)
+//        wave-level steps with A^(64T);
+//     3. each lane adds the homogeneous response of its true start state:
+//        y[j] += (A^j s_l)[0]  (table of A^j rows, scalar loads).
+//   The tile start state per section lives in LDS ("zi resident in LDS") and
+//   is carried from tile to tile; chunk-to-chunk state is in the handle.
+//   HBM traffic: each sample is read once and written once (16 B / sample).
+//   Global<->lane-block transposition is staged through a padded LDS tile so
+//   both the HBM side (consecutive lanes -> consecutive samples) and the LDS
+//   side (row stride T+2 doubles) are conflict free.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace osz {
+
+constexpr int kSosT = 32;       // samples per lane per tile
+constexpr int kSosNW = 8;       // waves per workgroup (one channel)
+constexpr int kSosPad = 2;      // LDS row padding (doubles): stride 34 = 17 b128 slots
+constexpr int kSosMaxSec = 32;  // sections supported per handle
+
+// Per-section constants, built on the host in osz_sos_create.
+struct SosSection {
+    double b0, b1, b2, a1, a2;
+    double pad_[3];
+    double AJ[kSosT + 1][4];  // A^j, row-major 2x2; row 0 is the homogeneous y response
+    double P[6][4];           // A^(T*2^k), k = 0..5: in-wave scan steps
+    double Q[4];              // A^(64*T): wave-to-wave step
+    double PL[64][4];         // A^(T*l): lane start-state propagation
+};
+
+struct SosArgs {
+    const double *x;
+    double *y;  // may be null: state-only pass (sosfiltfilt warm-up)
+    int64_t ldx, ldy, n;
+    const SosSection *sec;
+    const double *state_in;  // (nsec, nch, 2) or null
+    const double *zi_unit;   // (nsec, 2); used when state_in is null
+    double *state_out;       // (nsec, nch, 2) or null
+    int nsec, nch;
+};
+
+__device__ __forceinline__ void mat2_apply(const double *M, double u0, double u1,
+                                           double &r0, double &r1) {
+    r0 = fma(M[0], u0, M[1] * u1);
+    r1 = fma(M[2], u0, M[3] * u1);
+}
+
+template <int T, int NW, bool REV>
+__global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a) {
+    constexpr int ROW = T + kSosPad;
+    constexpr int WAVE_ELEMS = 64 * T;
+    extern __shared__ double lds[];
+    double *tile = lds;                              // NW * 64 * ROW
+    double *agg = tile + NW * 64 * ROW;              // [2][NW][2]
+    double *sst = agg + 2 * NW * 2;                  // [2][kSosMaxSec][2]
+
+    const int c = blockIdx.x;
+    const int w = threadIdx.x >> 6;
+    const int l = threadIdx.x & 63;
+    const int64_t n = a.n;
+    const double *xrow = a.x + (int64_t)c * a.ldx;
+    double *yrow = a.y ? a.y + (int64_t)c * a.ldy : nullptr;
+    double *wl = tile + w * 64 * ROW;
+
+    // ---- initial state of every section -> LDS slot 0
+    if (threadIdx.x < a.nsec) {
+        const int s = threadIdx.x;
+        double z0, z1;
+        if (a.state_in) {
+            z0 = a.state_in[((int64_t)s * a.nch + c) * 2 + 0];
+            z1 = a.state_in[((int64_t)s * a.nch + c) * 2 + 1];
+        } else {
+            const double x0 = xrow[REV ? n - 1 : 0];
+            z0 = a.zi_unit[2 * s + 0] * x0;
+            z1 = a.zi_unit[2 * s + 1] * x0;
+        }
+        sst[(0 * kSosMaxSec + s) * 2 + 0] = z0;
+        sst[(0 * kSosMaxSec + s) * 2 + 1] = z1;
+    }
+    __syncthreads();
+
+    const int64_t tile_elems = (int64_t)NW * WAVE_ELEMS;
+    const int64_t ntiles = (n + tile_elems - 1) / tile_elems;
+    int parity = 0;  // which sst slot holds the current tile's start states
+    int aggbuf = 0;
+
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const int64_t pw = t * tile_elems + (int64_t)w * WAVE_ELEMS;  // processing-order start of this wave
+        // memory window of this wave: WAVE_ELEMS consecutive samples
+        const int64_t mem_base = REV ? (n - pw - WAVE_ELEMS) : pw;
+        const bool full = REV ? (mem_base >= 0) : (pw + WAVE_ELEMS <= n);
+
+        // ---- stage HBM -> LDS (consecutive lanes, consecutive samples)
+#pragma unroll 8
+        for (int i = 0; i < T; ++i) {
+            const int m = i * 64 + l;
+            const int64_t g = mem_base + m;
+            double v = 0.0;
+            if (full || (g >= 0 && g < n)) v = xrow[g];
+            wl[(m / T) * ROW + (m % T)] = v;
+        }
+        __syncthreads();
+
+        // ---- lane block -> registers (processing order)
+        double v[T];
+        {
+            const double *blk = wl + (REV ? (63 - l) : l) * ROW;
+#pragma unroll
+            for (int j = 0; j < T; ++j) v[j] = blk[REV ? (T - 1 - j) : j];
+        }
+        // valid samples in this lane (prefix of its block)
+        const int64_t pl = pw + (int64_t)l * T;
+        const int64_t left = n - pl;
+        const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
+        const bool wave_full = (pw + WAVE_ELEMS <= n);
+        const bool has_last = (cnt > 0) && (pl + cnt == n);
+
+        for (int s = 0; s < a.nsec; ++s) {
+            const SosSection *S = a.sec + s;
+            const double b0 = S->b0, b1 = S->b1, b2 = S->b2, na1 = -S->a1, na2 = -S->a2;
+            // 1. zero-state pass
+            double z0 = 0.0, z1 = 0.0;
+            if (wave_full) {
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const double xin = v[j];
+                    const double y = fma(b0, xin, z0);
+                    z0 = fma(na1, y, fma(b1, xin, z1));
+                    z1 = fma(na2, y, b2 * xin);
+                    v[j] = y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const double xin = v[j];
+                    const double y = fma(b0, xin, z0);
+                    const double nz0 = fma(na1, y, fma(b1, xin, z1));
+                    const double nz1 = fma(na2, y, b2 * xin);
+                    const bool ok = j < cnt;
+                    z0 = ok ? nz0 : z0;
+                    z1 = ok ? nz1 : z1;
+                    v[j] = y;
+                }
+            }
+            const double e0raw = z0, e1raw = z1;
+            // 2a. in-wave inclusive scan of end states
+            double e0 = z0, e1 = z1;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int d = 1 << k;
+                const double u0 = __shfl_up(e0, d, 64);
+                const double u1 = __shfl_up(e1, d, 64);
+                double r0, r1;
+                mat2_apply(S->P[k], u0, u1, r0, r1);
+                if (l >= d) {
+                    e0 += r0;
+                    e1 += r1;
+                }
+            }
+            double p0 = __shfl_up(e0, 1, 64);
+            double p1 = __shfl_up(e1, 1, 64);
+            if (l == 0) p0 = p1 = 0.0;
+            if (l == 63) {
+                agg[(aggbuf * NW + w) * 2 + 0] = e0;
+                agg[(aggbuf * NW + w) * 2 + 1] = e1;
+            }
+            __syncthreads();
+            // 2b. wave-level replay (every wave, uniform values)
+            double s0 = sst[(parity * kSosMaxSec + s) * 2 + 0];
+            double s1 = sst[(parity * kSosMaxSec + s) * 2 + 1];
+            double sw0 = s0, sw1 = s1;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                if (q == w) {
+                    sw0 = s0;
+                    sw1 = s1;
+                }
+                double r0, r1;
+                mat2_apply(S->Q, s0, s1, r0, r1);
+                s0 = r0 + agg[(aggbuf * NW + q) * 2 + 0];
+                s1 = r1 + agg[(aggbuf * NW + q) * 2 + 1];
+            }
+            if (threadIdx.x == 0) {
+                sst[((parity ^ 1) * kSosMaxSec + s) * 2 + 0] = s0;
+                sst[((parity ^ 1) * kSosMaxSec + s) * 2 + 1] = s1;
+            }
+            aggbuf ^= 1;
+            // lane start state
+            double ls0, ls1;
+            mat2_apply(S->PL[l], sw0, sw1, ls0, ls1);
+            ls0 += p0;
+            ls1 += p1;
+            // 3. homogeneous fix-up
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+                v[j] = fma(S->AJ[j][0], ls0, fma(S->AJ[j][1], ls1, v[j]));
+            // final state of the chunk: the lane that owns the last sample
+            if (has_last && a.state_out) {
+                double f0, f1;
+                mat2_apply(S->AJ[cnt], ls0, ls1, f0, f1);
+                a.state_out[((int64_t)s * a.nch + c) * 2 + 0] = f0 + e0raw;
+                a.state_out[((int64_t)s * a.nch + c) * 2 + 1] = f1 + e1raw;
+            }
+        }
+        parity ^= 1;
+
+        // ---- registers -> LDS -> HBM
+        if (yrow) {
+            double *blk = wl + (REV ? (63 - l) : l) * ROW;
+#pragma unroll
+            for (int j = 0; j < T; ++j) blk[REV ? (T - 1 - j) : j] = v[j];
+            __syncthreads();
+#pragma unroll 8
+            for (int i = 0; i < T; ++i) {
+                const int m = i * 64 + l;
+                const int64_t g = mem_base + m;
+                if (full || (g >= 0 && g < n)) yrow[g] = wl[(m / T) * ROW + (m % T)];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static void mat2_mul(const double *X, const double *Y, double *Z) {
+    double r[4] = {X[0] * Y[0] + X[1] * Y[2], X[0] * Y[1] + X[1] * Y[3],
+                   X[2] * Y[0] + X[3] * Y[2], X[2] * Y[1] + X[3] * Y[3]};
+    memcpy(Z, r, sizeof r);
+}
+
+static void build_section(const double *c, SosSection &S) {
+    memset(&S, 0, sizeof S);
+    const double a0 = c[3];
+    S.b0 = c[0] / a0;
+    S.b1 = c[1] / a0;
+    S.b2 = c[2] / a0;
+    S.a1 = c[4] / a0;
+    S.a2 = c[5] / a0;
+    const double A[4] = {-S.a1, 1.0, -S.a2, 0.0};
+    double M[4] = {1, 0, 0, 1};
+    for (int j = 0; j <= kSosT; ++j) {
+        memcpy(S.AJ[j], M, sizeof M);
+        mat2_mul(A, M, M);
+    }
+    // A^T, then squarings
+    double Pk[4];
+    memcpy(Pk, S.AJ[kSosT], sizeof Pk);
+    for (int k = 0; k < 6; ++k) {
+        memcpy(S.P[k], Pk, sizeof Pk);
+        mat2_mul(Pk, Pk, Pk);
+    }
+    memcpy(S.Q, Pk, sizeof Pk);  // (A^T)^64
+    double L[4] = {1, 0, 0, 1};
+    for (int l = 0; l < 64; ++l) {
+        memcpy(S.PL[l], L, sizeof L);
+        mat2_mul(S.AJ[kSosT], L, L);
+    }
+}
+
+}  // namespace osz
+
+using namespace osz;
+
+struct osz_sos_s {
+    int nsec, nch;
+    SosSection *dsec;   // device
+    double *dstate;     // device (nsec, nch, 2): carried forward state
+    double *dtmp;       // device (nsec, nch, 2): warm-up state of sosfiltfilt
+    double *dzi;        // device (nsec, 2): sosfilt_zi of this cascade
+};
+
+static size_t sos_lds_bytes() {
+    return sizeof(double) * ((size_t)kSosNW * 64 * (kSosT + kSosPad) + 2 * kSosNW * 2 +
+                             2 * kSosMaxSec * 2);
+}
+
+template <bool REV>
+static int sos_launch(const SosArgs &a, hipStream_t st) {
+    auto kern = sos_kernel<kSosT, kSosNW, REV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sos_lds_bytes()));
+        attr_set = true;
+    }
+    {
+        KernelTimer kt(REV ? (a.y ? "sos_bwd" : "sos_warmup") : "sos_fwd", st);
+        hipLaunchKernelGGL(kern, dim3(a.nch), dim3(kSosNW * 64), sos_lds_bytes(), st, a);
+    }
+    OSZ_HIP(hipGetLastError());
+    return OSZ_OK;
+}
+
+extern "C" {
+
+int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
+    OSZ_REQUIRE(h && sos, "osz_sos_create: null argument");
+    OSZ_REQUIRE(nsec >= 1 && nsec <= kSosMaxSec, "osz_sos_create: nsec=%d not in [1, %d]",
+                nsec, kSosMaxSec);
+    OSZ_REQUIRE(nch >= 1, "osz_sos_create: nch=%d must be positive", nch);
+    for (int s = 0; s < nsec; ++s)
+        OSZ_REQUIRE(sos[6 * s + 3] == 1.0, "sos[:, 3] should be all ones (section %d)", s);
+    std::vector<SosSection> secs(nsec);
+    for (int s = 0; s < nsec; ++s) build_section(sos + 6 * s, secs[s]);
+    osz_sos_s *p = new osz_sos_s();
+    p->nsec = nsec;
+    p->nch = nch;
+    const size_t sb = sizeof(double) * (size_t)nsec * nch * 2;
+    OSZ_HIP(hipMalloc(&p->dsec, sizeof(SosSection) * nsec));
+    OSZ_HIP(hipMalloc(&p->dstate, sb));
+    OSZ_HIP(hipMalloc(&p->dtmp, sb));
+    OSZ_HIP(hipMalloc(&p->dzi, sizeof(double) * nsec * 2));
+    OSZ_HIP(hipMemcpy(p->dsec, secs.data(), sizeof(SosSection) * nsec, hipMemcpyHostToDevice));
+    OSZ_HIP(hipMemset(p->dstate, 0, sb));
+    // steady-state unit-step state of each section (what scipy.signal.sosfilt_zi
+    // returns at numerical.py:378): with section DC gain g and unit input,
+    // z0 = g - b0, z1 = b2 - a2*g; the next section sees the input scaled by g.
+    std::vector<double> zi(2 * nsec);
+    double scale = 1.0;
+    for (int s = 0; s < nsec; ++s) {
+        const SosSection &S = secs[s];
+        const double g = (S.b0 + S.b1 + S.b2) / (1.0 + S.a1 + S.a2);
+        zi[2 * s + 0] = scale * (g - S.b0);
+        zi[2 * s + 1] = scale * (S.b2 - S.a2 * g);
+        scale *= g;
+    }
+    OSZ_HIP(hipMemcpy(p->dzi, zi.data(), sizeof(double) * 2 * nsec, hipMemcpyHostToDevice));
+    *h = p;
+    return OSZ_OK;
+}
+
+int osz_sos_set_zi_unit(osz_sos_t h, const double *zi_unit) {
+    OSZ_REQUIRE(h && zi_unit, "osz_sos_set_zi_unit: null argument");
+    OSZ_HIP(hipMemcpy(h->dzi, zi_unit, sizeof(double) * 2 * h->nsec, hipMemcpyHostToDevice));
+    return OSZ_OK;
+}
+
+int osz_sos_destroy(osz_sos_t h) {
+    if (!h) return OSZ_OK;
+    (void)hipFree(h->dsec);
+    (void)hipFree(h->dstate);
+    (void)hipFree(h->dtmp);
+    (void)hipFree(h->dzi);
+    delete h;
+    return OSZ_OK;
+}
+
+int osz_sos_set_state(osz_sos_t h, const double *zi, void *stream) {
+    OSZ_REQUIRE(h, "osz_sos_set_state: null handle");
+    const size_t sb = sizeof(double) * (size_t)h->nsec * h->nch * 2;
+    hipStream_t st = as_stream(stream);
+    if (zi) {
+        OSZ_HIP(hipMemcpyAsync(h->dstate, zi, sb, hipMemcpyHostToDevice, st));
+    } else {
+        OSZ_HIP(hipMemsetAsync(h->dstate, 0, sb, st));
+    }
+    OSZ_HIP(hipStreamSynchronize(st));
+    return OSZ_OK;
+}
+
+int osz_sos_get_state(osz_sos_t h, double *zf, void *stream) {
+    OSZ_REQUIRE(h && zf, "osz_sos_get_state: null argument");
+    const size_t sb = sizeof(double) * (size_t)h->nsec * h->nch * 2;
+    hipStream_t st = as_stream(stream);
+    OSZ_HIP(hipMemcpyAsync(zf, h->dstate, sb, hipMemcpyDeviceToHost, st));
+    OSZ_HIP(hipStreamSynchronize(st));
+    return OSZ_OK;
+}
+
+__global__ void sos_scale_state_kernel(double *state, const double *zi_unit, const double *x,
+                                       int64_t ldx, int64_t col, int nsec, int nch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsec * nch) return;
+    const int s = i / nch, c = i % nch;
+    const double x0 = x[(int64_t)c * ldx + col];
+    state[2 * i + 0] = zi_unit[2 * s + 0] * x0;
+    state[2 * i + 1] = zi_unit[2 * s + 1] * x0;
+}
+
+int osz_sos_set_state_scaled(osz_sos_t h, const double *x, int64_t ldx, int64_t col,
+                             void *stream) {
+    OSZ_REQUIRE(h && x, "osz_sos_set_state_scaled: null argument");
+    hipStream_t st = as_stream(stream);
+    const int total = h->nsec * h->nch;
+    hipLaunchKernelGGL(sos_scale_state_kernel, dim3((total + 255) / 256), dim3(256), 0, st,
+                       h->dstate, h->dzi, x, ldx, col, h->nsec, h->nch);
+    OSZ_HIP(hipGetLastError());
+    return OSZ_OK;
+}
+
+int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y, int64_t ldy, int64_t n,
+                    void *stream) {
+    OSZ_REQUIRE(h && x && y, "osz_sos_forward: null argument");
+    OSZ_REQUIRE(n >= 0 && ldx >= n && ldy >= n, "osz_sos_forward: n=%lld ldx=%lld ldy=%lld",
+                (long long)n, (long long)ldx, (long long)ldy);
+    if (n == 0) return OSZ_OK;
+    SosArgs a{};
+    a.x = x;
+    a.y = y;
+    a.ldx = ldx;
+    a.ldy = ldy;
+    a.n = n;
+    a.sec = h->dsec;
+    a.state_in = h->dstate;
+    a.zi_unit = nullptr;
+    a.state_out = h->dstate;
+    a.nsec = h->nsec;
+    a.nch = h->nch;
+    return sos_launch<false>(a, as_stream(stream));
+}
+
+int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t na,
+                          const double *fb, int64_t ldfb, int64_t nb, double *y, int64_t ldy,
+                          void *stream) {
+    OSZ_REQUIRE(h && fa && y, "osz_sosfiltfilt_chunk: null argument");
+    OSZ_REQUIRE(na >= 1 && ldfa >= na && ldy >= na, "osz_sosfiltfilt_chunk: bad chunk a");
+    OSZ_REQUIRE(!fb || (nb >= 1 && ldfb >= nb), "osz_sosfiltfilt_chunk: bad chunk b");
+    hipStream_t st = as_stream(stream);
+    SosArgs a{};
+    a.sec = h->dsec;
+    a.nsec = h->nsec;
+    a.nch = h->nch;
+    a.zi_unit = h->dzi;
+    if (fb) {
+        // warm-up over the next chunk: state only (numerical.py:397-399)
+        a.x = fb;
+        a.ldx = ldfb;
+        a.n = nb;
+        a.y = nullptr;
+        a.ldy = 0;
+        a.state_in = nullptr;
+        a.state_out = h->dtmp;
+        int rc = sos_launch<true>(a, st);
+        if (rc) return rc;
+        a.state_in = h->dtmp;
+    } else {
+        a.state_in = nullptr;  // zi_unit * fa[:, na-1]  (numerical.py:408-410)
+    }
+    a.x = fa;
+    a.ldx = ldfa;
+    a.n = na;
+    a.y = y;
+    a.ldy = ldy;
+    a.state_out = nullptr;
+    return sos_launch<true>(a, st);
+}
+
+}  // extern "C"

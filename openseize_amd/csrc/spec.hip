@@ -1,0 +1,385 @@
+// spec.hip -- K5/K6: streaming segmenter + detrend + window + real FFT
+// (+ power, one-sided doubling and segment averaging) on gfx950.
+//
+// Replaces, per nfft-sample segment, the reference's call chain
+//   _spectra_estimatives FIFO   src/openseize/core/numerical.py:799-849
+//   scipy.signal.detrend        :691     get_window * x   :694-695
+//   np.fft.rfft                 :699     X *= sqrt(norm)  :703-716
+//   periodogram re^2+im^2, x2   :782-794
+//   psd running mean            src/openseize/spectra/estimators.py:149-152
+//
+// General-nfft path (this file): a "prep" kernel gathers every complete
+// segment from (carry ++ chunk), removes the trend, applies the window and
+// writes one row per (segment, channel); rocFFT runs ONE batched r2c over
+// all rows; a "post" kernel scales and either stores the complex DFT, stores
+// the periodogram, or folds the periodograms of the batch into the running
+// sum in a fixed order (deterministic, no atomics).  The FIFO of the
+// reference becomes a (nch, < nfft) carry buffer on the device.
+#include <rocfft/rocfft.h>
+
+#include <map>
+#include <vector>
+
+#include "common.h"
+
+namespace osz {
+
+#define OSZ_FFT(call)                                                               \
+    do {                                                                            \
+        rocfft_status s_ = (call);                                                  \
+        if (s_ != rocfft_status_success)                                            \
+            return osz::fail(OSZ_ERR_HIP, "%s: rocfft status %d (%s:%d)", #call, (int)s_, \
+                             __FILE__, __LINE__);                                   \
+    } while (0)
+
+struct PrepArgs {
+    const double *x;      // chunk (nch, n)
+    const double *carry;  // (nch, ncap): first ncarry columns valid
+    double *rows;         // (nseg*nch, nfft)
+    const double *window;
+    int64_t ldx;
+    int64_t ncarry, ncap;
+    int64_t seg0;         // first segment of this batch
+    int nwin, nfft, stride, nch, detrend;  // nwin samples per segment, zero-padded to nfft
+};
+
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+
+// grid: (nseg_batch, nch); block 256
+__global__ __launch_bounds__(256) void spec_prep_kernel(PrepArgs a) {
+    __shared__ double red[4];
+    const int seg = blockIdx.x;
+    const int c = blockIdx.y;
+    const int64_t v0 = (a.seg0 + seg) * (int64_t)a.stride;  // virtual start in carry ++ chunk
+    const double *cr = a.carry + (int64_t)c * a.ncap;
+    const double *xr = a.x + (int64_t)c * a.ldx;
+    double *row = a.rows + ((int64_t)seg * a.nch + c) * a.nfft;
+    auto sample = [&](int i) -> double {
+        const int64_t v = v0 + i;
+        return v < a.ncarry ? cr[v] : xr[v - a.ncarry];
+    };
+    // trend: mean, and for 'linear' the least-squares slope about the centre
+    double s0 = 0.0, s1 = 0.0;
+    const double mid = 0.5 * (a.nwin - 1);
+    for (int i = threadIdx.x; i < a.nwin; i += 256) {
+        const double v = sample(i);
+        s0 += v;
+        s1 += (i - mid) * v;
+    }
+    const double mean = block_sum(s0, red) / a.nwin;
+    double slope = 0.0;
+    if (a.detrend == OSZ_DETREND_LINEAR) {
+        const double sxy = block_sum(s1, red);
+        // sum (i - mid)^2 = n (n^2 - 1) / 12
+        const double sxx = (double)a.nwin * ((double)a.nwin * a.nwin - 1.0) / 12.0;
+        slope = sxx > 0 ? sxy / sxx : 0.0;
+    }
+    for (int i = threadIdx.x; i < a.nfft; i += 256)
+        row[i] = i < a.nwin ? (sample(i) - mean - slope * (i - mid)) * a.window[i] : 0.0;
+}
+
+struct PostArgs {
+    const double *spec;  // (nseg*nch, nfreq) complex interleaved
+    double *out;         // SEGMENTS: (nseg, nch, nfreq) f64 or c128; MEAN: accumulator (nch, nfreq)
+    int64_t nseg;
+    int nfreq, nch, nfft, mode;
+    double scale;
+};
+
+// grid: (ceil(nfreq/256), nch)
+__global__ void spec_post_kernel(PostArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (k >= a.nfreq) return;
+    // one-sided doubling: every bin but DC and (even nfft) Nyquist
+    const bool dbl = (k != 0) && !((a.nfft % 2 == 0) && k == a.nfreq - 1);
+    double acc = 0.0;
+    for (int64_t s = 0; s < a.nseg; ++s) {
+        const int64_t idx = ((int64_t)s * a.nch + c) * a.nfreq + k;
+        const double re = a.spec[2 * idx], im = a.spec[2 * idx + 1];
+        if (a.mode == OSZ_SPEC_DFT_SEGMENTS) {
+            a.out[2 * idx] = re * a.scale;
+            a.out[2 * idx + 1] = im * a.scale;
+        } else {
+            const double sr = re * a.scale, si = im * a.scale;
+            double p = sr * sr + si * si;
+            if (dbl) p *= 2.0;
+            if (a.mode == OSZ_SPEC_PSD_SEGMENTS)
+                a.out[idx] = p;
+            else
+                acc += p;
+        }
+    }
+    if (a.mode == OSZ_SPEC_PSD_MEAN) a.out[(int64_t)c * a.nfreq + k] += acc;
+}
+
+// newcarry = virtual[consumed : total)
+__global__ void spec_carry_kernel(const double *x, int64_t ldx, const double *carry,
+                                  double *newcarry, int64_t ncap, int64_t ncarry,
+                                  int64_t consumed, int64_t nnew) {
+    const int c = blockIdx.y;
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nnew) return;
+    const int64_t v = consumed + q;
+    newcarry[(int64_t)c * ncap + q] =
+        v < ncarry ? carry[(int64_t)c * ncap + v] : x[(int64_t)c * ldx + (v - ncarry)];
+}
+
+}  // namespace osz
+
+using namespace osz;
+
+struct osz_spec_s {
+    int nwin, nfft, stride, nfreq, detrend, mode, nch;
+    double scale;
+    double *dwindow;
+    double *dcarry[2];
+    int cur;
+    int64_t ncarry, ncap;
+    double *dsum;       // (nch, nfreq) PSD_MEAN accumulator
+    int64_t count;      // segments accumulated
+    // batched FFT staging, grow-only
+    double *drows, *dspec;
+    int64_t rows_cap;   // rows the staging buffers hold
+    void *dwork;
+    size_t work_cap;
+    std::map<int64_t, rocfft_plan> *plans;  // keyed by batch (rows)
+};
+
+static const int64_t kSpecMaxElems = (int64_t)1 << 27;  // staging doubles per batch (1 GiB)
+
+static int spec_plan(osz_spec_s *h, int64_t rows, rocfft_plan *out) {
+    auto it = h->plans->find(rows);
+    if (it != h->plans->end()) {
+        *out = it->second;
+        return OSZ_OK;
+    }
+    static bool setup_done = false;
+    if (!setup_done) {
+        OSZ_FFT(rocfft_setup());
+        setup_done = true;
+    }
+    rocfft_plan plan = nullptr;
+    size_t len[1] = {(size_t)h->nfft};
+    OSZ_FFT(rocfft_plan_create(&plan, rocfft_placement_notinplace,
+                               rocfft_transform_type_real_forward, rocfft_precision_double, 1, len,
+                               (size_t)rows, nullptr));
+    (*h->plans)[rows] = plan;
+    *out = plan;
+    return OSZ_OK;
+}
+
+extern "C" {
+
+int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride, const double *window,
+                    double scale, int detrend, int mode, int nch) {
+    OSZ_REQUIRE(h && window, "osz_spec_create: null argument");
+    OSZ_REQUIRE(nwin >= 1 && nfft >= nwin && stride >= 1 && stride <= nwin && nch >= 1,
+                "osz_spec_create: nwin=%d nfft=%d stride=%d nch=%d", nwin, nfft, stride, nch);
+    OSZ_REQUIRE(detrend == OSZ_DETREND_CONSTANT || detrend == OSZ_DETREND_LINEAR,
+                "osz_spec_create: unknown detrend %d", detrend);
+    OSZ_REQUIRE(mode >= OSZ_SPEC_PSD_MEAN && mode <= OSZ_SPEC_DFT_SEGMENTS,
+                "osz_spec_create: unknown mode %d", mode);
+    osz_spec_s *p = new osz_spec_s();
+    p->nwin = nwin;
+    p->nfft = nfft;
+    p->stride = stride;
+    p->nfreq = nfft / 2 + 1;
+    p->detrend = detrend;
+    p->mode = mode;
+    p->nch = nch;
+    p->scale = scale;
+    p->cur = 0;
+    p->ncarry = 0;
+    p->ncap = nwin;  // carry always holds < nwin samples
+    p->count = 0;
+    p->drows = p->dspec = nullptr;
+    p->rows_cap = 0;
+    p->dwork = nullptr;
+    p->work_cap = 0;
+    p->plans = new std::map<int64_t, rocfft_plan>();
+    const size_t cb = sizeof(double) * (size_t)nch * p->ncap;
+    const size_t ab = sizeof(double) * (size_t)nch * p->nfreq;
+    OSZ_HIP(hipMalloc(&p->dwindow, sizeof(double) * nwin));
+    OSZ_HIP(hipMalloc(&p->dcarry[0], cb));
+    OSZ_HIP(hipMalloc(&p->dcarry[1], cb));
+    OSZ_HIP(hipMalloc(&p->dsum, ab));
+    OSZ_HIP(hipMemcpy(p->dwindow, window, sizeof(double) * nwin, hipMemcpyHostToDevice));
+    OSZ_HIP(hipMemset(p->dsum, 0, ab));
+    *h = p;
+    return OSZ_OK;
+}
+
+int osz_spec_destroy(osz_spec_t h) {
+    if (!h) return OSZ_OK;
+    for (auto &kv : *h->plans) rocfft_plan_destroy(kv.second);
+    delete h->plans;
+    (void)hipFree(h->dwindow);
+    (void)hipFree(h->dcarry[0]);
+    (void)hipFree(h->dcarry[1]);
+    (void)hipFree(h->dsum);
+    (void)hipFree(h->drows);
+    (void)hipFree(h->dspec);
+    (void)hipFree(h->dwork);
+    delete h;
+    return OSZ_OK;
+}
+
+int osz_spec_reset(osz_spec_t h, void *stream) {
+    OSZ_REQUIRE(h, "osz_spec_reset: null handle");
+    h->ncarry = 0;
+    h->count = 0;
+    OSZ_HIP(hipMemsetAsync(h->dsum, 0, sizeof(double) * (size_t)h->nch * h->nfreq,
+                           as_stream(stream)));
+    return OSZ_OK;
+}
+
+int64_t osz_spec_seg_count(osz_spec_t h, int64_t n) {
+    if (!h || n < 0) return -1;
+    const int64_t total = h->ncarry + n;
+    return total >= h->nwin ? (total - h->nwin) / h->stride + 1 : 0;
+}
+
+int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *out, int64_t *nseg_out,
+                  void *stream) {
+    OSZ_REQUIRE(h, "osz_spec_push: null handle");
+    OSZ_REQUIRE(n >= 0 && (n == 0 || (x && ldx >= n)), "osz_spec_push: bad input");
+    hipStream_t st = as_stream(stream);
+    const int64_t total = h->ncarry + n;
+    const int64_t nseg = osz_spec_seg_count(h, n);
+    OSZ_REQUIRE(nseg == 0 || h->mode == OSZ_SPEC_PSD_MEAN || out, "osz_spec_push: null output");
+    if (nseg > 0) {
+        int64_t segs_per_batch = kSpecMaxElems / ((int64_t)h->nch * h->nfft);
+        if (segs_per_batch < 1) segs_per_batch = 1;
+        if (segs_per_batch > nseg) segs_per_batch = nseg;
+        if (segs_per_batch > 65535) segs_per_batch = 65535;
+        const int64_t rows_needed = segs_per_batch * h->nch;
+        if (rows_needed > h->rows_cap) {
+            OSZ_HIP(hipStreamSynchronize(st));
+            (void)hipFree(h->drows);
+            (void)hipFree(h->dspec);
+            h->drows = h->dspec = nullptr;
+            hipError_t e1 = hipMalloc(&h->drows, sizeof(double) * (size_t)rows_needed * h->nfft);
+            hipError_t e2 = hipMalloc(&h->dspec, sizeof(double) * 2 * (size_t)rows_needed * h->nfreq);
+            if (e1 != hipSuccess || e2 != hipSuccess)
+                return fail(OSZ_ERR_NOMEM, "osz_spec_push: staging for %lld rows", (long long)rows_needed);
+            h->rows_cap = rows_needed;
+        }
+        rocfft_execution_info info = nullptr;
+        OSZ_FFT(rocfft_execution_info_create(&info));
+        OSZ_FFT(rocfft_execution_info_set_stream(info, st));
+        for (int64_t s0 = 0; s0 < nseg; s0 += segs_per_batch) {
+            const int64_t ns = (nseg - s0 < segs_per_batch) ? nseg - s0 : segs_per_batch;
+            const int64_t rows = ns * h->nch;
+            PrepArgs pa{};
+            pa.x = x ? x : h->dcarry[h->cur];
+            pa.carry = h->dcarry[h->cur];
+            pa.rows = h->drows;
+            pa.window = h->dwindow;
+            pa.ldx = ldx;
+            pa.ncarry = h->ncarry;
+            pa.ncap = h->ncap;
+            pa.seg0 = s0;
+            pa.nwin = h->nwin;
+            pa.nfft = h->nfft;
+            pa.stride = h->stride;
+            pa.nch = h->nch;
+            pa.detrend = h->detrend;
+            {
+                KernelTimer kt("spec_prep", st);
+                hipLaunchKernelGGL(spec_prep_kernel, dim3((unsigned)ns, h->nch), dim3(256), 0, st,
+                                   pa);
+            }
+            OSZ_HIP(hipGetLastError());
+            rocfft_plan plan;
+            int rc = spec_plan(h, rows, &plan);
+            if (rc) return rc;
+            size_t wb = 0;
+            OSZ_FFT(rocfft_plan_get_work_buffer_size(plan, &wb));
+            if (wb > h->work_cap) {
+                OSZ_HIP(hipStreamSynchronize(st));
+                (void)hipFree(h->dwork);
+                h->dwork = nullptr;
+                if (hipMalloc(&h->dwork, wb) != hipSuccess)
+                    return fail(OSZ_ERR_NOMEM, "osz_spec_push: rocFFT work buffer %zu B", wb);
+                h->work_cap = wb;
+            }
+            if (wb) OSZ_FFT(rocfft_execution_info_set_work_buffer(info, h->dwork, wb));
+            void *in[1] = {h->drows};
+            void *outb[1] = {h->dspec};
+            {
+                KernelTimer kt("spec_rocfft", st);
+                OSZ_FFT(rocfft_execute(plan, in, outb, info));
+            }
+            PostArgs po{};
+            po.spec = h->dspec;
+            po.nseg = ns;
+            po.nfreq = h->nfreq;
+            po.nch = h->nch;
+            po.nfft = h->nfft;
+            po.mode = h->mode;
+            po.scale = h->scale;
+            if (h->mode == OSZ_SPEC_PSD_MEAN)
+                po.out = h->dsum;
+            else if (h->mode == OSZ_SPEC_PSD_SEGMENTS)
+                po.out = (double *)out + (size_t)s0 * h->nch * h->nfreq;
+            else
+                po.out = (double *)out + 2 * (size_t)s0 * h->nch * h->nfreq;
+            {
+                KernelTimer kt("spec_post", st);
+                hipLaunchKernelGGL(spec_post_kernel, dim3((h->nfreq + 255) / 256, h->nch),
+                                   dim3(256), 0, st, po);
+            }
+            OSZ_HIP(hipGetLastError());
+        }
+        OSZ_FFT(rocfft_execution_info_destroy(info));
+        h->count += nseg;
+    }
+    // new carry: everything from the start of the next segment on
+    const int64_t consumed = nseg * h->stride;
+    const int64_t nnew = total - consumed;
+    if (n > 0 || consumed > 0) {
+        if (nnew > 0) {
+            hipLaunchKernelGGL(spec_carry_kernel, dim3((unsigned)((nnew + 255) / 256), h->nch),
+                               dim3(256), 0, st, x ? x : h->dcarry[h->cur], ldx, h->dcarry[h->cur],
+                               h->dcarry[h->cur ^ 1], h->ncap, h->ncarry, consumed, nnew);
+            OSZ_HIP(hipGetLastError());
+        }
+        h->cur ^= 1;
+        h->ncarry = nnew;
+    }
+    if (nseg_out) *nseg_out = nseg;
+    return OSZ_OK;
+}
+
+int osz_spec_sum(osz_spec_t h, double **dsum, int64_t *count) {
+    OSZ_REQUIRE(h && dsum && count, "osz_spec_sum: null argument");
+    OSZ_REQUIRE(h->mode == OSZ_SPEC_PSD_MEAN, "osz_spec_sum: handle is not in PSD_MEAN mode");
+    *dsum = h->dsum;
+    *count = h->count;
+    return OSZ_OK;
+}
+
+int osz_spec_mean(osz_spec_t h, double *mean, int64_t *count, void *stream) {
+    OSZ_REQUIRE(h && mean && count, "osz_spec_mean: null argument");
+    OSZ_REQUIRE(h->mode == OSZ_SPEC_PSD_MEAN, "osz_spec_mean: handle is not in PSD_MEAN mode");
+    hipStream_t st = as_stream(stream);
+    const size_t ne = (size_t)h->nch * h->nfreq;
+    OSZ_HIP(hipMemcpyAsync(mean, h->dsum, sizeof(double) * ne, hipMemcpyDeviceToHost, st));
+    OSZ_HIP(hipStreamSynchronize(st));
+    if (h->count > 0)
+        for (size_t i = 0; i < ne; ++i) mean[i] /= (double)h->count;
+    *count = h->count;
+    return OSZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+"""IIR designs (reference filtering/iir.py:44-351): minimum order from
+SciPy's ``*ord`` helpers, coefficients from ``scipy.signal.iirfilter``
+(``IIR._build``)."""
+
+import scipy.signal as sps
+
+from openseize_amd.filtering.bases import IIR
+
+
+class Butter(IIR):
+    def __init__(self, fpass, fstop, fs, gpass=1.0, gstop=40.0, fmt="sos"):
+        super().__init__(fpass, fstop, gpass, gstop, fs, fmt)
+
+    @property
+    def order(self):
+        return sps.buttord(self.fpass, self.fstop, self.gpass, self.gstop,
+                           fs=self.fs)
+
+
+class Cheby1(IIR):
+    def __init__(self, fpass, fstop, fs, gpass=1.0, gstop=40.0, fmt="sos"):
+        super().__init__(fpass, fstop, gpass, gstop, fs, fmt)
+
+    @property
+    def order(self):
+        return sps.cheb1ord(self.fpass, self.fstop, self.gpass, self.gstop,
+                            fs=self.fs)
+
+
+class Cheby2(IIR):
+    def __init__(self, fpass, fstop, fs, gpass=1.0, gstop=40.0, fmt="sos"):
+        super().__init__(fpass, fstop, gpass, gstop, fs, fmt)
+
+    @property
+    def order(self):
+        return sps.cheb2ord(self.fpass, self.fstop, self.gpass, self.gstop,
+                            fs=self.fs)
+
+
+class Ellip(IIR):
+    def __init__(self, fpass, fstop, fs, gpass=1.0, gstop=40.0, fmt="sos"):
+        super().__init__(fpass, fstop, gpass, gstop, fs, fmt)
+
+    @property
+    def order(self):
+        return sps.ellipord(self.fpass, self.fstop, self.gpass, self.gstop,
+                            fs=self.fs)

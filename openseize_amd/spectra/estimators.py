@@ -1,0 +1,67 @@
+"""psd / stft: user API over the windowed-DFT path.
+
+Same signatures and return values as reference spectra/estimators.py:59-156
+(``psd`` -> (cnt, freqs, mean PSD)) and :160-284 (``stft`` -> (freqs, time,
+X)).  ``psd`` keeps the segment average on the device: the ``osz_spec`` handle
+accumulates the periodogram sum (K6) and the mean is taken once at the end --
+mathematically the running mean of estimators.py:149-152.
+"""
+
+import numpy as np
+
+from openseize_amd import _device as dev
+from openseize_amd import _lib
+from openseize_amd.core import numerical as nm
+from openseize_amd.core.producer import producer
+from openseize_amd.core.resources import assignable
+
+
+def psd(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
+        detrend="constant", scaling="density"):
+    """Welch power spectrum (density) estimate.  chunksize is forced to
+    ``int(fs)`` (estimators.py:141) and nfft = int(fs / resolution) (:144)."""
+    pro = producer(data, chunksize=int(fs), axis=axis)
+    nfft = int(fs / resolution)
+    freqs = np.fft.rfftfreq(nfft, 1 / fs)
+    noverlap = int(nfft * overlap)
+    stride = nfft - noverlap
+    coeffs, scale = nm._window_and_scale(window, nfft, fs, scaling)
+    axis_n = nm.normalize_axis(axis, len(pro.shape))
+    layout = dev.Layout(pro.shape, axis_n)
+    spec = dev.SpecStream(nfft, nfft, stride, coeffs, scale, detrend,
+                          _lib.SPEC_PSD_MEAN, layout.nch)
+    host = True
+    try:
+        for arr in pro:
+            x2d, host = layout.to2d(arr)
+            if x2d.shape[1]:
+                spec.push(x2d)
+        cnt, mean = spec.mean()
+    finally:
+        spec.close()
+    if cnt == 0:
+        # the reference's loop variable is unbound here (estimators.py:156)
+        raise UnboundLocalError(
+            "no complete segment: data is shorter than nfft = int(fs/resolution)")
+    result = mean.reshape(layout.other + (mean.shape[-1],))
+    result = np.moveaxis(result, -1, axis_n)
+    if not host:
+        import torch
+        result = torch.from_numpy(np.ascontiguousarray(result)).cuda()
+    return cnt, freqs, result
+
+
+def stft(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
+         detrend="constant", scaling="density", boundary=True, padded=True,
+         asarray=True):
+    """Short-time Fourier transform (estimators.py:160-284).  With
+    ``asarray`` the per-segment estimates are stacked on a new last axis when
+    they fit in memory (:279-282), else a producer is returned."""
+    pro = producer(data, chunksize=int(fs), axis=axis)
+    nfft = int(fs / resolution)
+    freqs, time, result = nm.stft(pro, fs, nfft, window, overlap, axis,
+                                  detrend, scaling, boundary, padded)
+    if asarray:
+        if assignable(result.shape):
+            result = dev.stack(list(result), axis=-1)
+    return freqs, time, result

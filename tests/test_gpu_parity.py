@@ -1,0 +1,355 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors the
+reference produced and against the CPU oracle on seeded inputs.
+
+Tolerance: BASELINE.json's north_star asks for 1e-6 relative on float64 filter
+outputs and bit-exact indexing/masking.  The float checks below use
+RTOL = 1e-9 of the output scale (three orders tighter than required).
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(float(np.max(np.abs(b))), 1e-300)
+    return float(np.max(np.abs(a - b))) / scale
+
+
+@pytest.fixture(scope="module")
+def osz():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import openseize_amd  # noqa: F401
+    from openseize_amd import _lib
+    _lib.load()      # fails loudly if the HIP library was not built
+    from openseize_amd.core import numerical as nm
+    return nm
+
+
+def producer(*a, **k):
+    from openseize_amd import producer as p
+    return p(*a, **k)
+
+
+# --------------------------------------------------------------------- FIR
+@pytest.mark.parametrize("taps", [76, 255, 256, 1024])
+@pytest.mark.parametrize("mode", ["full", "same", "valid"])
+def test_oaconvolve_golden(osz, golden, taps, mode):
+    g = golden("g2_fir.npz")
+    x, h = g["x"], g[f"h{taps}"]
+    for cs in (1000, 4096):
+        y = np.concatenate(list(osz.oaconvolve(producer(x, cs, -1), h, -1, mode)), -1)
+        assert rel_err(y, g[f"y_t{taps}_{mode}"]) < RTOL
+
+
+def test_oaconvolve_long_and_axis(osz, golden):
+    g = golden("g2_fir.npz")
+    x, h = g["x_long"], g["h76"]
+    for mode in ("full", "same", "valid"):
+        y = np.concatenate(list(osz.oaconvolve(producer(x, 16384, -1), h, -1, mode)), -1)
+        assert rel_err(y[:, :400], g[f"ylong_{mode}_head"]) < RTOL
+        assert rel_err(y[:, -400:], g[f"ylong_{mode}_tail"]) < RTOL
+        assert rel_err(y[:, ::37], g[f"ylong_{mode}_dec"]) < RTOL
+    y = np.concatenate(list(osz.oaconvolve(
+        producer(g["x3"], 700, 1), g["kaiser_h"], 1, "same")), 1)
+    assert rel_err(y, g["kaiser_axis1_same"]) < RTOL
+
+
+def test_fir_class_api(osz, golden):
+    from openseize_amd.filtering.fir import Kaiser
+    g = golden("g2_fir.npz")
+    kais = Kaiser(fpass=200, fstop=400, fs=5000, gpass=0.5, gstop=40)
+    assert np.array_equal(kais.coeffs, g["kaiser_h"])
+    xk = g["xk"]
+    for mode in ("full", "same", "valid"):
+        y = kais(xk, chunksize=2000, axis=-1, mode=mode)
+        assert isinstance(y, np.ndarray)
+        assert rel_err(y, g[f"kaiser_arr_{mode}"]) < RTOL
+        res = kais(producer(xk, 2000, -1), chunksize=2000, axis=-1, mode=mode)
+        assert [a.shape[-1] for a in res] == list(g[f"kaiser_pro_len_{mode}"])
+        assert tuple(res.shape) == tuple(g[f"kaiser_pro_shape_{mode}"])
+
+
+def test_oaconvolve_edges(osz):
+    rng = np.random.default_rng(1)
+    from oracle import oracle as orc
+    # data shorter than the window -> ValueError (reference: broadcasting ValueError)
+    with pytest.raises(ValueError):
+        list(osz.oaconvolve(producer(rng.standard_normal((2, 50)), 10, -1),
+                            np.ones(64), -1, "same"))
+    # the reference's quirk lengths: plain np.convolve answer here
+    h = np.hanning(9) / 4
+    for n in (4087, 4088, 4089, 9, 10):
+        x = rng.standard_normal((2, n))
+        for mode in ("full", "same", "valid"):
+            y = np.concatenate(list(osz.oaconvolve(producer(x, 1000, -1), h, -1, mode)), -1)
+            assert rel_err(y, orc.convolve_direct(x, h, mode)) < RTOL
+    # chunks of 1 sample, single tap, max supported taps, tiny chunks vs oracle
+    x = rng.standard_normal((3, 300))
+    for taps, cs in ((1, 7), (2049, 100000), (33, 1), (300, 299)):
+        xx = rng.standard_normal((2, 5000)) if taps > 300 else x
+        h = rng.standard_normal(taps)
+        y = np.concatenate(list(osz.oaconvolve(producer(xx, cs, -1), h, -1, "full")), -1)
+        assert rel_err(y, orc.convolve_direct(xx, h, "full")) < RTOL
+
+
+# --------------------------------------------------------------------- SOS
+FILTERS = ["butter_lp", "butter_bp6", "cheby1_bp", "butter_cls6"]
+
+
+@pytest.mark.parametrize("name", FILTERS)
+def test_sosfilt_golden(osz, golden, name):
+    g = golden("g3_sosfilt.npz")
+    x, sos = g["x"], g[f"sos_{name}"]
+    for cs in (1000, 4096):
+        y = np.concatenate(list(osz.sosfilt(producer(x, cs, -1), sos, -1)), -1)
+        assert rel_err(y, g[f"y_{name}_cs{cs}"]) < RTOL
+    y = np.concatenate(list(osz.sosfilt(producer(x, 1000, -1), sos, -1,
+                                        zi=g[f"zi_{name}"])), -1)
+    assert rel_err(y, g[f"yzi_{name}"]) < RTOL
+
+
+def test_sosfilt_axis_and_state(osz, golden):
+    g = golden("g3_sosfilt.npz")
+    y = np.concatenate(list(osz.sosfilt(producer(g["x3"], 1000, 1),
+                                        g["sos_butter_lp"], 1)), 1)
+    assert rel_err(y, g["y3_butter_lp"]) < RTOL
+    # ragged chunking (tiles, partial tiles, 1-sample chunks) against the oracle
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    import torch
+    rng = np.random.default_rng(5)
+    sos = g["sos_butter_bp6"]
+    x = rng.standard_normal((5, 70001))
+    ref, zf = orc.sosfilt(x, sos, 70001)
+    st = dev.SosStream(sos, 5)
+    xd = torch.from_numpy(x).cuda()
+    cuts = [0, 1, 2, 33, 2048, 2049, 16384 + 2049, 16384 * 3 + 7, 70000, 70001]
+    out = [st.forward(xd[:, a:b].contiguous()).cpu().numpy()
+           for a, b in zip(cuts[:-1], cuts[1:])]
+    assert rel_err(np.concatenate(out, -1), ref) < RTOL
+    assert rel_err(st.get_state(), zf) < 1e-7
+    st.close()
+
+
+@pytest.mark.parametrize("name", FILTERS)
+@pytest.mark.parametrize("cs", [200, 1000, 4096, 6007])
+def test_sosfiltfilt_golden(osz, golden, name, cs):
+    g = golden("g4_sosfiltfilt.npz")
+    y = np.concatenate(list(osz.sosfiltfilt(producer(g["x"], cs, -1),
+                                            g[f"sos_{name}"], -1)), -1)
+    assert rel_err(y, g[f"y_{name}_cs{cs}"]) < RTOL
+
+
+def test_iir_class_api(osz, golden):
+    from openseize_amd.filtering.iir import Butter
+    g = golden("g4_sosfiltfilt.npz")
+    butter = Butter(fpass=[8, 30], fstop=[3, 60], fs=500, gpass=1, gstop=40)
+    y = butter(g["x"], chunksize=2000, axis=-1, dephase=True)
+    assert isinstance(y, np.ndarray) and rel_err(y, g["cls_dephase"]) < RTOL
+    y = butter(g["x"], chunksize=2000, axis=-1, dephase=False)
+    assert rel_err(y, g["cls_causal"]) < RTOL
+
+
+def test_sos_stress_narrowband(osz):
+    """Poles close to the unit circle (0.5-4 Hz band at fs = 5 kHz): the
+    block-parallel scan must stay within tolerance of the serial recurrence."""
+    import scipy.signal as sps
+    from oracle import oracle as orc
+    sos = sps.butter(3, [0.5, 4], "bandpass", fs=5000, output="sos")
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((3, 120000)) + 5.0
+    ref, _ = orc.sosfilt(x, sos, 120000)
+    y = np.concatenate(list(osz.sosfilt(producer(x, 50000, -1), sos, -1)), -1)
+    assert rel_err(y, ref) < 1e-7
+    ref = orc.sosfiltfilt(x, sos, 50000)
+    y = np.concatenate(list(osz.sosfiltfilt(producer(x, 50000, -1), sos, -1)), -1)
+    assert rel_err(y, ref) < 1e-7
+
+
+# --------------------------------------------------------------- resampling
+@pytest.mark.parametrize("LM", [(1, 5), (3, 1), (3, 2), (2, 7), (3, 11)])
+def test_resample_golden(osz, golden, LM):
+    from openseize_amd.resampling.resampling import resample
+    g = golden("g5_resample.npz")
+    L, M = LM
+    for cs in (3000, 7001):
+        y = resample(g["x"], L, M, 5000, chunksize=cs, axis=-1)
+        assert rel_err(y, g[f"y_L{L}_M{M}_cs{cs}"]) < RTOL
+    pro = resample(producer(g["x"], 3000, -1), L, M, 5000, 3000, axis=-1)
+    assert [a.shape[-1] for a in pro] == list(g[f"len_L{L}_M{M}"])
+    assert tuple(pro.shape) == tuple(g[f"shape_L{L}_M{M}"])
+
+
+def test_resample_wrappers(osz, golden):
+    from openseize_amd.resampling.resampling import downsample, upsample, resample
+    g = golden("g5_resample.npz")
+    x = g["x"]
+    assert rel_err(downsample(x, 5, 5000, chunksize=4000, axis=-1), g["down5"]) < RTOL
+    assert rel_err(upsample(x[:, :6000], 3, 5000, chunksize=2000, axis=-1), g["up3"]) < RTOL
+    xt = np.ascontiguousarray(x[:2, :5000].T)
+    assert rel_err(downsample(xt, 5, 5000, chunksize=1000, axis=0), g["down5_axis0"]) < RTOL
+    assert downsample(x, 1, 5000, 1000) is x and resample(x, 4, 4, 5000, 1000) is x
+    with pytest.raises(ValueError):
+        downsample(x[:, :5], 5, 5000, chunksize=1000)
+
+
+# ------------------------------------------------------------------ spectra
+def test_periodogram_golden(osz, golden):
+    g = golden("g6_periodogram.npz")
+    x = g["x"]
+    for window in ("hann", "hamming", "boxcar", "blackman"):
+        for detrend in ("constant", "linear"):
+            for scaling in ("density", "spectrum"):
+                f, p = osz.periodogram(x, 500, None, window, -1, detrend, scaling)
+                assert rel_err(p, g[f"p_{window}_{detrend}_{scaling}"]) < RTOL
+    assert np.array_equal(f, g["freqs"])
+    f, X = osz.modified_dft(x, 500, 1024, "hann", -1, "constant", "density")
+    assert X.shape == g["dft_hann"].shape
+    assert np.max(np.abs(X - g["dft_hann"])) < RTOL * np.max(np.abs(g["dft_hann"]))
+    f, p = osz.periodogram(x[:, :1023], 500)
+    assert rel_err(p, g["p_odd"]) < RTOL and np.array_equal(f, g["freqs_odd"])
+    f, p = osz.periodogram(x, 500, 2048)
+    assert rel_err(p, g["p_pad2048"]) < RTOL
+    f, p = osz.periodogram(x, 500, 512, "hann", -1, "linear", "spectrum")
+    assert rel_err(p, g["p_crop512"]) < RTOL
+    with pytest.raises(ValueError):
+        osz.modified_dft(x, 500, 1024, "hann", -1, "constant", "power")
+    with pytest.raises(ValueError):
+        osz.periodogram(np.zeros((3, 0)), 500)
+
+
+def test_psd_golden(osz, golden):
+    from openseize_amd.spectra.estimators import psd
+    g = golden("g7_welch.npz")
+    x = g["x"]
+    for ov in (0.0, 0.5, 0.6):
+        cnt, f, p = psd(x, 1024, axis=-1, resolution=1.0, overlap=ov)
+        assert cnt == int(g[f"cnt_ov{ov}"])
+        assert rel_err(p, g[f"psd_ov{ov}"]) < RTOL
+        assert np.array_equal(f, g["freqs"])
+    cnt, f, p = psd(x, 1024, axis=-1, resolution=0.5, window="hamming",
+                    detrend="linear", scaling="spectrum")
+    assert cnt == int(g["cnt_hamming"])
+    assert rel_err(p, g["psd_hamming_linear_spectrum"]) < RTOL
+    cnt, f, p = psd(np.ascontiguousarray(x[:2].T), 1000, axis=0, resolution=2.0)
+    assert cnt == int(g["cnt_axis0"]) and rel_err(p, g["psd_axis0_nfft500"]) < RTOL
+
+
+def test_welch_producer(osz, golden):
+    g = golden("g7_welch.npz")
+    pro = producer(g["x"], 5000, -1)
+    f, wp = osz.welch(pro, 1024, 1024, "hann", 0.5, -1, "constant", "density")
+    segs = list(wp)
+    assert tuple(wp.shape) == tuple(g["welch_shape"])
+    assert len(segs) == int(g["welch_nseg"])
+    assert rel_err(segs[0], g["welch_seg0"]) < RTOL
+    assert rel_err(segs[-1], g["welch_seg_last"]) < RTOL
+
+
+def test_stft_golden(osz, golden):
+    from openseize_amd.spectra.estimators import stft
+    g = golden("g8_stft.npz")
+    x = g["x"]
+    for b in (True, False):
+        for p in (True, False):
+            for scaling in ("density", "spectrum"):
+                f, t, X = stft(x, 256, axis=-1, resolution=1.0, boundary=b,
+                               padded=p, scaling=scaling, asarray=True)
+                key = f"b{int(b)}_p{int(p)}_{scaling}"
+                assert X.shape == g[f"X_{key}"].shape
+                assert np.allclose(t, g[f"t_{key}"], rtol=0, atol=1e-12)
+                assert np.max(np.abs(X - g[f"X_{key}"])) < RTOL * np.max(np.abs(g[f"X_{key}"]))
+                assert np.array_equal(f, g["freqs"])
+    f, t, pro = stft(producer(x, 1000, -1), 256, axis=-1, resolution=0.5,
+                     overlap=0.75, detrend="linear", window="hamming",
+                     asarray=False)
+    assert tuple(pro.shape) == tuple(g["pro_shape"])
+    assert np.allclose(t, g["pro_t"])
+    X = np.stack(list(pro), axis=-1)
+    assert np.max(np.abs(X - g["pro_X"])) < RTOL * np.max(np.abs(g["pro_X"]))
+
+
+# ------------------------------------------- device-resident chain + masking
+def test_device_resident_chain(osz, golden):
+    """CUDA tensors in -> CUDA tensors out, FIR -> sosfiltfilt chained as
+    producers, equal to the host-fed result and to the oracle."""
+    import torch
+    from functools import partial
+    from oracle import oracle as orc
+    g = golden("g4_sosfiltfilt.npz")
+    x, sos = g["x"], g["sos_butter_bp6"]
+    h = golden("g2_fir.npz")["h256"]
+    xd = torch.from_numpy(x).cuda()
+    fir = producer(partial(osz.oaconvolve, producer(xd, 1500, -1), h, -1, "same"),
+                   1500, -1, shape=x.shape)
+    out = list(osz.sosfiltfilt(fir, sos, -1))
+    assert all(o.is_cuda for o in out)
+    y = torch.cat(out, -1).cpu().numpy()
+    ref = orc.sosfiltfilt(orc.convolve_direct(x, h, "same"), sos, 1500)
+    assert rel_err(y, ref) < RTOL
+
+
+def test_masked_producer_device(osz, golden):
+    import torch
+    g = golden("g1_producer.npz")
+    x = g["x"]
+    xd = torch.from_numpy(x).cuda()
+    for name in ("rand", "hole", "short"):
+        pro = producer(xd, 1000, -1, mask=g[f"mask_{name}"])
+        chunks = list(pro)
+        assert [c.shape[-1] for c in chunks] == list(g[f"masked_{name}_len_cs1000"])
+        y = torch.cat(chunks, -1).cpu().numpy()
+        assert np.array_equal(y, g[f"masked_{name}_cat_cs1000"])      # bit exact
+    xt = torch.from_numpy(np.ascontiguousarray(x.T)).cuda()
+    y = torch.cat(list(producer(xt, 1000, 0, mask=g["mask_rand"])), 0).cpu().numpy()
+    assert np.array_equal(y, g["masked_axis0_cat"])
+
+
+# ------------------------------------------- full-size properties (cfg shapes)
+def test_fullsize_properties(osz):
+    """BASELINE chunk shape (256 ch x 2^20): linearity of the FIR and SOS
+    paths, impulse response of the FIR = the taps, and chunking invariance of
+    the carried state -- size-independent checks that need no CPU reference."""
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev
+    C, n = 256, 1 << 20
+    h = sps.firwin(1024, 0.2)
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    a = dev.synth_normal(C, n, seed=1)
+    b = dev.synth_normal(C, n, seed=2)
+
+    def run_fir(x):
+        f = dev.FirStream(h, C)
+        y = f.push(x)
+        f.close()
+        return y
+
+    def run_sos(x, pieces=1):
+        s = dev.SosStream(sos, C)
+        out = [s.forward(p.contiguous()) for p in torch.chunk(x, pieces, dim=1)]
+        s.close()
+        return torch.cat(out, 1)
+
+    for run in (run_fir, run_sos):
+        lhs = run(a + 2.0 * b)
+        rhs = run(a) + 2.0 * run(b)
+        assert float((lhs - rhs).abs().max()) < 1e-10 * float(rhs.abs().max())
+    # impulse -> taps at every channel
+    imp = torch.zeros((C, n), dtype=torch.float64, device="cuda")
+    imp[:, 12345] = 1.0
+    y = run_fir(imp)
+    got = y[:, 12345:12345 + 1024].cpu().numpy()
+    assert np.max(np.abs(got - h[None, :])) < 1e-14
+    assert float(y[:, :12345].abs().max()) < 1e-14
+    # carried state: one chunk == seven ragged chunks
+    assert float((run_sos(a, 1) - run_sos(a, 7)).abs().max()) < 1e-10
+    # order-independent checksum is reproducible
+    assert dev.checksum(a)[0] == dev.checksum(dev.synth_normal(C, n, seed=1))[0]

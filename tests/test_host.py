@@ -1,0 +1,233 @@
+"""CPU-only tests of the host logic: producers (bit-exact indexing/masking
+against the golden vectors), the FIFO, axis helpers, filter design, shape
+planning, pickling, and that the C-ABI library loads and exports every symbol
+declared in include/osz_hip.h.  No compute call is made (no GPU here)."""
+
+import ctypes
+import os
+import pickle
+import re
+from functools import partial
+
+import numpy as np
+import pytest
+
+from openseize_amd import _lib, producer
+from openseize_amd.core import arraytools, numerical as nm, protools
+from openseize_amd.core.producer import (ArrayProducer, GenProducer,
+                                         MaskedProducer, Producer)
+from openseize_amd.core.queues import FIFOArray
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def lengths(pro, axis=-1):
+    return [a.shape[axis] for a in pro]
+
+
+# ------------------------------------------------------------ a1: arrays
+def test_array_producer_golden(golden):
+    g = golden("g1_producer.npz")
+    x = g["x"]
+    for cs in (1000, 1024, 10007, 20000):
+        pro = producer(x, cs, axis=-1)
+        assert isinstance(pro, ArrayProducer)
+        assert lengths(pro) == list(g[f"array_len_cs{cs}"])
+        assert np.array_equal(pro.to_array(), x)
+        assert pro.shape == x.shape and pro.ndim == 2
+    pro = producer(x, 3e3, axis=-1)            # float chunksize is int-coerced
+    assert pro.chunksize == 3000 and isinstance(pro.chunksize, int)
+    first = next(iter(pro))
+    assert np.shares_memory(first, x)           # views, never copies
+
+
+def test_producer_mutates_existing():
+    x = np.arange(40.0).reshape(2, 20)
+    p1 = producer(x, 5, axis=-1)
+    p2 = producer(p1, 7, axis=-1)
+    assert p2 is p1 and p1.chunksize == 7       # reference producer.py:114-117
+    assert lengths(p1) == [7, 7, 6]
+
+
+def test_sequence_and_errors():
+    parts = [np.ones((2, 3)), np.zeros((2, 4))]
+    pro = producer(parts, 5, axis=-1)
+    assert pro.shape == (2, 7) and lengths(pro) == [5, 2]
+    with pytest.raises(TypeError, match="unproducible type"):
+        producer(3.0, 5, axis=-1)
+
+    def gen():
+        yield np.ones((2, 3))
+
+    with pytest.raises(ValueError, match="requires a shape"):
+        producer(gen, 5, axis=-1)
+
+
+# ------------------------------------------------------------ a2: generators
+def test_gen_producer_golden(golden):
+    g = golden("g1_producer.npz")
+    x, cuts = g["x"], g["gen_cuts"]
+
+    def ragged(arr, cuts):
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                yield arr[:, a:b]
+
+    for cs in (1000, 4096, 20000):
+        pro = producer(ragged, cs, axis=-1, shape=x.shape, arr=x, cuts=cuts)
+        assert isinstance(pro, GenProducer)
+        assert lengths(pro) == list(g[f"gen_len_cs{cs}"])
+        assert lengths(pro) == list(g[f"gen_len_cs{cs}"])   # re-iterable
+    pro = producer(ragged, 1000, axis=-1, shape=x.shape, arr=x, cuts=cuts)
+    assert np.array_equal(pro.to_array(), g["gen_cat_cs1000"])
+    # partial of a generator function is accepted like a generator function
+    pro = producer(partial(ragged, x, cuts), 1000, axis=-1, shape=x.shape)
+    assert np.array_equal(pro.to_array(), x)
+
+
+# ------------------------------------------------------------ a3: masks
+@pytest.mark.parametrize("name", ["rand", "hole", "short"])
+def test_masked_producer_golden(golden, name):
+    g = golden("g1_producer.npz")
+    x, m = g["x"], g[f"mask_{name}"]
+    for cs in (1000, 1024):
+        pro = producer(x, cs, axis=-1, mask=m)
+        assert isinstance(pro, MaskedProducer)
+        assert lengths(pro) == list(g[f"masked_{name}_len_cs{cs}"])
+        assert tuple(pro.shape) == tuple(g[f"masked_{name}_shape_cs{cs}"])
+    pro = producer(x, 1000, axis=-1, mask=m)
+    assert np.array_equal(pro.to_array(), g[f"masked_{name}_cat_cs1000"])  # bit exact
+
+
+def test_masked_axis0_and_chunksize_setter(golden):
+    g = golden("g1_producer.npz")
+    xt = np.ascontiguousarray(g["x"].T)
+    pro = producer(xt, 1000, axis=0, mask=g["mask_rand"])
+    assert np.array_equal(np.concatenate(list(pro), 0), g["masked_axis0_cat"])
+    pro.chunksize = 512
+    assert pro.data.chunksize == 512 and pro.mask.chunksize == 512
+    assert np.array_equal(np.concatenate(list(pro), 0), g["masked_axis0_cat"])
+
+
+# ------------------------------------------------------------ a4: FIFO
+def test_fifo_semantics():
+    fifo = FIFOArray(chunksize=4, axis=-1)
+    assert fifo.empty() and fifo.qsize() == 0 and not fifo.full()
+    a = np.arange(6.0).reshape(2, 3)
+    fifo.put(a)
+    assert fifo.qsize() == 3 and not fifo.full()
+    fifo.put(a + 10)
+    assert fifo.full() and fifo.qsize() == 6
+    out = fifo.get()
+    assert out.shape == (2, 4) and fifo.qsize() == 2
+    assert np.array_equal(out, np.concatenate([a, a + 10], -1)[:, :4])
+    assert np.array_equal(fifo.queue, (a + 10)[:, 1:])
+
+
+def test_arraytools():
+    x = np.arange(24.0).reshape(2, 3, 4)
+    assert arraytools.normalize_axis(-1, 3) == 2
+    with pytest.raises(IndexError):
+        arraytools.normalize_axis(3, 3)
+    assert np.array_equal(arraytools.slice_along_axis(x, 1, 3, axis=1), x[:, 1:3])
+    a, b = arraytools.split_along_axis(x, 1, axis=2)
+    assert a.shape == (2, 3, 1) and b.shape == (2, 3, 3)
+    p = arraytools.pad_along_axis(x, [1, 2], axis=1)
+    assert p.shape == (2, 6, 4) and np.all(p[:, 0] == 0) and np.all(p[:, -2:] == 0)
+    y = arraytools.multiply_along_axis(x, np.array([1.0, 2.0, 3.0]), axis=1)
+    assert np.array_equal(y[:, 2], 3 * x[:, 2])
+
+
+def test_protools_pad():
+    x = np.arange(1000.0).reshape(4, 250)
+    pro = producer(x, chunksize=100, axis=-1)
+    padded = protools.pad(pro, [3, 10], axis=-1)
+    assert padded.shape == (4, 263)
+    assert np.array_equal(np.pad(x, [(0, 0), (3, 10)]), padded.to_array())
+    other = protools.pad(pro, 2, axis=0)
+    assert other.shape == (8, 250)
+    assert np.array_equal(np.pad(x, [(2, 2), (0, 0)]), other.to_array())
+
+
+# ------------------------------------------------------------ planning
+def test_convolved_shape_and_welch_stft_plans(golden):
+    assert nm.convolved_shape((3, 100), (9,), "full", -1) == (3, 108)
+    assert nm.convolved_shape((3, 100), (9,), "same", -1) == (3, 100)
+    assert nm.convolved_shape((3, 100), (9,), "valid", -1) == (3, 92)
+    assert nm.convolved_shape((3, 100, 2), (9,), "same", 1) == (3, 100, 2)
+    assert nm.optimal_nffts(np.ones(1024)) == 8192
+    assert nm.optimal_nffts(np.ones(203)) == 2048
+    g = golden("g7_welch.npz")
+    pro = producer(g["x"], 5000, axis=-1)
+    f, wp = nm.welch(pro, 1024, 1024, "hann", 0.5, -1, "constant", "density")
+    assert tuple(wp.shape) == tuple(g["welch_shape"]) and wp.chunksize == 513
+    assert np.array_equal(f, g["freqs"])
+    g = golden("g8_stft.npz")
+    for b in (True, False):
+        for p in (True, False):
+            pro = producer(g["x"], 256, axis=-1)
+            f, t, sp = nm.stft(pro, 256, 256, "hann", 0.5, -1, "constant",
+                               "density", b, p)
+            assert np.allclose(t, g[f"t_b{int(b)}_p{int(p)}_density"], rtol=0, atol=1e-12)
+    with pytest.raises(ValueError, match="Unknown scaling"):
+        nm.welch(pro, 256, 256, "hann", 0.5, -1, "constant", "power")
+
+
+def test_design_classes(golden):
+    from openseize_amd.filtering import fir, iir
+    g = golden("g9_design.npz")
+    assert np.array_equal(iir.Butter(fpass=100, fstop=200, fs=500).coeffs, g["sos_butter_lp"])
+    assert np.array_equal(iir.Cheby1(fpass=[200, 600], fstop=[150, 650], fs=2500).coeffs,
+                          g["sos_cheby1_bp"])
+    assert np.array_equal(iir.Cheby2(fpass=100, fstop=150, fs=1000).coeffs, g["cheby2_lp"])
+    assert np.array_equal(iir.Ellip(fpass=200, fstop=150, fs=1000).coeffs, g["ellip_hp"])
+    assert np.array_equal(fir.Hamming(fpass=[100, 200], fstop=[50, 250], fs=1000).coeffs,
+                          g["hamming_bp"])
+    c = 500.0
+    assert np.array_equal(fir.Kaiser(c - c / 10, c + c / 10, 5000, gpass=0.1, gstop=40).coeffs,
+                          g["kaiser_down5_fs5000"])
+    with pytest.raises(ValueError, match="same shape"):
+        iir.Butter(fpass=[1, 2], fstop=3, fs=100)
+
+
+def test_pickleable_pipeline():
+    """Producers wrapping every hot-path generator pickle (the reference's
+    tests/test_concurrency.py:85-149): no device handle lives on a producer."""
+    import scipy.signal as sps
+    from openseize_amd.filtering.fir import Kaiser
+    x = np.random.default_rng(0).standard_normal((3, 5000))
+    pro = producer(x, 1000, axis=-1)
+    sos = sps.butter(2, 0.2, output="sos")
+    gens = [partial(nm.oaconvolve, pro, np.ones(9), -1, "same"),
+            partial(nm.sosfilt, pro, sos, -1),
+            partial(nm.sosfiltfilt, pro, sos, -1),
+            partial(nm.polyphase_resample, pro, 1, 5, 500, Kaiser, -1)]
+    for gf in gens:
+        p = producer(gf, 1000, axis=-1, shape=x.shape)
+        q = pickle.loads(pickle.dumps(p))
+        assert q.shape == p.shape and q.chunksize == 1000
+    f, wp = nm.welch(pro, 500, 500, "hann", 0.5, -1, "constant", "density")
+    assert pickle.loads(pickle.dumps(wp)).shape == wp.shape
+
+
+def test_no_gpu_fails_loudly():
+    """Without a HIP device the product path raises; it never falls back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    x = np.zeros((2, 100))
+    with pytest.raises(RuntimeError, match="no CPU fallback|No CPU fallback|no GPU"):
+        list(nm.sosfilt(producer(x, 50, -1), np.array([[1.0, 0, 0, 1, 0, 0]]), -1))
+
+
+# ------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "osz_hip.h")).read()
+    declared = set(re.findall(r"\b(osz_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) > 35
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert os.path.exists(_lib.LIB_PATH), "build libosz_hip.so first (__graft_entry__.build)"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} not exported"
+    assert lib.osz_version() >= 100
