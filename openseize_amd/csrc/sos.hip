@@ -237,10 +237,20 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a) {
     }
 }
 
-static void mat2_mul(const double *X, const double *Y, double *Z) {
-    double r[4] = {X[0] * Y[0] + X[1] * Y[2], X[0] * Y[1] + X[1] * Y[3],
-                   X[2] * Y[0] + X[3] * Y[2], X[2] * Y[1] + X[3] * Y[3]};
-    memcpy(Z, r, sizeof r);
+// The constant matrices are powers of the companion matrix A.  For poles close
+// to the unit circle A is nearly defective and products formed in float64 lose
+// up to ~1e-9 relative accuracy at A^2048; they are therefore built in 80-bit
+// long double on the host and rounded once.
+typedef long double ld_t;
+
+static void mat2_mul(const ld_t *X, const ld_t *Y, ld_t *Z) {
+    ld_t r[4] = {X[0] * Y[0] + X[1] * Y[2], X[0] * Y[1] + X[1] * Y[3],
+                 X[2] * Y[0] + X[3] * Y[2], X[2] * Y[1] + X[3] * Y[3]};
+    for (int i = 0; i < 4; ++i) Z[i] = r[i];
+}
+
+static void mat2_store(const ld_t *M, double *out) {
+    for (int i = 0; i < 4; ++i) out[i] = (double)M[i];
 }
 
 static void build_section(const double *c, SosSection &S) {
@@ -251,24 +261,25 @@ static void build_section(const double *c, SosSection &S) {
     S.b2 = c[2] / a0;
     S.a1 = c[4] / a0;
     S.a2 = c[5] / a0;
-    const double A[4] = {-S.a1, 1.0, -S.a2, 0.0};
-    double M[4] = {1, 0, 0, 1};
+    const ld_t A[4] = {-(ld_t)S.a1, 1.0L, -(ld_t)S.a2, 0.0L};
+    ld_t M[4] = {1, 0, 0, 1}, AT[4];
     for (int j = 0; j <= kSosT; ++j) {
-        memcpy(S.AJ[j], M, sizeof M);
+        mat2_store(M, S.AJ[j]);
+        if (j == kSosT) memcpy(AT, M, sizeof M);
         mat2_mul(A, M, M);
     }
     // A^T, then squarings
-    double Pk[4];
-    memcpy(Pk, S.AJ[kSosT], sizeof Pk);
+    ld_t Pk[4];
+    memcpy(Pk, AT, sizeof Pk);
     for (int k = 0; k < 6; ++k) {
-        memcpy(S.P[k], Pk, sizeof Pk);
+        mat2_store(Pk, S.P[k]);
         mat2_mul(Pk, Pk, Pk);
     }
-    memcpy(S.Q, Pk, sizeof Pk);  // (A^T)^64
-    double L[4] = {1, 0, 0, 1};
+    mat2_store(Pk, S.Q);  // (A^T)^64
+    ld_t L[4] = {1, 0, 0, 1};
     for (int l = 0; l < 64; ++l) {
-        memcpy(S.PL[l], L, sizeof L);
-        mat2_mul(S.AJ[kSosT], L, L);
+        mat2_store(L, S.PL[l]);
+        mat2_mul(AT, L, L);
     }
 }
 

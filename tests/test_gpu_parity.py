@@ -167,10 +167,10 @@ def test_sos_stress_narrowband(osz):
     x = rng.standard_normal((3, 120000)) + 5.0
     ref, _ = orc.sosfilt(x, sos, 120000)
     y = np.concatenate(list(osz.sosfilt(producer(x, 50000, -1), sos, -1)), -1)
-    assert rel_err(y, ref) < 1e-7
+    assert rel_err(y, ref) < 1e-8
     ref = orc.sosfiltfilt(x, sos, 50000)
     y = np.concatenate(list(osz.sosfiltfilt(producer(x, 50000, -1), sos, -1)), -1)
-    assert rel_err(y, ref) < 1e-7
+    assert rel_err(y, ref) < 1e-8
 
 
 # --------------------------------------------------------------- resampling
