@@ -30,8 +30,8 @@
 namespace osz {
 
 constexpr int kSosT = 32;       // samples per lane per tile
-constexpr int kSosNW = 8;       // waves per workgroup (one channel)
-constexpr int kSosPad = 2;      // LDS row padding (doubles): stride 34 = 17 b128 slots
+constexpr int kSosNW = 4;       // waves per workgroup (one channel), one per SIMD
+constexpr int kSosPad = 1;      // LDS row padding (doubles): odd row stride, conflict-free b64
 constexpr int kSosMaxSec = 32;  // sections supported per handle
 
 // Per-section constants, built on the host in osz_sos_create.
@@ -61,8 +61,17 @@ __device__ __forceinline__ void mat2_apply(const double *M, double u0, double u1
     r1 = fma(M[2], u0, M[3] * u1);
 }
 
+// wave-private LDS hand-offs need no workgroup barrier: LDS executes one
+// wave's instructions in order; this only stops the compiler reordering them
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int T, int NW, bool REV>
-__global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a) {
+__global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
+                                                      const SosSection *__restrict__ sec) {
     constexpr int ROW = T + kSosPad;
     constexpr int WAVE_ELEMS = 64 * T;
     extern __shared__ double lds[];
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a) {
     const int64_t n = a.n;
     const double *xrow = a.x + (int64_t)c * a.ldx;
     double *yrow = a.y ? a.y + (int64_t)c * a.ldy : nullptr;
-    double *wl = tile + w * 64 * ROW;
+    double *wl = tile + w * 64 * ROW;                // this wave's private staging rows
 
     // ---- initial state of every section -> LDS slot 0
     if (threadIdx.x < a.nsec) {
@@ -100,30 +109,46 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a) {
     int parity = 0;  // which sst slot holds the current tile's start states
     int aggbuf = 0;
 
+    // HBM -> registers for one tile: consecutive lanes, consecutive samples.
+    // Issued one tile ahead so the loads fly while the current tile computes.
+    double nx[T];
+    auto fetch = [&](int64_t t) {
+        const int64_t pw = t * tile_elems + (int64_t)w * WAVE_ELEMS;
+        const int64_t mem_base = REV ? (n - pw - WAVE_ELEMS) : pw;
+        const bool full = REV ? (mem_base >= 0) : (pw + WAVE_ELEMS <= n);
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) nx[i] = xrow[mem_base + i * 64 + l];
+        } else {
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const int64_t g = mem_base + i * 64 + l;
+                nx[i] = (g >= 0 && g < n) ? xrow[g] : 0.0;
+            }
+        }
+    };
+    fetch(0);
+
     for (int64_t t = 0; t < ntiles; ++t) {
         const int64_t pw = t * tile_elems + (int64_t)w * WAVE_ELEMS;  // processing-order start of this wave
-        // memory window of this wave: WAVE_ELEMS consecutive samples
         const int64_t mem_base = REV ? (n - pw - WAVE_ELEMS) : pw;
         const bool full = REV ? (mem_base >= 0) : (pw + WAVE_ELEMS <= n);
 
-        // ---- stage HBM -> LDS (consecutive lanes, consecutive samples)
-#pragma unroll 8
+        // ---- registers -> LDS rows (transpose), then lane block -> registers
+#pragma unroll
         for (int i = 0; i < T; ++i) {
             const int m = i * 64 + l;
-            const int64_t g = mem_base + m;
-            double v = 0.0;
-            if (full || (g >= 0 && g < n)) v = xrow[g];
-            wl[(m / T) * ROW + (m % T)] = v;
+            wl[(m / T) * ROW + (m % T)] = nx[i];
         }
-        __syncthreads();
-
-        // ---- lane block -> registers (processing order)
+        wave_lds_fence();
         double v[T];
         {
             const double *blk = wl + (REV ? (63 - l) : l) * ROW;
 #pragma unroll
             for (int j = 0; j < T; ++j) v[j] = blk[REV ? (T - 1 - j) : j];
         }
+        if (t + 1 < ntiles) fetch(t + 1);
+
         // valid samples in this lane (prefix of its block)
         const int64_t pl = pw + (int64_t)l * T;
         const int64_t left = n - pl;
@@ -132,7 +157,7 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a) {
         const bool has_last = (cnt > 0) && (pl + cnt == n);
 
         for (int s = 0; s < a.nsec; ++s) {
-            const SosSection *S = a.sec + s;
+            const SosSection *__restrict__ S = sec + s;
             const double b0 = S->b0, b1 = S->b1, b2 = S->b2, na1 = -S->a1, na2 = -S->a2;
             // 1. zero-state pass
             double z0 = 0.0, z1 = 0.0;
@@ -220,20 +245,28 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a) {
         }
         parity ^= 1;
 
-        // ---- registers -> LDS -> HBM
+        // ---- registers -> LDS rows -> HBM (wave private: no workgroup barrier)
         if (yrow) {
             double *blk = wl + (REV ? (63 - l) : l) * ROW;
 #pragma unroll
             for (int j = 0; j < T; ++j) blk[REV ? (T - 1 - j) : j] = v[j];
-            __syncthreads();
-#pragma unroll 8
-            for (int i = 0; i < T; ++i) {
-                const int m = i * 64 + l;
-                const int64_t g = mem_base + m;
-                if (full || (g >= 0 && g < n)) yrow[g] = wl[(m / T) * ROW + (m % T)];
+            wave_lds_fence();
+            if (full) {
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    const int m = i * 64 + l;
+                    yrow[mem_base + m] = wl[(m / T) * ROW + (m % T)];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    const int m = i * 64 + l;
+                    const int64_t g = mem_base + m;
+                    if (g >= 0 && g < n) yrow[g] = wl[(m / T) * ROW + (m % T)];
+                }
             }
+            wave_lds_fence();
         }
-        __syncthreads();
     }
 }
 
@@ -312,7 +345,7 @@ static int sos_launch(const SosArgs &a, hipStream_t st) {
     }
     {
         KernelTimer kt(REV ? (a.y ? "sos_bwd" : "sos_warmup") : "sos_fwd", st);
-        hipLaunchKernelGGL(kern, dim3(a.nch), dim3(kSosNW * 64), sos_lds_bytes(), st, a);
+        hipLaunchKernelGGL(kern, dim3(a.nch), dim3(kSosNW * 64), sos_lds_bytes(), st, a, a.sec);
     }
     OSZ_HIP(hipGetLastError());
     return OSZ_OK;
