@@ -111,6 +111,13 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y,
  * y (nch, na) receives the result in natural sample order. The handle's
  * carried forward state is not touched.
  */
+/* The warm-up over fb stops once further samples cannot change a float64
+ * state: after warmup_len samples, the smallest multiple of the kernel tile
+ * with ||M^len||_inf < 1e-18 (M: state-transition matrix of the cascade).
+ * For slowly decaying cascades warmup_len exceeds the chunk and the whole of
+ * fb is used, exactly as the reference does.  set(0) forces the full chunk. */
+int64_t osz_sos_warmup_len(osz_sos_t h);
+int osz_sos_set_warmup_len(osz_sos_t h, int64_t len);
 int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa,
                           int64_t na, const double *fb, int64_t ldfb,
                           int64_t nb, double *y, int64_t ldy, void *stream);

@@ -316,11 +316,72 @@ static void build_section(const double *c, SosSection &S) {
     }
 }
 
+// Length of the chunk-local backward warm-up that is numerically complete.
+// sosfiltfilt back-filters the whole next chunk only to obtain a start state
+// (numerical.py:397-399); the influence of a sample that lies k samples away
+// on that state is bounded by ||M^k|| (M: state-transition matrix of the
+// whole cascade, transient growth included).  Once ||M^k||_inf < 1e-18 the
+// remaining samples cannot change a float64 state, so the warm-up stops there.
+// Returns a multiple of `quantum` samples, or `cap` when the cascade decays
+// too slowly (the caller then warms up over the full chunk).
+static int64_t sos_warmup_len(const std::vector<SosSection> &secs, int64_t quantum, int64_t cap) {
+    const int ns = (int)secs.size(), d = 2 * ns;
+    std::vector<ld_t> M((size_t)d * d, 0.0L);
+    for (int col = 0; col < d; ++col) {  // one homogeneous step applied to e_col
+        std::vector<ld_t> z(d, 0.0L), zn(d, 0.0L);
+        z[col] = 1.0L;
+        ld_t u = 0.0L;  // input of the current section (x = 0)
+        for (int s = 0; s < ns; ++s) {
+            const SosSection &S = secs[s];
+            const ld_t y = (ld_t)S.b0 * u + z[2 * s];
+            zn[2 * s] = (ld_t)S.b1 * u - (ld_t)S.a1 * y + z[2 * s + 1];
+            zn[2 * s + 1] = (ld_t)S.b2 * u - (ld_t)S.a2 * y;
+            u = y;
+        }
+        for (int r = 0; r < d; ++r) M[(size_t)r * d + col] = zn[r];
+    }
+    auto matmul = [d](const std::vector<ld_t> &X, const std::vector<ld_t> &Y) {
+        std::vector<ld_t> Z((size_t)d * d, 0.0L);
+        for (int i = 0; i < d; ++i)
+            for (int k = 0; k < d; ++k) {
+                const ld_t x = X[(size_t)i * d + k];
+                if (x == 0.0L) continue;
+                for (int j = 0; j < d; ++j) Z[(size_t)i * d + j] += x * Y[(size_t)k * d + j];
+            }
+        return Z;
+    };
+    auto norm = [d](const std::vector<ld_t> &X) {
+        ld_t m = 0.0L;
+        for (int i = 0; i < d; ++i) {
+            ld_t r = 0.0L;
+            for (int j = 0; j < d; ++j) r += fabsl(X[(size_t)i * d + j]);
+            if (r > m) m = r;
+        }
+        return m;
+    };
+    // Mq = M^quantum by square-and-multiply
+    std::vector<ld_t> Mq((size_t)d * d, 0.0L), base = M;
+    for (int i = 0; i < d; ++i) Mq[(size_t)i * d + i] = 1.0L;
+    for (int64_t e = quantum; e > 0; e >>= 1) {
+        if (e & 1) Mq = matmul(Mq, base);
+        base = matmul(base, base);
+    }
+    std::vector<ld_t> P = Mq;
+    for (int64_t len = quantum; len < cap; len += quantum) {
+        const ld_t nm = norm(P);
+        if (!(nm == nm)) break;        // NaN: unstable cascade, no truncation
+        if (nm < 1e-18L) return len;
+        P = matmul(P, Mq);
+    }
+    return cap;
+}
+
 }  // namespace osz
 
 using namespace osz;
 
 struct osz_sos_s {
+    int64_t warm_len;   // samples of the sosfiltfilt warm-up that matter (see sos_warmup_len)
     int nsec, nch;
     SosSection *dsec;   // device
     double *dstate;     // device (nsec, nch, 2): carried forward state
@@ -385,7 +446,16 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
         scale *= g;
     }
     OSZ_HIP(hipMemcpy(p->dzi, zi.data(), sizeof(double) * 2 * nsec, hipMemcpyHostToDevice));
+    p->warm_len = sos_warmup_len(secs, (int64_t)kSosNW * 64 * kSosT, (int64_t)1 << 24);
     *h = p;
+    return OSZ_OK;
+}
+
+int64_t osz_sos_warmup_len(osz_sos_t h) { return h ? h->warm_len : -1; }
+
+int osz_sos_set_warmup_len(osz_sos_t h, int64_t len) {
+    OSZ_REQUIRE(h && len >= 0, "osz_sos_set_warmup_len: bad argument");
+    h->warm_len = len == 0 ? ((int64_t)1 << 62) : len;
     return OSZ_OK;
 }
 
@@ -483,9 +553,10 @@ int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t n
     a.zi_unit = h->dzi;
     if (fb) {
         // warm-up over the next chunk: state only (numerical.py:397-399)
+        // only the warm_len samples next to chunk a can influence the state
         a.x = fb;
         a.ldx = ldfb;
-        a.n = nb;
+        a.n = nb < h->warm_len ? nb : h->warm_len;
         a.y = nullptr;
         a.ldy = 0;
         a.state_in = nullptr;

@@ -173,6 +173,26 @@ def test_sos_stress_narrowband(osz):
     assert rel_err(y, ref) < 1e-8
 
 
+def test_sosfiltfilt_warmup_truncation(osz, golden):
+    """The backward warm-up stops after warmup_len samples (the point where the
+    cascade's transition matrix has decayed below 1e-18): results must equal the
+    oracle, which back-filters the whole next chunk like the reference."""
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    g = golden("g4_sosfiltfilt.npz")
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((4, 90000))
+    for name in ("butter_bp6", "cheby1_bp"):
+        sos = g[f"sos_{name}"]
+        st = dev.SosStream(sos, 4)
+        wl = st.lib.osz_sos_warmup_len(st.h)
+        st.close()
+        assert 0 < wl < 30000          # truncation is active for 30000-sample chunks
+        y = np.concatenate(list(osz.sosfiltfilt(producer(x, 30000, -1), sos, -1)), -1)
+        assert rel_err(y, orc.sosfiltfilt(x, sos, 30000)) < 1e-12
+
+
 # --------------------------------------------------------------- resampling
 @pytest.mark.parametrize("LM", [(1, 5), (3, 1), (3, 2), (2, 7), (3, 11)])
 def test_resample_golden(osz, golden, LM):
