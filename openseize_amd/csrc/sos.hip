@@ -23,6 +23,7 @@
 //   both the HBM side (consecutive lanes -> consecutive samples) and the LDS
 //   side (row stride T+2 doubles) are conflict free.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -38,10 +39,13 @@ constexpr int kSosMaxSec = 32;  // sections supported per handle
 struct SosSection {
     double b0, b1, b2, a1, a2;
     double pad_[3];
-    double AJ[kSosT + 1][4];  // A^j, row-major 2x2; row 0 is the homogeneous y response
-    double P[6][4];           // A^(T*2^k), k = 0..5: in-wave scan steps
+    double G8[8][2];          // row 0 of A^r, r = 0..7: homogeneous y response inside an octet
+    double A8[4];             // A^8: octet-to-octet step of the homogeneous response
+    double P[4][4];           // A^(T*2^k), k = 0..3: scan steps inside a 16-lane row (DPP)
+    double B[4];              // A^(16*T): row-to-row step
     double Q[4];              // A^(64*T): wave-to-wave step
-    double PL[64][4];         // A^(T*l): lane start-state propagation
+    double PL16[16][4];       // A^(T*j), j = 0..15: row start state -> lane start state
+    double AJ[kSosT + 1][4];  // A^j (per-lane lookup for the final state of a chunk)
 };
 
 struct SosArgs {
@@ -59,6 +63,21 @@ __device__ __forceinline__ void mat2_apply(const double *M, double u0, double u1
                                            double &r0, double &r1) {
     r0 = fma(M[0], u0, M[1] * u1);
     r1 = fma(M[2], u0, M[3] * u1);
+}
+
+// lane i <- lane i-D inside its 16-lane row, 0 for the first D lanes (DPP row_shr)
+template <int D>
+__device__ __forceinline__ double row_shr(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + D, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + D, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
 }
 
 // wave-private LDS hand-offs need no workgroup barrier: LDS executes one
@@ -159,51 +178,71 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
         for (int s = 0; s < a.nsec; ++s) {
             const SosSection *__restrict__ S = sec + s;
             const double b0 = S->b0, b1 = S->b1, b2 = S->b2, na1 = -S->a1, na2 = -S->a2;
-            // 1. zero-state pass
+            // 1. zero-state pass.  Samples past the end of the chunk were
+            // loaded as zeros, so the pass needs no predication; only the lane
+            // that owns the last sample also needs the state after `cnt`
+            // samples (rare path, last tile only).
+            double zc0 = 0.0, zc1 = 0.0;
+            if (!wave_full) {
+                double q0 = 0.0, q1 = 0.0;
+                for (int j = 0; j < T; ++j) {
+                    if (j == cnt) {
+                        zc0 = q0;
+                        zc1 = q1;
+                    }
+                    const double xin = v[j];
+                    const double y = fma(b0, xin, q0);
+                    q0 = fma(na1, y, fma(b1, xin, q1));
+                    q1 = fma(na2, y, b2 * xin);
+                }
+                if (cnt == T) {
+                    zc0 = q0;
+                    zc1 = q1;
+                }
+            }
             double z0 = 0.0, z1 = 0.0;
-            if (wave_full) {
 #pragma unroll
-                for (int j = 0; j < T; ++j) {
-                    const double xin = v[j];
-                    const double y = fma(b0, xin, z0);
-                    z0 = fma(na1, y, fma(b1, xin, z1));
-                    z1 = fma(na2, y, b2 * xin);
-                    v[j] = y;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < T; ++j) {
-                    const double xin = v[j];
-                    const double y = fma(b0, xin, z0);
-                    const double nz0 = fma(na1, y, fma(b1, xin, z1));
-                    const double nz1 = fma(na2, y, b2 * xin);
-                    const bool ok = j < cnt;
-                    z0 = ok ? nz0 : z0;
-                    z1 = ok ? nz1 : z1;
-                    v[j] = y;
-                }
+            for (int j = 0; j < T; ++j) {
+                const double xin = v[j];
+                const double y = fma(b0, xin, z0);
+                z0 = fma(na1, y, fma(b1, xin, z1));
+                z1 = fma(na2, y, b2 * xin);
+                v[j] = y;
             }
-            const double e0raw = z0, e1raw = z1;
-            // 2a. in-wave inclusive scan of end states
+            const double e0raw = wave_full ? z0 : zc0, e1raw = wave_full ? z1 : zc1;
+            // per-lane constants for later (issued early: the load flies meanwhile)
+            const double pl0 = S->PL16[l & 15][0], pl1 = S->PL16[l & 15][1];
+            const double pl2 = S->PL16[l & 15][2], pl3 = S->PL16[l & 15][3];
+            // 2a. inclusive scan of end states inside each 16-lane row (DPP)
             double e0 = z0, e1 = z1;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int d = 1 << k;
-                const double u0 = __shfl_up(e0, d, 64);
-                const double u1 = __shfl_up(e1, d, 64);
-                double r0, r1;
-                mat2_apply(S->P[k], u0, u1, r0, r1);
-                if (l >= d) {
-                    e0 += r0;
-                    e1 += r1;
+#define OSZ_SCAN_STEP(K, D)                                   \
+    {                                                         \
+        const double u0 = row_shr<D>(e0), u1 = row_shr<D>(e1); \
+        double r0, r1;                                        \
+        mat2_apply(S->P[K], u0, u1, r0, r1);                  \
+        e0 += r0;                                             \
+        e1 += r1;                                             \
+    }
+            OSZ_SCAN_STEP(0, 1)
+            OSZ_SCAN_STEP(1, 2)
+            OSZ_SCAN_STEP(2, 4)
+            OSZ_SCAN_STEP(3, 8)
+#undef OSZ_SCAN_STEP
+            const double p0 = row_shr<1>(e0), p1 = row_shr<1>(e1);  // exclusive, 0 at row start
+            // row totals, wave-uniform
+            const double R00 = lane_bcast(e0, 15), R01 = lane_bcast(e1, 15);
+            const double R10 = lane_bcast(e0, 31), R11 = lane_bcast(e1, 31);
+            const double R20 = lane_bcast(e0, 47), R21 = lane_bcast(e1, 47);
+            const double R30 = lane_bcast(e0, 63), R31 = lane_bcast(e1, 63);
+            {   // wave aggregate from a zero start: E = B(B(B R0 + R1) + R2) + R3
+                double y0 = R00, y1 = R01, t0, t1;
+                mat2_apply(S->B, y0, y1, t0, t1); y0 = t0 + R10; y1 = t1 + R11;
+                mat2_apply(S->B, y0, y1, t0, t1); y0 = t0 + R20; y1 = t1 + R21;
+                mat2_apply(S->B, y0, y1, t0, t1); y0 = t0 + R30; y1 = t1 + R31;
+                if (l == 0) {
+                    agg[(aggbuf * NW + w) * 2 + 0] = y0;
+                    agg[(aggbuf * NW + w) * 2 + 1] = y1;
                 }
-            }
-            double p0 = __shfl_up(e0, 1, 64);
-            double p1 = __shfl_up(e1, 1, 64);
-            if (l == 0) p0 = p1 = 0.0;
-            if (l == 63) {
-                agg[(aggbuf * NW + w) * 2 + 0] = e0;
-                agg[(aggbuf * NW + w) * 2 + 1] = e1;
             }
             __syncthreads();
             // 2b. wave-level replay (every wave, uniform values)
@@ -226,15 +265,32 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
                 sst[((parity ^ 1) * kSosMaxSec + s) * 2 + 1] = s1;
             }
             aggbuf ^= 1;
-            // lane start state
-            double ls0, ls1;
-            mat2_apply(S->PL[l], sw0, sw1, ls0, ls1);
-            ls0 += p0;
-            ls1 += p1;
-            // 3. homogeneous fix-up
+            // 2c. start state of each row, then of each lane
+            double x10, x11, x20, x21, x30, x31;
+            mat2_apply(S->B, sw0, sw1, x10, x11); x10 += R00; x11 += R01;
+            mat2_apply(S->B, x10, x11, x20, x21); x20 += R10; x21 += R11;
+            mat2_apply(S->B, x20, x21, x30, x31); x30 += R20; x31 += R21;
+            const int row = l >> 4;
+            const double xr0 = row == 0 ? sw0 : (row == 1 ? x10 : (row == 2 ? x20 : x30));
+            const double xr1 = row == 0 ? sw1 : (row == 1 ? x11 : (row == 2 ? x21 : x31));
+            double ls0 = fma(pl0, xr0, fma(pl1, xr1, p0));
+            double ls1 = fma(pl2, xr0, fma(pl3, xr1, p1));
+            // 3. homogeneous fix-up, octet by octet: y[8q + r] += row0(A^r) (A^8)^q s
+            {
+                double h0 = ls0, h1 = ls1;
 #pragma unroll
-            for (int j = 0; j < T; ++j)
-                v[j] = fma(S->AJ[j][0], ls0, fma(S->AJ[j][1], ls1, v[j]));
+                for (int q = 0; q < T / 8; ++q) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        v[8 * q + r] = fma(S->G8[r][0], h0, fma(S->G8[r][1], h1, v[8 * q + r]));
+                    if (q + 1 < T / 8) {
+                        double n0, n1;
+                        mat2_apply(S->A8, h0, h1, n0, n1);
+                        h0 = n0;
+                        h1 = n1;
+                    }
+                }
+            }
             // final state of the chunk: the lane that owns the last sample
             if (has_last && a.state_out) {
                 double f0, f1;
@@ -298,20 +354,28 @@ static void build_section(const double *c, SosSection &S) {
     ld_t M[4] = {1, 0, 0, 1}, AT[4];
     for (int j = 0; j <= kSosT; ++j) {
         mat2_store(M, S.AJ[j]);
+        if (j < 8) {
+            S.G8[j][0] = (double)M[0];
+            S.G8[j][1] = (double)M[1];
+        }
+        if (j == 8) mat2_store(M, S.A8);
         if (j == kSosT) memcpy(AT, M, sizeof M);
         mat2_mul(A, M, M);
     }
-    // A^T, then squarings
+    // A^T, then squarings: A^(T 2^k)
     ld_t Pk[4];
     memcpy(Pk, AT, sizeof Pk);
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 4; ++k) {
         mat2_store(Pk, S.P[k]);
         mat2_mul(Pk, Pk, Pk);
     }
-    mat2_store(Pk, S.Q);  // (A^T)^64
+    mat2_store(Pk, S.B);      // A^(16 T)
+    mat2_mul(Pk, Pk, Pk);
+    mat2_mul(Pk, Pk, Pk);
+    mat2_store(Pk, S.Q);      // A^(64 T)
     ld_t L[4] = {1, 0, 0, 1};
-    for (int l = 0; l < 64; ++l) {
-        mat2_store(L, S.PL[l]);
+    for (int j = 0; j < 16; ++j) {
+        mat2_store(L, S.PL16[j]);
         mat2_mul(AT, L, L);
     }
 }
@@ -389,27 +453,43 @@ struct osz_sos_s {
     double *dzi;        // device (nsec, 2): sosfilt_zi of this cascade
 };
 
+template <int NW>
 static size_t sos_lds_bytes() {
-    return sizeof(double) * ((size_t)kSosNW * 64 * (kSosT + kSosPad) + 2 * kSosNW * 2 +
+    return sizeof(double) * ((size_t)NW * 64 * (kSosT + kSosPad) + 2 * NW * 2 +
                              2 * kSosMaxSec * 2);
 }
 
-template <bool REV>
-static int sos_launch(const SosArgs &a, hipStream_t st) {
-    auto kern = sos_kernel<kSosT, kSosNW, REV>;
+template <int NW, bool REV>
+static int sos_launch_nw(const SosArgs &a, hipStream_t st) {
+    auto kern = sos_kernel<kSosT, NW, REV>;
     static bool attr_set = false;
     if (!attr_set) {
         OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)sos_lds_bytes()));
+                                    (int)sos_lds_bytes<NW>()));
         attr_set = true;
     }
     {
         KernelTimer kt(REV ? (a.y ? "sos_bwd" : "sos_warmup") : "sos_fwd", st);
-        hipLaunchKernelGGL(kern, dim3(a.nch), dim3(kSosNW * 64), sos_lds_bytes(), st, a, a.sec);
+        hipLaunchKernelGGL(kern, dim3(a.nch), dim3(NW * 64), sos_lds_bytes<NW>(), st, a, a.sec);
     }
     OSZ_HIP(hipGetLastError());
     return OSZ_OK;
+}
+
+// waves per workgroup: tuning knob (OSZ_SOS_NW=4|8), default kSosNW
+static int sos_nw() {
+    static int nw = 0;
+    if (!nw) {
+        const char *e = getenv("OSZ_SOS_NW");
+        nw = (e && atoi(e) == 8) ? 8 : ((e && atoi(e) == 4) ? 4 : kSosNW);
+    }
+    return nw;
+}
+
+template <bool REV>
+static int sos_launch(const SosArgs &a, hipStream_t st) {
+    return sos_nw() == 8 ? sos_launch_nw<8, REV>(a, st) : sos_launch_nw<4, REV>(a, st);
 }
 
 extern "C" {
@@ -446,7 +526,7 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
         scale *= g;
     }
     OSZ_HIP(hipMemcpy(p->dzi, zi.data(), sizeof(double) * 2 * nsec, hipMemcpyHostToDevice));
-    p->warm_len = sos_warmup_len(secs, (int64_t)kSosNW * 64 * kSosT, (int64_t)1 << 24);
+    p->warm_len = sos_warmup_len(secs, (int64_t)8 * 64 * kSosT, (int64_t)1 << 24);
     *h = p;
     return OSZ_OK;
 }
