@@ -88,7 +88,9 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int T, int NW, bool REV>
+// GUARD = false: n is a whole number of tiles (the hot kernel: no bounds
+// checks, no predication); GUARD = true handles a ragged remainder.
+template <int T, int NW, bool REV, bool GUARD>
 __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
                                                       const SosSection *__restrict__ sec) {
     constexpr int ROW = T + kSosPad;
@@ -134,10 +136,11 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
     auto fetch = [&](int64_t t) {
         const int64_t pw = t * tile_elems + (int64_t)w * WAVE_ELEMS;
         const int64_t mem_base = REV ? (n - pw - WAVE_ELEMS) : pw;
-        const bool full = REV ? (mem_base >= 0) : (pw + WAVE_ELEMS <= n);
+        const bool full = !GUARD || (REV ? (mem_base >= 0) : (pw + WAVE_ELEMS <= n));
         if (full) {
+            const double *p = xrow + mem_base + l;   // one base, immediate offsets
 #pragma unroll
-            for (int i = 0; i < T; ++i) nx[i] = xrow[mem_base + i * 64 + l];
+            for (int i = 0; i < T; ++i) nx[i] = p[i * 64];
         } else {
 #pragma unroll
             for (int i = 0; i < T; ++i) {
@@ -151,14 +154,14 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
     for (int64_t t = 0; t < ntiles; ++t) {
         const int64_t pw = t * tile_elems + (int64_t)w * WAVE_ELEMS;  // processing-order start of this wave
         const int64_t mem_base = REV ? (n - pw - WAVE_ELEMS) : pw;
-        const bool full = REV ? (mem_base >= 0) : (pw + WAVE_ELEMS <= n);
+        const bool full = !GUARD || (REV ? (mem_base >= 0) : (pw + WAVE_ELEMS <= n));
 
         // ---- registers -> LDS rows (transpose), then lane block -> registers
+        // lane l, step i <-> element m = 64 i + l of the wave window: row m / T, col m % T
+        double *stage = wl + (l / T) * ROW + (l % T);
+        constexpr int STEP = (64 / T) * ROW;
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
-            const int m = i * 64 + l;
-            wl[(m / T) * ROW + (m % T)] = nx[i];
-        }
+        for (int i = 0; i < T; ++i) stage[i * STEP] = nx[i];
         wave_lds_fence();
         double v[T];
         {
@@ -171,8 +174,8 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
         // valid samples in this lane (prefix of its block)
         const int64_t pl = pw + (int64_t)l * T;
         const int64_t left = n - pl;
-        const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
-        const bool wave_full = (pw + WAVE_ELEMS <= n);
+        const int cnt = (!GUARD || left >= T) ? T : (left > 0 ? (int)left : 0);
+        const bool wave_full = !GUARD || (pw + WAVE_ELEMS <= n);
         const bool has_last = (cnt > 0) && (pl + cnt == n);
 
         for (int s = 0; s < a.nsec; ++s) {
@@ -308,11 +311,9 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
             for (int j = 0; j < T; ++j) blk[REV ? (T - 1 - j) : j] = v[j];
             wave_lds_fence();
             if (full) {
+                double *q = yrow + mem_base + l;
 #pragma unroll
-                for (int i = 0; i < T; ++i) {
-                    const int m = i * 64 + l;
-                    yrow[mem_base + m] = wl[(m / T) * ROW + (m % T)];
-                }
+                for (int i = 0; i < T; ++i) q[i * 64] = stage[i * STEP];
             } else {
 #pragma unroll
                 for (int i = 0; i < T; ++i) {
@@ -342,7 +343,7 @@ static void mat2_store(const ld_t *M, double *out) {
     for (int i = 0; i < 4; ++i) out[i] = (double)M[i];
 }
 
-static void build_section(const double *c, SosSection &S) {
+static void build_section(const double *c, SosSection &S, int T) {
     memset(&S, 0, sizeof S);
     const double a0 = c[3];
     S.b0 = c[0] / a0;
@@ -352,14 +353,14 @@ static void build_section(const double *c, SosSection &S) {
     S.a2 = c[5] / a0;
     const ld_t A[4] = {-(ld_t)S.a1, 1.0L, -(ld_t)S.a2, 0.0L};
     ld_t M[4] = {1, 0, 0, 1}, AT[4];
-    for (int j = 0; j <= kSosT; ++j) {
+    for (int j = 0; j <= T; ++j) {
         mat2_store(M, S.AJ[j]);
         if (j < 8) {
             S.G8[j][0] = (double)M[0];
             S.G8[j][1] = (double)M[1];
         }
         if (j == 8) mat2_store(M, S.A8);
-        if (j == kSosT) memcpy(AT, M, sizeof M);
+        if (j == T) memcpy(AT, M, sizeof M);
         mat2_mul(A, M, M);
     }
     // A^T, then squarings: A^(T 2^k)
@@ -445,51 +446,70 @@ static int64_t sos_warmup_len(const std::vector<SosSection> &secs, int64_t quant
 using namespace osz;
 
 struct osz_sos_s {
+    int T, NW;          // kernel geometry: samples per lane, waves per workgroup
     int64_t warm_len;   // samples of the sosfiltfilt warm-up that matter (see sos_warmup_len)
     int nsec, nch;
     SosSection *dsec;   // device
     double *dstate;     // device (nsec, nch, 2): carried forward state
     double *dtmp;       // device (nsec, nch, 2): warm-up state of sosfiltfilt
+    double *dcarry;     // device (nsec, nch, 2): state between the main and remainder launches
     double *dzi;        // device (nsec, 2): sosfilt_zi of this cascade
 };
 
-template <int NW>
-static size_t sos_lds_bytes() {
-    return sizeof(double) * ((size_t)NW * 64 * (kSosT + kSosPad) + 2 * NW * 2 +
-                             2 * kSosMaxSec * 2);
-}
-
-template <int NW, bool REV>
-static int sos_launch_nw(const SosArgs &a, hipStream_t st) {
-    auto kern = sos_kernel<kSosT, NW, REV>;
+template <int T, int NW, bool REV, bool GUARD>
+static int sos_launch_one(const SosArgs &a, hipStream_t st) {
+    auto kern = sos_kernel<T, NW, REV, GUARD>;
     static bool attr_set = false;
+    const size_t lds = sizeof(double) * ((size_t)NW * 64 * (T + kSosPad) + 2 * NW * 2 +
+                                         2 * kSosMaxSec * 2);
     if (!attr_set) {
         OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)sos_lds_bytes<NW>()));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     {
-        KernelTimer kt(REV ? (a.y ? "sos_bwd" : "sos_warmup") : "sos_fwd", st);
-        hipLaunchKernelGGL(kern, dim3(a.nch), dim3(NW * 64), sos_lds_bytes<NW>(), st, a, a.sec);
+        KernelTimer kt(REV ? (a.y ? (GUARD ? "sos_bwd_tail" : "sos_bwd") : "sos_warmup")
+                           : (GUARD ? "sos_fwd_tail" : "sos_fwd"), st);
+        hipLaunchKernelGGL(kern, dim3(a.nch), dim3(NW * 64), lds, st, a, a.sec);
     }
     OSZ_HIP(hipGetLastError());
     return OSZ_OK;
 }
 
-// waves per workgroup: tuning knob (OSZ_SOS_NW=4|8), default kSosNW
-static int sos_nw() {
-    static int nw = 0;
-    if (!nw) {
-        const char *e = getenv("OSZ_SOS_NW");
-        nw = (e && atoi(e) == 8) ? 8 : ((e && atoi(e) == 4) ? 4 : kSosNW);
+// One logical pass = the hot kernel over the whole tiles + a guarded kernel
+// over the ragged remainder; the cascade state travels through `carry`
+// (nsec, nch, 2) between the two launches.
+template <int T, int NW, bool REV>
+static int sos_launch_tn(const SosArgs &a0, double *carry, hipStream_t st) {
+    const int64_t tile = (int64_t)NW * 64 * T;
+    const int64_t nfull = (a0.n / tile) * tile, rem = a0.n - nfull;
+    if (nfull == 0 || rem == 0) {
+        return rem ? sos_launch_one<T, NW, REV, true>(a0, st)
+                   : sos_launch_one<T, NW, REV, false>(a0, st);
     }
-    return nw;
+    SosArgs m = a0, r = a0;  // main (whole tiles) first in processing order, then remainder
+    m.n = nfull;
+    r.n = rem;
+    if (REV) {
+        m.x = a0.x + rem;
+        if (a0.y) m.y = a0.y + rem;
+    } else {
+        r.x = a0.x + nfull;
+        if (a0.y) r.y = a0.y + nfull;
+    }
+    m.state_out = carry;
+    r.state_in = carry;
+    int rc = sos_launch_one<T, NW, REV, false>(m, st);
+    if (rc) return rc;
+    return sos_launch_one<T, NW, REV, true>(r, st);
 }
 
 template <bool REV>
-static int sos_launch(const SosArgs &a, hipStream_t st) {
-    return sos_nw() == 8 ? sos_launch_nw<8, REV>(a, st) : sos_launch_nw<4, REV>(a, st);
+static int sos_launch(const SosArgs &a, double *carry, int T, int NW, hipStream_t st) {
+    if (T == 32 && NW == 4) return sos_launch_tn<32, 4, REV>(a, carry, st);
+    if (T == 32 && NW == 8) return sos_launch_tn<32, 8, REV>(a, carry, st);
+    if (T == 16 && NW == 8) return sos_launch_tn<16, 8, REV>(a, carry, st);
+    return fail(OSZ_ERR_INVALID, "sos: unsupported geometry T=%d NW=%d", T, NW);
 }
 
 extern "C" {
@@ -501,15 +521,24 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     OSZ_REQUIRE(nch >= 1, "osz_sos_create: nch=%d must be positive", nch);
     for (int s = 0; s < nsec; ++s)
         OSZ_REQUIRE(sos[6 * s + 3] == 1.0, "sos[:, 3] should be all ones (section %d)", s);
+    // kernel geometry (tuning knobs: OSZ_SOS_T = 16|32, OSZ_SOS_NW = 4|8|16)
+    int T = kSosT, NW = kSosNW;
+    if (const char *e = getenv("OSZ_SOS_T")) T = atoi(e);
+    if (const char *e = getenv("OSZ_SOS_NW")) NW = atoi(e);
+    OSZ_REQUIRE((T == 32 && (NW == 4 || NW == 8)) || (T == 16 && NW == 8),
+                "osz_sos_create: unsupported OSZ_SOS_T=%d / OSZ_SOS_NW=%d", T, NW);
     std::vector<SosSection> secs(nsec);
-    for (int s = 0; s < nsec; ++s) build_section(sos + 6 * s, secs[s]);
+    for (int s = 0; s < nsec; ++s) build_section(sos + 6 * s, secs[s], T);
     osz_sos_s *p = new osz_sos_s();
+    p->T = T;
+    p->NW = NW;
     p->nsec = nsec;
     p->nch = nch;
     const size_t sb = sizeof(double) * (size_t)nsec * nch * 2;
     OSZ_HIP(hipMalloc(&p->dsec, sizeof(SosSection) * nsec));
     OSZ_HIP(hipMalloc(&p->dstate, sb));
     OSZ_HIP(hipMalloc(&p->dtmp, sb));
+    OSZ_HIP(hipMalloc(&p->dcarry, sb));
     OSZ_HIP(hipMalloc(&p->dzi, sizeof(double) * nsec * 2));
     OSZ_HIP(hipMemcpy(p->dsec, secs.data(), sizeof(SosSection) * nsec, hipMemcpyHostToDevice));
     OSZ_HIP(hipMemset(p->dstate, 0, sb));
@@ -526,7 +555,7 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
         scale *= g;
     }
     OSZ_HIP(hipMemcpy(p->dzi, zi.data(), sizeof(double) * 2 * nsec, hipMemcpyHostToDevice));
-    p->warm_len = sos_warmup_len(secs, (int64_t)8 * 64 * kSosT, (int64_t)1 << 24);
+    p->warm_len = sos_warmup_len(secs, (int64_t)NW * 64 * T, (int64_t)1 << 24);
     *h = p;
     return OSZ_OK;
 }
@@ -550,6 +579,7 @@ int osz_sos_destroy(osz_sos_t h) {
     (void)hipFree(h->dsec);
     (void)hipFree(h->dstate);
     (void)hipFree(h->dtmp);
+    (void)hipFree(h->dcarry);
     (void)hipFree(h->dzi);
     delete h;
     return OSZ_OK;
@@ -616,7 +646,7 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y, int64_
     a.state_out = h->dstate;
     a.nsec = h->nsec;
     a.nch = h->nch;
-    return sos_launch<false>(a, as_stream(stream));
+    return sos_launch<false>(a, h->dcarry, h->T, h->NW, as_stream(stream));
 }
 
 int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t na,
@@ -641,7 +671,7 @@ int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t n
         a.ldy = 0;
         a.state_in = nullptr;
         a.state_out = h->dtmp;
-        int rc = sos_launch<true>(a, st);
+        int rc = sos_launch<true>(a, h->dcarry, h->T, h->NW, st);
         if (rc) return rc;
         a.state_in = h->dtmp;
     } else {
@@ -653,7 +683,7 @@ int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t n
     a.y = y;
     a.ldy = ldy;
     a.state_out = nullptr;
-    return sos_launch<true>(a, st);
+    return sos_launch<true>(a, h->dcarry, h->T, h->NW, st);
 }
 
 }  // extern "C"
