@@ -7,8 +7,8 @@ on): 256 channels x float64, chunksize 2^20, 1024-tap FIR overlap-add
 `sosfiltfilt` (`butter(6, [0.05, 0.3], 'bandpass')`).  A "step" is one chunk
 (256 x 2^20 channel-samples) through the whole chain in steady state:
 
-    FIR push(chunk k) -> SOS forward(chunk k)
-    -> SOS backward(chunk k-1; chunk-local warm-up over forward chunk k)
+    FIR push(chunk k) -> [SOS forward(chunk k) + SOS backward(chunk k-2;
+    chunk-local warm-up over forward chunk k-1)] in one launch
 
 Inputs are synthesised on the device before the timed region (a ring of
 resident chunks keyed by (seed, channel, sample)); outputs land in a resident
@@ -36,8 +36,8 @@ C_PER_GPU = 256
 CHUNK = 1 << 20
 NTAPS = 1024
 # algorithmic HBM bytes per channel-sample of one launch
-KERNEL_BYTES = {"fir_oa": 16, "sos_fwd": 16, "sos_bwd": 16, "sos_warmup": 8,
-                "fir_seam": 0}
+KERNEL_BYTES = {"fir_oa": 16, "sos_dual": 32, "sos_fwd": 16, "sos_bwd": 16,
+                "sos_warmup": 0, "fir_seam": 0}
 CHAIN_BYTES = 48         # FIR 16 + sosfiltfilt 32 (unfused)
 
 
@@ -90,19 +90,23 @@ def main():
     fir = dev.FirStream(h, C)
     iir = dev.SosStream(sos, C)
     fir_out = torch.empty((C, CHUNK), dtype=torch.float64, device="cuda")
-    fwd = [torch.empty_like(fir_out) for _ in range(2)]
+    fwd = [torch.empty_like(fir_out) for _ in range(3)]
     y_out = torch.empty_like(fir_out)
 
     def step(k):
+        # chunk k: FIR, then ONE launch = forward(chunk k) + backward(chunk
+        # k-2, warmed up over forward chunk k-1)  [osz_sosfiltfilt_step]
         fir.push(ring[k % len(ring)], 0, out=fir_out)
-        fb = iir.forward(fir_out, out=fwd[k % 2])
-        if k > 0:
-            iir.backward(fwd[(k - 1) % 2], fb, out=y_out)
+        if k < 2:
+            iir.forward(fir_out, out=fwd[k % 3])
+        else:
+            iir.step(fir_out, fwd[(k - 2) % 3], fwd[(k - 1) % 3],
+                     f_out=fwd[k % 3], y_out=y_out)
 
     # start of the stream: steady-state init as sosfiltfilt does, then warm up
     iir.set_state_scaled(ring[0], 0)
     k = 0
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(args.warmup, 2)):
         step(k)
         k += 1
 

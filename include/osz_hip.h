@@ -122,6 +122,19 @@ int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa,
                           int64_t na, const double *fb, int64_t ldfb,
                           int64_t nb, double *y, int64_t ldy, void *stream);
 
+/*
+ * One steady-state step of sosfiltfilt in a single launch: forward-filter the
+ * incoming chunk x (nch, nx) -> f (advancing the carried state) AND back-filter
+ * an earlier forward chunk fa with the warm-up over fb (as
+ * osz_sosfiltfilt_chunk) -> y.  The two passes are independent and share the
+ * GPU (two workgroups per CU).  Equivalent to osz_sos_forward followed by
+ * osz_sosfiltfilt_chunk, which it falls back to for ragged chunk lengths.
+ */
+int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx,
+                         double *f, int64_t ldf, const double *fa, int64_t ldfa,
+                         int64_t na, const double *fb, int64_t ldfb, int64_t nb,
+                         double *y, int64_t ldy, void *stream);
+
 /* ---- K1: streaming FFT overlap-add FIR -------------------------------- */
 /*
  * Replaces the np.fft.rfft / irfft circular convolution and overlap add of

@@ -189,6 +189,22 @@ class SosStream(_Handle):
         return y
 
 
+    def step(self, x2d, fa, fb=None, f_out=None, y_out=None):
+        """Forward-filter x2d and back-filter fa (warm-up over fb) in one
+        launch (osz_sosfiltfilt_step).  Returns (forward of x2d, backward of
+        fa)."""
+        f = torch.empty_like(x2d) if f_out is None else f_out
+        y = torch.empty_like(fa) if y_out is None else y_out
+        _lib.check(self.lib.osz_sosfiltfilt_step(
+            self.h, ptr(x2d), x2d.stride(0), x2d.shape[1], ptr(f), f.stride(0),
+            ptr(fa), fa.stride(0), fa.shape[1],
+            ptr(fb) if fb is not None else None,
+            fb.stride(0) if fb is not None else 0,
+            fb.shape[1] if fb is not None else 0,
+            ptr(y), y.stride(0), stream_ptr()))
+        return f, y
+
+
 class FirStream(_Handle):
     """One iterator's overlap-add state (C ABI: osz_fir_*)."""
     _destroy = "osz_fir_destroy"

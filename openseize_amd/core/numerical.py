@@ -192,26 +192,33 @@ def sosfiltfilt(pro, sos, axis):
             return
         x2d, host = layout.to2d(first)
         stream.set_state_scaled(x2d, 0)
-        fa = stream.forward(x2d)
+        fwd, hosts = [stream.forward(x2d)], [host]
+        second = next(chunks, None)
+        if second is not None:
+            b2d, host_b = layout.to2d(second)
+            fwd.append(stream.forward(b2d))
+            hosts.append(host_b)
         n = int(np.ceil(pro.shape[axis] / pro.chunksize))
         idx = 1
-        while True:
-            # one-chunk lookahead: the forward pass runs over every chunk in
-            # order, the backward pass of chunk idx needs forward chunk idx+1
-            nxt = next(chunks, None)
-            fb, host_b = None, host
+        while fwd:
+            # fwd[0] = forward chunk idx, fwd[1] = forward chunk idx+1 (if any).
+            # The backward pass of chunk idx warms up over forward chunk idx+1;
+            # the reference takes its "last chunk" branch for every idx >= n.
+            fa = fwd[0]
+            fb = fwd[1] if (len(fwd) > 1 and idx < n) else None
+            nxt = next(chunks, None) if len(fwd) > 1 else None
             if nxt is not None:
-                b2d, host_b = layout.to2d(nxt)
-                fb = stream.forward(b2d)
-            if idx < n and fb is not None:
-                y = stream.backward(fa, fb)
+                # steady state: forward of chunk idx+2 and backward of chunk
+                # idx share one launch (osz_sosfiltfilt_step)
+                c2d, host_c = layout.to2d(nxt)
+                fnew, y = stream.step(c2d, fa, fb)
+                fwd.append(fnew)
+                hosts.append(host_c)
             else:
-                # last chunk (the reference takes this branch for idx >= n)
-                y = stream.backward(fa, None)
-            yield layout.from2d(y, host)
-            if fb is None:
-                break
-            fa, host = fb, host_b
+                y = stream.backward(fa, fb)
+            yield layout.from2d(y, hosts[0])
+            fwd.pop(0)
+            hosts.pop(0)
             idx += 1
     finally:
         stream.close()

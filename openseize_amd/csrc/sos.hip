@@ -91,8 +91,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 // GUARD = false: n is a whole number of tiles (the hot kernel: no bounds
 // checks, no predication); GUARD = true handles a ragged remainder.
 template <int T, int NW, bool REV, bool GUARD>
-__global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
-                                                      const SosSection *__restrict__ sec) {
+__device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__restrict__ sec,
+                                         const int c) {
     constexpr int ROW = T + kSosPad;
     constexpr int WAVE_ELEMS = 64 * T;
     extern __shared__ double lds[];
@@ -100,7 +100,6 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
     double *agg = tile + NW * 64 * ROW;              // [2][NW][2]
     double *sst = agg + 2 * NW * 2;                  // [2][kSosMaxSec][2]
 
-    const int c = blockIdx.x;
     const int w = threadIdx.x >> 6;
     const int l = threadIdx.x & 63;
     const int64_t n = a.n;
@@ -327,6 +326,25 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
     }
 }
 
+template <int T, int NW, bool REV, bool GUARD>
+__global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
+                                                      const SosSection *__restrict__ sec) {
+    sos_body<T, NW, REV, GUARD>(a, sec, blockIdx.x);
+}
+
+// Forward pass of one chunk and backward pass of another in ONE launch:
+// grid (nch, 2).  The two passes are independent; two workgroups per CU
+// (<= 256 VGPRs, 67 KB LDS each) fill each other's latency gaps, which one
+// wave per SIMD cannot do alone.
+template <int T, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void sos_dual_kernel(SosArgs f, SosArgs b,
+                                                             const SosSection *__restrict__ sec) {
+    if (blockIdx.y == 0)
+        sos_body<T, NW, false, false>(f, sec, blockIdx.x);
+    else
+        sos_body<T, NW, true, false>(b, sec, blockIdx.x);
+}
+
 // The constant matrices are powers of the companion matrix A.  For poles close
 // to the unit circle A is nearly defective and products formed in float64 lose
 // up to ~1e-9 relative accuracy at A^2048; they are therefore built in 80-bit
@@ -512,6 +530,25 @@ static int sos_launch(const SosArgs &a, double *carry, int T, int NW, hipStream_
     return fail(OSZ_ERR_INVALID, "sos: unsupported geometry T=%d NW=%d", T, NW);
 }
 
+template <int T, int NW>
+static int sos_launch_dual(const SosArgs &f, const SosArgs &b, hipStream_t st) {
+    auto kern = sos_dual_kernel<T, NW>;
+    static bool attr_set = false;
+    const size_t lds = sizeof(double) * ((size_t)NW * 64 * (T + kSosPad) + 2 * NW * 2 +
+                                         2 * kSosMaxSec * 2);
+    if (!attr_set) {
+        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    {
+        KernelTimer kt("sos_dual", st);
+        hipLaunchKernelGGL(kern, dim3(f.nch, 2), dim3(NW * 64), lds, st, f, b, f.sec);
+    }
+    OSZ_HIP(hipGetLastError());
+    return OSZ_OK;
+}
+
 extern "C" {
 
 int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
@@ -647,6 +684,51 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y, int64_
     a.nsec = h->nsec;
     a.nch = h->nch;
     return sos_launch<false>(a, h->dcarry, h->T, h->NW, as_stream(stream));
+}
+
+int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, double *f,
+                         int64_t ldf, const double *fa, int64_t ldfa, int64_t na,
+                         const double *fb, int64_t ldfb, int64_t nb, double *y, int64_t ldy,
+                         void *stream) {
+    OSZ_REQUIRE(h && x && f && fa && y, "osz_sosfiltfilt_step: null argument");
+    OSZ_REQUIRE(nx >= 1 && ldx >= nx && ldf >= nx, "osz_sosfiltfilt_step: bad forward chunk");
+    OSZ_REQUIRE(na >= 1 && ldfa >= na && ldy >= na, "osz_sosfiltfilt_step: bad chunk a");
+    OSZ_REQUIRE(!fb || (nb >= 1 && ldfb >= nb), "osz_sosfiltfilt_step: bad chunk b");
+    const int64_t tile = (int64_t)h->NW * 64 * h->T;
+    const bool fusable = h->T == 32 && h->NW == 4 && nx % tile == 0 && na % tile == 0;
+    if (!fusable) {
+        int rc = osz_sos_forward(h, x, ldx, f, ldf, nx, stream);
+        if (rc) return rc;
+        return osz_sosfiltfilt_chunk(h, fa, ldfa, na, fb, ldfb, nb, y, ldy, stream);
+    }
+    hipStream_t st = as_stream(stream);
+    SosArgs w{}, fw{}, bw{};
+    w.sec = fw.sec = bw.sec = h->dsec;
+    w.nsec = fw.nsec = bw.nsec = h->nsec;
+    w.nch = fw.nch = bw.nch = h->nch;
+    w.zi_unit = fw.zi_unit = bw.zi_unit = h->dzi;
+    if (fb) {  // warm-up over the head of the next forward chunk: state only
+        w.x = fb;
+        w.ldx = ldfb;
+        w.n = nb < h->warm_len ? nb : h->warm_len;
+        w.state_out = h->dtmp;
+        int rc = sos_launch<true>(w, h->dcarry, h->T, h->NW, st);
+        if (rc) return rc;
+        bw.state_in = h->dtmp;
+    }
+    fw.x = x;
+    fw.y = f;
+    fw.ldx = ldx;
+    fw.ldy = ldf;
+    fw.n = nx;
+    fw.state_in = h->dstate;
+    fw.state_out = h->dstate;
+    bw.x = fa;
+    bw.y = y;
+    bw.ldx = ldfa;
+    bw.ldy = ldy;
+    bw.n = na;
+    return sos_launch_dual<32, 4>(fw, bw, st);
 }
 
 int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t na,
