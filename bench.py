@@ -132,6 +132,10 @@ def main():
         elapsed = float(t.item())
     barrier()
 
+    # order-independent checksum of the last output chunk (also the 8 B/lane
+    # streaming read of known size that calibrates FETCH_SIZE in the PMC runs)
+    bits, fsum = dev.checksum(y_out)
+
     samples_per_step = C * CHUNK
     value = samples_per_step * args.steps * world / elapsed / 1e6
 
@@ -173,6 +177,7 @@ def main():
         "chain_hbm_gbps": value * 1e6 * CHAIN_BYTES / 1e9 / world,
         "chain_hbm_frac": value * 1e6 * CHAIN_BYTES / 1e9 / world / HBM_PEAK_GBPS,
         "roofline": roofline, "kernels": kernels,
+        "output_checksum": {"bits": f"{bits:#018x}", "sum": fsum},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(h, sos)
