@@ -208,6 +208,9 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n,
  * segment count so far -- a multi-GPU time split reduces these (RCCL) before
  * dividing.  The pointer stays owned by the handle. */
 int osz_spec_sum(osz_spec_t h, double **dsum, int64_t *count);
+/* PSD_MEAN: copies the raw sum into a caller-owned device buffer (nch, nfreq),
+ * e.g. a tensor handed to an RCCL all-reduce. Asynchronous on `stream`. */
+int osz_spec_export_sum(osz_spec_t h, double *dst, int64_t *count, void *stream);
 /* PSD_MEAN: mean = sum / count into host array (nch, nfreq). Synchronous. */
 int osz_spec_mean(osz_spec_t h, double *mean, int64_t *count, void *stream);
 

@@ -298,6 +298,15 @@ class SpecStream(_Handle):
                                          ctypes.byref(cnt)))
         return dsum, cnt.value
 
+    def export_sum(self, device="cuda"):
+        """(CUDA tensor copy of the running periodogram sum, segment count)."""
+        out = torch.empty((self.nch, self.nfreq), dtype=torch.float64,
+                          device=device)
+        cnt = ctypes.c_int64()
+        _lib.check(self.lib.osz_spec_export_sum(self.h, ptr(out),
+                                                ctypes.byref(cnt), stream_ptr()))
+        return out, cnt.value
+
     def mean(self):
         out = np.empty((self.nch, self.nfreq))
         cnt = ctypes.c_int64()

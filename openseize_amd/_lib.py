@@ -96,6 +96,7 @@ SIGNATURES = {
                                      ctypes.POINTER(c_i64), c_vp]),
     "osz_spec_sum": (ctypes.c_int, [c_vp, ctypes.POINTER(c_vp),
                                     ctypes.POINTER(c_i64)]),
+    "osz_spec_export_sum": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
     "osz_spec_mean": (ctypes.c_int, [c_vp, c_dp, ctypes.POINTER(c_i64), c_vp]),
     "osz_take": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp,
                                 c_i64, c_vp]),

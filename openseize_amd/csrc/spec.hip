@@ -369,6 +369,15 @@ int osz_spec_sum(osz_spec_t h, double **dsum, int64_t *count) {
     return OSZ_OK;
 }
 
+int osz_spec_export_sum(osz_spec_t h, double *dst, int64_t *count, void *stream) {
+    OSZ_REQUIRE(h && dst && count, "osz_spec_export_sum: null argument");
+    OSZ_REQUIRE(h->mode == OSZ_SPEC_PSD_MEAN, "osz_spec_export_sum: handle is not in PSD_MEAN mode");
+    OSZ_HIP(hipMemcpyAsync(dst, h->dsum, sizeof(double) * (size_t)h->nch * h->nfreq,
+                           hipMemcpyDeviceToDevice, as_stream(stream)));
+    *count = h->count;
+    return OSZ_OK;
+}
+
 int osz_spec_mean(osz_spec_t h, double *mean, int64_t *count, void *stream) {
     OSZ_REQUIRE(h && mean && count, "osz_spec_mean: null argument");
     OSZ_REQUIRE(h->mode == OSZ_SPEC_PSD_MEAN, "osz_spec_mean: handle is not in PSD_MEAN mode");

@@ -1,0 +1,106 @@
+"""Multi-rank logic on CPU: gloo backend, world_size 2 (spawned processes).
+Covers the channel/time partition and the Welch segment-average reduce that
+runs over RCCL on the GPUs."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from openseize_amd import sharding
+
+
+def test_channel_and_time_blocks():
+    for nch, world in ((256, 8), (10, 4), (3, 8), (1024, 8)):
+        blocks = [sharding.channel_block(nch, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == nch
+        assert all(a[1] == b[0] for a, b in zip(blocks[:-1], blocks[1:]))
+        sizes = [b - a for a, b in blocks]
+        assert max(sizes) - min(sizes) <= 1
+    # time split: every segment exactly once, halo included
+    n, nfft, stride = 100000, 4096, 2048
+    nseg = (n - nfft) // stride + 1
+    seen = []
+    for r in range(8):
+        a, b = sharding.time_block(n, nfft, stride, r, 8)
+        assert a % stride == 0 and (b - a - nfft) % stride == 0 and b <= n
+        seen += list(range(a // stride, a // stride + (b - a - nfft) // stride + 1))
+    assert seen == list(range(nseg))
+    assert sharding.time_block(100, 4096, 2048, 0, 2) == (0, 0)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _segments(rank):
+    return np.random.default_rng(100 + rank).random((5 + rank, 4, 33))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # per-rank periodogram sums and counts, as the SpecStream would export
+        seg = _segments(rank)                          # (segments, ch, freq)
+        total = torch.from_numpy(seg.sum(0))
+        mean, cnt = sharding.reduce_segment_sums(total, seg.shape[0])
+        # channel all-gather with unequal blocks (5 channels over 2 ranks)
+        a, b = sharding.channel_block(5, rank, world)
+        local = (torch.arange(a, b, dtype=torch.float64).reshape(-1, 1)
+                 * torch.ones(1, 3, dtype=torch.float64))
+        full = sharding.gather_channels(local, 5)
+        q.put((rank, mean.numpy(), cnt, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_welch_reduce_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    allseg = np.concatenate([_segments(r) for r in range(world)], 0)
+    # the reference's running mean over all segments (estimators.py:149-152)
+    running = 0
+    for c, arr in enumerate(allseg, 1):
+        running = running + 1 / c * (arr - running)
+    for rank, mean, cnt, full in results:
+        assert cnt == allseg.shape[0]
+        assert np.max(np.abs(mean - running)) < 1e-14
+        assert np.array_equal(full[:, 0], np.arange(5.0))
+
+
+@pytest.mark.gpu
+def test_psd_time_split_single_gpu(golden):
+    """world_size 1 on the GPU: the time-split driver equals psd(); two time
+    blocks run back to back recombine to the same mean."""
+    from openseize_amd.spectra.estimators import psd
+    g = golden("g7_welch.npz")
+    x = g["x"]
+    ref = g["psd_ov0.5"]
+    cnt, f, p = sharding.psd_time_split(torch.from_numpy(x).cuda(), 1024, 0, 1,
+                                        resolution=1.0)
+    assert cnt == int(g["cnt_ov0.5"])
+    assert np.max(np.abs(p.cpu().numpy() - ref)) < 1e-9 * np.max(ref)
+    parts = []
+    for r in range(2):
+        a, b = sharding.time_block(x.shape[-1], 1024, 512, r, 2)
+        c, _, pr = psd(x[:, a:b], 1024, resolution=1.0)
+        parts.append((c, pr))
+    tot = sum(c * pr for c, pr in parts) / sum(c for c, _ in parts)
+    assert sum(c for c, _ in parts) == cnt
+    assert np.max(np.abs(tot - ref)) < 1e-9 * np.max(ref)
