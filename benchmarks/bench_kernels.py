@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Secondary measurements: the other kernels of the path at the shapes of
+BASELINE.json configs 4 and 5 (per-GPU shard), against their own algorithmic
+bytes.  Prints one JSON object per workload.  The
+headline metric is bench.py's; this script feeds DESIGN.md / profiles/."""
+
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(fn, reps):
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev
+    from openseize_amd import _lib
+    from openseize_amd.filtering.fir import Kaiser
+    CH, N = 256, 1 << 20
+    x = dev.synth_normal(CH, N, seed=3)
+    out = []
+
+    # cfg-4: Welch PSD, nperseg 4096, 50 % overlap, hann, density (8 B / sample)
+    nfft, fs = 4096, 4096.0
+    w = sps.get_window("hann", nfft)
+    scale = float(np.sqrt(1 / (fs * np.sum(w ** 2))))
+    spec = dev.SpecStream(nfft, nfft, nfft // 2, w, scale, "constant",
+                          _lib.SPEC_PSD_MEAN, CH)
+    dt = timed(lambda: spec.push(x), 5)
+    out.append({"workload": "cfg-4 Welch PSD 256 ch x 2^20, nfft 4096, 50 %",
+                "ms_per_chunk": dt * 1e3, "Msamples_s": CH * N / dt / 1e6,
+                "algorithmic_GBps": 8 * CH * N / dt / 1e9})
+    spec.close()
+
+    # cfg-5 part 1: polyphase downsample 5 -> 1, default Kaiser (113 taps)
+    cutoff = 20480 / 10
+    h = Kaiser(cutoff - cutoff / 10, cutoff + cutoff / 10, 20480, gpass=0.1, gstop=40).coeffs
+    poly = dev.PolyStream(h, 1, 5, CH)
+    dt = timed(lambda: poly.push(x, final=False), 5)
+    out.append({"workload": f"cfg-5 downsample M=5 ({len(h)} taps) 256 ch x 2^20",
+                "ms_per_chunk": dt * 1e3, "Msamples_s": CH * N / dt / 1e6,
+                "algorithmic_GBps": 9.6 * CH * N / dt / 1e9})
+    poly.close()
+
+    # cfg-5 part 2: STFT segments (complex128 out), nfft 4096, 50 % (24 B / sample)
+    xs = x[:, : 1 << 18].contiguous()
+    stft = dev.SpecStream(nfft, nfft, nfft // 2, w, scale, "constant",
+                          _lib.SPEC_DFT_SEGMENTS, CH)
+    dt = timed(lambda: stft.push(xs), 5)
+    out.append({"workload": "cfg-5 STFT 256 ch x 2^18, nfft 4096, 50 %",
+                "ms_per_chunk": dt * 1e3, "Msamples_s": CH * xs.shape[1] / dt / 1e6,
+                "algorithmic_GBps": 24 * CH * xs.shape[1] / dt / 1e9})
+    stft.close()
+
+    # mask compaction (K7), 50 % density
+    idx = torch.arange(0, N, 2, dtype=torch.int64, device="cuda")
+    dt = timed(lambda: dev.take(x, idx), 5)
+    out.append({"workload": "K7 take 256 ch x 2^20, every 2nd sample",
+                "ms_per_chunk": dt * 1e3, "Msamples_s": CH * N / dt / 1e6,
+                "algorithmic_GBps": 12 * CH * N / dt / 1e9})
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()

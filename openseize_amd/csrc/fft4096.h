@@ -20,7 +20,8 @@
 // slot1 = k0*258 + n1*16 + n0, exchange 2 uses slot2 = n0*272 + k1*16 + k0:
 // the writer side is always lane-contiguous, the reader side strides 258
 // (= 2 mod 32) resp. 272 (= 16 mod 32) doubles, which keeps the 32-lane b64
-// read groups conflict free.
+// read groups conflict free.  (Measured: the alternative with layout B as
+// t = n0 + 16 k0 and strides 272 / 273 is 20 % slower.)
 //
 // The phase functions are __host__ __device__ so tests/fft_host_check.cpp can
 // replay the 256 threads on the CPU and pin the index math without a GPU.
@@ -38,8 +39,8 @@ namespace fft {
 
 constexpr int N = 4096;
 constexpr int NT = 256;          // threads per transform
-constexpr int S1 = 258;          // exchange-1 row stride (doubles)
-constexpr int S2 = 272;          // exchange-2 row stride (doubles)
+constexpr int S1 = 258;          // exchange-1 row stride (doubles), = 2 mod 32
+constexpr int S2 = 272;          // exchange-2 row stride (doubles), = 16 mod 32
 constexpr int PLANE = 16 * S2;   // doubles per plane (>= 16*S1)
 
 // after fwd16 register r holds logical index dr(r); inv16 expects the same
@@ -127,16 +128,41 @@ struct Tables {
     const double *t2;  // [16][16][2]   W256^(n0 k1)
 };
 
+// Pass-1 twiddles W4096^(t k0), k0 = 1..15, for this thread: only the four
+// power-of-two ones are loaded (64 B instead of 240 B of L2 traffic per
+// thread and pass); the others are products of at most three of them.
+OSZ_HD void t1_powers(int t, const Tables &tb, double *wr, double *wi) {
+#define OSZ_LD(K) wr[K] = tb.t1[((K) * 256 + t) * 2]; wi[K] = tb.t1[((K) * 256 + t) * 2 + 1];
+#define OSZ_MUL(C, A, B) wr[C] = wr[A] * wr[B] - wi[A] * wi[B]; wi[C] = wr[A] * wi[B] + wi[A] * wr[B];
+    OSZ_LD(1) OSZ_LD(2) OSZ_LD(4) OSZ_LD(8)
+    OSZ_MUL(3, 1, 2) OSZ_MUL(5, 1, 4) OSZ_MUL(6, 2, 4) OSZ_MUL(7, 3, 4)
+    OSZ_MUL(9, 1, 8) OSZ_MUL(10, 2, 8) OSZ_MUL(11, 3, 8) OSZ_MUL(12, 4, 8)
+    OSZ_MUL(13, 5, 8) OSZ_MUL(14, 6, 8) OSZ_MUL(15, 7, 8)
+#undef OSZ_LD
+#undef OSZ_MUL
+}
+
 // ---- forward phases ----------------------------------------------------
 // F1: registers hold x[256 j + t] at register j (layout A).  Pass 1, twiddle,
 // store to exchange 1.
+template <bool POW = true>
 OSZ_HD void f1(int t, double *re, double *im, const Tables &tb, double *pr, double *pi) {
+    double twr[16], twi[16];
+    if constexpr (POW) {
+        t1_powers(t, tb, twr, twi);
+    } else {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            twr[k] = tb.t1[(k * 256 + t) * 2];
+            twi[k] = tb.t1[(k * 256 + t) * 2 + 1];
+        }
+    }
     fwd16(re, im);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int k0 = dr(r);
         if (k0 != 0) {
-            const double wr = tb.t1[(k0 * 256 + t) * 2], wi = tb.t1[(k0 * 256 + t) * 2 + 1];
+            const double wr = twr[k0], wi = twi[k0];
             const double a = re[r], b = im[r];
             re[r] = a * wr - b * wi;
             im[r] = a * wi + b * wr;
@@ -236,14 +262,25 @@ OSZ_HD void i2_compute_store(int t, double *re, double *im, double *pr, double *
 
 // I1: load layout A with logical k0 at register dr(k0), conj twiddle, inverse
 // pass 1.  Afterwards register j holds y[256 j + t] (times 4096).
+template <bool POW = true>
 OSZ_HD void i1(int t, double *re, double *im, const Tables &tb, const double *pr,
                const double *pi) {
+    double twr[16], twi[16];
+    if constexpr (POW) {
+        t1_powers(t, tb, twr, twi);
+    } else {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            twr[k] = tb.t1[(k * 256 + t) * 2];
+            twi[k] = tb.t1[(k * 256 + t) * 2 + 1];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int k0 = dr(r);
         double a = pr[k0 * S1 + t], b = pi[k0 * S1 + t];
         if (k0 != 0) {
-            const double wr = tb.t1[(k0 * 256 + t) * 2], wi = -tb.t1[(k0 * 256 + t) * 2 + 1];
+            const double wr = twr[k0], wi = -twi[k0];
             const double a2 = a * wr - b * wi;
             b = a * wi + b * wr;
             a = a2;

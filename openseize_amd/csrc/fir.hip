@@ -22,6 +22,7 @@
 //     samples) and written once (8 B): 16 B per channel-sample; twiddles and
 //     H (64 KB each) stay L2 resident.
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -43,6 +44,7 @@ struct FirArgs {
     double *tails;    // [nch][nruns][wlen-1]
 };
 
+template <bool POW>
 __global__ __launch_bounds__(256) void fir_oa_kernel(FirArgs a) {
     extern __shared__ double lds[];
     double *pr = lds;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void fir_oa_kernel(FirArgs a) {
             im[j] = p < len_b ? xr[start_b + p] : 0.0;
         }
         // ---- forward transform
-        fft::f1(t, re, im, a.tb, pr, pi);
+        fft::f1<POW>(t, re, im, a.tb, pr, pi);
         __syncthreads();
         fft::f2_load(t, re, im, pr, pi);
         fft::f2_compute(t, re, im, a.tb);
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void fir_oa_kernel(FirArgs a) {
         __syncthreads();
         fft::i2_compute_store(t, re, im, pr, pi, true);
         __syncthreads();
-        fft::i1(t, re, im, a.tb, pr, pi);
+        fft::i1<POW>(t, re, im, a.tb, pr, pi);
         __syncthreads();
         // ---- overlap add.  re[j] = a[256 j + t], im[j] = b[256 j + t]
         double *xb = pr;  // a's tail handed to b's head
@@ -326,10 +328,15 @@ int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y
         h->nruns_cap = (int)nruns;
     }
     static bool attr_set = false;
+    static bool pow_tw = true;    // pass-1 twiddles as products of 4 loaded powers (OSZ_FIR_T1POW=0: table)
     const size_t lds = sizeof(double) * (2 * fft::PLANE + 2048);
     if (!attr_set) {
-        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fir_oa_kernel),
+        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fir_oa_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fir_oa_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const char *e = getenv("OSZ_FIR_T1POW");
+        pow_tw = !(e && atoi(e) == 0);   // default on: measured 2.4 % faster
         attr_set = true;
     }
     FirArgs a{};
@@ -350,7 +357,12 @@ int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y
     const size_t lds_used = sizeof(double) * (2 * fft::PLANE + (wm1 > 0 ? wm1 : 1));
     {
         KernelTimer kt("fir_oa", st);
-        hipLaunchKernelGGL(fir_oa_kernel, dim3((unsigned)nruns, h->nch), dim3(256), lds_used, st, a);
+        if (pow_tw)
+            hipLaunchKernelGGL(fir_oa_kernel<true>, dim3((unsigned)nruns, h->nch), dim3(256),
+                               lds_used, st, a);
+        else
+            hipLaunchKernelGGL(fir_oa_kernel<false>, dim3((unsigned)nruns, h->nch), dim3(256),
+                               lds_used, st, a);
     }
     OSZ_HIP(hipGetLastError());
     if (wm1 > 0) {
