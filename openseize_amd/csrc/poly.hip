@@ -50,6 +50,57 @@ __global__ __launch_bounds__(256) void poly_kernel(PolyArgs a) {
     }
 }
 
+// Fast path for decimation (L == 1):  out[j] = sum_k hL[k] x[j M + half - k].
+// A 256-thread workgroup produces 256*R consecutive outputs of one channel:
+// the input window (256 R M + ntaps - M samples) is staged once in LDS with
+// coalesced loads; thread t accumulates outputs j0 + t + 256 r, r < R, reading
+// its taps from LDS (lane stride M doubles: conflict free for odd M) while the
+// coefficient of each tap is wave-uniform (scalar load).  HBM sees every input
+// once and every output once.
+template <int R>
+__global__ __launch_bounds__(256) void poly_decim_kernel(PolyArgs a,
+                                                         const double *__restrict__ hL) {
+    extern __shared__ double win[];
+    const int c = blockIdx.y;
+    const int t = threadIdx.x;
+    const double *xr = a.x + (int64_t)c * a.ldx;
+    const double *hr = a.hist + (int64_t)c * a.H;
+    double *yr = a.y + (int64_t)c * a.ldy;
+    const int64_t jt = a.j0 + (int64_t)blockIdx.x * (256 * R);   // first output of this tile
+    const int nj = (int)((a.j1 - jt) < (256 * R) ? (a.j1 - jt) : (256 * R));
+    // window: inputs [i0, i0 + wlen)
+    const int64_t i0 = jt * a.M + a.half - (a.m - 1);
+    const int wlen = (nj - 1) * a.M + a.m;
+    for (int q = t; q < wlen; q += 256) {
+        const int64_t i = i0 + q;
+        double v = 0.0;
+        if (i >= 0 && i < a.navail)
+            v = i >= a.nin ? xr[i - a.nin] : (i >= a.nin - a.H ? hr[i - (a.nin - a.H)] : 0.0);
+        win[q] = v;
+    }
+    __syncthreads();
+    // output j = jt + t + 256 r reads win[(t + 256 r) M + (m - 1) - k]
+    double acc[R];
+    const double *base[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        acc[r] = 0.0;
+        const int o = t + 256 * r;
+        base[r] = win + (o < nj ? o : 0) * a.M + (a.m - 1);
+    }
+#pragma unroll 4
+    for (int k = 0; k < a.m; ++k) {
+        const double ck = hL[k];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = fma(ck, base[r][-k], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int o = t + 256 * r;
+        if (o < nj) yr[(jt - a.j0) + o] = acc[r];
+    }
+}
+
 // newhist = last H samples of (hist ++ x[0:n])
 __global__ void poly_hist_kernel(const double *x, int64_t ldx, int64_t n, const double *hist,
                                  double *newhist, int H) {
@@ -162,9 +213,17 @@ int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n, int fin
         a.M = h->M;
         a.H = h->H;
         a.half = h->half;
-        int64_t bx = (cnt + 255) / 256;
-        if (bx > 4096) bx = 4096;
-        {
+        constexpr int R = 4;
+        const size_t lds = sizeof(double) * ((size_t)(256 * R - 1) * h->M + h->m);
+        if (h->L == 1 && lds <= 64 * 1024) {
+            // decimation fast path: LDS-tiled, 256*R outputs per workgroup
+            const int64_t bx = (cnt + 256 * R - 1) / (256 * R);
+            KernelTimer kt("poly_decim", st);
+            hipLaunchKernelGGL(poly_decim_kernel<R>, dim3((unsigned)bx, h->nch), dim3(256), lds, st,
+                               a, h->dhL);
+        } else {
+            int64_t bx = (cnt + 255) / 256;
+            if (bx > 4096) bx = 4096;
             KernelTimer kt("poly", st);
             hipLaunchKernelGGL(poly_kernel, dim3((unsigned)bx, h->nch), dim3(256), 0, st, a);
         }

@@ -17,12 +17,16 @@
 // reference becomes a (nch, < nfft) carry buffer on the device.
 #include <rocfft/rocfft.h>
 
+#include <cstdlib>
 #include <map>
 #include <vector>
 
 #include "common.h"
+#include "fft4096.h"
 
 namespace osz {
+
+int get_fft_tables(fft::Tables &out);  // fir.hip
 
 #define OSZ_FFT(call)                                                               \
     do {                                                                            \
@@ -134,6 +138,172 @@ __global__ void spec_carry_kernel(const double *x, int64_t ldx, const double *ca
         v < ncarry ? carry[(int64_t)c * ncap + v] : x[(int64_t)c * ldx + (v - ncarry)];
 }
 
+
+// ---------------------------------------------------------------------------
+// Fused on-chip path for nwin == nfft == 4096 (cfg-4 / cfg-5): one workgroup
+// walks a run of consecutive segment PAIRS of one channel.  The two real
+// segments of a pair ride one 4096-point complex transform (fft4096.h);
+// detrend and window are applied in registers on the way in, the two spectra
+// are separated with one LDS exchange (A[k] = (Z[k] + conj Z[N-k]) / 2,
+// B[k] = (Z[k] - conj Z[N-k]) / 2i), and scaling, |.|^2, one-sided doubling
+// and the segment sum happen in registers.  No staging rows: HBM sees each
+// sample once (the 50 % overlap re-read of the neighbouring pair hits L2) and,
+// for the segment modes, each output bin once.
+struct FusedArgs {
+    const double *x;
+    const double *carry;
+    const double *window;   // 4096
+    void *out;              // SEGMENTS modes: (nseg, nch, 2049) f64 / c128
+    double *partial;        // PSD_MEAN: (nch, nruns, 2049) sums of this launch
+    int64_t ldx, ncarry, ncap;
+    int64_t nseg;           // complete segments in carry ++ chunk
+    int stride, nch, detrend, R, nruns;
+    double scale;
+    fft::Tables tb;
+};
+
+constexpr int kNF = 2049;   // nfft / 2 + 1
+
+template <int MODE>
+__global__ __launch_bounds__(256) void spec_fused_kernel(FusedArgs a) {
+    extern __shared__ double lds[];
+    double *pr = lds;
+    double *pi = lds + fft::PLANE;
+    __shared__ double red[4][4];
+    const int t = threadIdx.x;
+    const int run = blockIdx.x;
+    const int c = blockIdx.y;
+    const double *cr = a.carry + (int64_t)c * a.ncap;
+    const double *xr = a.x + (int64_t)c * a.ldx;
+    const int64_t npairs = (a.nseg + 1) / 2;
+    const int64_t p0 = (int64_t)run * a.R;
+    const int64_t p1 = (p0 + a.R < npairs) ? p0 + a.R : npairs;
+    const double mid = 0.5 * (fft::N - 1);
+    const double s2 = a.scale * a.scale;
+
+    double acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = 0.0;
+
+    double re[16], im[16];
+    for (int64_t p = p0; p < p1; ++p) {
+        const int64_t sa = 2 * p, sb = 2 * p + 1;
+        const bool has_b = sb < a.nseg;
+        const int64_t va = sa * (int64_t)a.stride, vb = va + a.stride;
+        // ---- load both segments (virtual stream = carry ++ chunk)
+        double sum_a = 0.0, sum_b = 0.0, lin_a = 0.0, lin_b = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = 256 * j + t;
+            const int64_t ia = va + i, ib = vb + i;
+            re[j] = ia < a.ncarry ? cr[ia] : xr[ia - a.ncarry];
+            im[j] = has_b ? (ib < a.ncarry ? cr[ib] : xr[ib - a.ncarry]) : 0.0;
+            sum_a += re[j];
+            sum_b += im[j];
+            lin_a += (i - mid) * re[j];
+            lin_b += (i - mid) * im[j];
+        }
+        // ---- trend: block sums
+        for (int off = 32; off > 0; off >>= 1) {
+            sum_a += __shfl_down(sum_a, off, 64);
+            sum_b += __shfl_down(sum_b, off, 64);
+            lin_a += __shfl_down(lin_a, off, 64);
+            lin_b += __shfl_down(lin_b, off, 64);
+        }
+        if ((t & 63) == 0) {
+            red[t >> 6][0] = sum_a;
+            red[t >> 6][1] = sum_b;
+            red[t >> 6][2] = lin_a;
+            red[t >> 6][3] = lin_b;
+        }
+        __syncthreads();
+        const double mean_a = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) / fft::N;
+        const double mean_b = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) / fft::N;
+        double slope_a = 0.0, slope_b = 0.0;
+        if (a.detrend == OSZ_DETREND_LINEAR) {
+            const double sxx = (double)fft::N * ((double)fft::N * fft::N - 1.0) / 12.0;
+            slope_a = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) / sxx;
+            slope_b = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) / sxx;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = 256 * j + t;
+            const double w = a.window[i];
+            re[j] = (re[j] - mean_a - slope_a * (i - mid)) * w;
+            im[j] = has_b ? (im[j] - mean_b - slope_b * (i - mid)) * w : 0.0;
+        }
+        // ---- forward transform of a + i b
+        fft::f1<true>(t, re, im, a.tb, pr, pi);
+        __syncthreads();
+        fft::f2_load(t, re, im, pr, pi);
+        fft::f2_compute(t, re, im, a.tb);
+        __syncthreads();
+        fft::f2_store(t, re, im, pr, pi);
+        __syncthreads();
+        fft::f3(t, re, im, pr, pi);
+        __syncthreads();
+        // ---- separate the two spectra: exchange Z in natural order
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = t + 256 * fft::dr(r);
+            pr[k] = re[r];
+            pi[k] = im[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = fft::dr(r);
+            if (j > 8) continue;
+            const int k = t + 256 * j;
+            if (j == 8 && t != 0) continue;
+            const int kp = (fft::N - k) & (fft::N - 1);
+            const double zr = re[r], zi = im[r], qr = pr[kp], qi = pi[kp];
+            const double ar = 0.5 * (zr + qr), ai = 0.5 * (zi - qi);
+            const double br = 0.5 * (zi + qi), bi = -0.5 * (zr - qr);
+            const bool dbl = (k != 0) && (k != fft::N / 2);
+            if (MODE == OSZ_SPEC_DFT_SEGMENTS) {
+                double *o = (double *)a.out;
+                const int64_t ia = ((sa * a.nch + c) * (int64_t)kNF + k) * 2;
+                o[ia] = ar * a.scale;
+                o[ia + 1] = ai * a.scale;
+                if (has_b) {
+                    const int64_t ib = ((sb * a.nch + c) * (int64_t)kNF + k) * 2;
+                    o[ib] = br * a.scale;
+                    o[ib + 1] = bi * a.scale;
+                }
+            } else {
+                const double f = dbl ? 2.0 * s2 : s2;
+                const double pa = (ar * ar + ai * ai) * f;
+                const double pb = (br * br + bi * bi) * f;
+                if (MODE == OSZ_SPEC_PSD_SEGMENTS) {
+                    double *o = (double *)a.out;
+                    o[(sa * a.nch + c) * (int64_t)kNF + k] = pa;
+                    if (has_b) o[(sb * a.nch + c) * (int64_t)kNF + k] = pb;
+                } else {
+                    acc[j] += has_b ? pa + pb : pa;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == OSZ_SPEC_PSD_MEAN) {
+        double *o = a.partial + ((int64_t)c * a.nruns + run) * kNF;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[t + 256 * j] = acc[j];
+        if (t == 0) o[2048] = acc[8];
+    }
+}
+
+// dsum[c][k] += sum over runs of partial[c][run][k], fixed order (deterministic)
+__global__ void spec_partial_reduce_kernel(const double *partial, double *dsum, int nruns) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (k >= kNF) return;
+    double s = 0.0;
+    for (int r = 0; r < nruns; ++r) s += partial[((int64_t)c * nruns + r) * kNF + k];
+    dsum[(int64_t)c * kNF + k] += s;
+}
+
 }  // namespace osz
 
 using namespace osz;
@@ -153,6 +323,10 @@ struct osz_spec_s {
     void *dwork;
     size_t work_cap;
     std::map<int64_t, rocfft_plan> *plans;  // keyed by batch (rows)
+    bool fused;          // nwin == nfft == 4096: on-chip path
+    double *dpartial;    // fused PSD_MEAN: (nch, nruns_cap, 2049)
+    int64_t partial_cap;
+    fft::Tables tb;
 };
 
 static const int64_t kSpecMaxElems = (int64_t)1 << 27;  // staging doubles per batch (1 GiB)
@@ -207,6 +381,16 @@ int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride, const double 
     p->dwork = nullptr;
     p->work_cap = 0;
     p->plans = new std::map<int64_t, rocfft_plan>();
+    p->dpartial = nullptr;
+    p->partial_cap = 0;
+    {
+        const char *e = getenv("OSZ_SPEC_FUSED");
+        p->fused = (nwin == fft::N && nfft == fft::N) && !(e && atoi(e) == 0);
+        if (p->fused) {
+            int rc = get_fft_tables(p->tb);
+            if (rc) { delete p->plans; delete p; return rc; }
+        }
+    }
     const size_t cb = sizeof(double) * (size_t)nch * p->ncap;
     const size_t ab = sizeof(double) * (size_t)nch * p->nfreq;
     OSZ_HIP(hipMalloc(&p->dwindow, sizeof(double) * nwin));
@@ -230,6 +414,7 @@ int osz_spec_destroy(osz_spec_t h) {
     (void)hipFree(h->drows);
     (void)hipFree(h->dspec);
     (void)hipFree(h->dwork);
+    (void)hipFree(h->dpartial);
     delete h;
     return OSZ_OK;
 }
@@ -257,7 +442,70 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
     const int64_t total = h->ncarry + n;
     const int64_t nseg = osz_spec_seg_count(h, n);
     OSZ_REQUIRE(nseg == 0 || h->mode == OSZ_SPEC_PSD_MEAN || out, "osz_spec_push: null output");
-    if (nseg > 0) {
+    if (nseg > 0 && h->fused) {
+        const int64_t npairs = (nseg + 1) / 2;
+        // run length: enough workgroups to fill the chip, long runs for L2 reuse
+        int64_t R = (npairs * h->nch) / 2048;
+        if (R > 32) R = 32;
+        if (R < 1) R = 1;
+        const int64_t nruns = (npairs + R - 1) / R;
+        FusedArgs fa{};
+        fa.x = x ? x : h->dcarry[h->cur];
+        fa.carry = h->dcarry[h->cur];
+        fa.window = h->dwindow;
+        fa.out = out;
+        fa.ldx = ldx;
+        fa.ncarry = h->ncarry;
+        fa.ncap = h->ncap;
+        fa.nseg = nseg;
+        fa.stride = h->stride;
+        fa.nch = h->nch;
+        fa.detrend = h->detrend;
+        fa.R = (int)R;
+        fa.nruns = (int)nruns;
+        fa.scale = h->scale;
+        fa.tb = h->tb;
+        if (h->mode == OSZ_SPEC_PSD_MEAN) {
+            const int64_t need = (int64_t)h->nch * nruns * kNF;
+            if (need > h->partial_cap) {
+                OSZ_HIP(hipStreamSynchronize(st));
+                (void)hipFree(h->dpartial);
+                h->dpartial = nullptr;
+                if (hipMalloc(&h->dpartial, sizeof(double) * need) != hipSuccess)
+                    return fail(OSZ_ERR_NOMEM, "osz_spec_push: partial sums (%lld doubles)", (long long)need);
+                h->partial_cap = need;
+            }
+            fa.partial = h->dpartial;
+        }
+        const size_t lds = sizeof(double) * 2 * fft::PLANE;
+        static bool attr_set = false;
+        if (!attr_set) {
+            OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spec_fused_kernel<0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spec_fused_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spec_fused_kernel<2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        {
+            KernelTimer kt("spec_fused", st);
+            const dim3 grid((unsigned)nruns, h->nch), block(256);
+            if (h->mode == OSZ_SPEC_PSD_MEAN)
+                hipLaunchKernelGGL(spec_fused_kernel<OSZ_SPEC_PSD_MEAN>, grid, block, lds, st, fa);
+            else if (h->mode == OSZ_SPEC_PSD_SEGMENTS)
+                hipLaunchKernelGGL(spec_fused_kernel<OSZ_SPEC_PSD_SEGMENTS>, grid, block, lds, st, fa);
+            else
+                hipLaunchKernelGGL(spec_fused_kernel<OSZ_SPEC_DFT_SEGMENTS>, grid, block, lds, st, fa);
+        }
+        OSZ_HIP(hipGetLastError());
+        if (h->mode == OSZ_SPEC_PSD_MEAN) {
+            hipLaunchKernelGGL(spec_partial_reduce_kernel, dim3((kNF + 255) / 256, h->nch), dim3(256),
+                               0, st, h->dpartial, h->dsum, (int)nruns);
+            OSZ_HIP(hipGetLastError());
+        }
+        h->count += nseg;
+    } else if (nseg > 0) {
         int64_t segs_per_batch = kSpecMaxElems / ((int64_t)h->nch * h->nfft);
         if (segs_per_batch < 1) segs_per_batch = 1;
         if (segs_per_batch > nseg) segs_per_batch = nseg;

@@ -296,6 +296,44 @@ def test_stft_golden(osz, golden):
     assert np.max(np.abs(X - g["pro_X"])) < RTOL * np.max(np.abs(g["pro_X"]))
 
 
+def test_spectra_fused_4096(osz):
+    """nfft = 4096 takes the fused on-chip path (pairs of segments per
+    transform): check all three modes, both detrends, odd and even segment
+    counts and ragged pushes against the oracle and the rocFFT path."""
+    import os
+    from oracle import oracle as orc
+    from openseize_amd.spectra.estimators import psd, stft
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((3, 47001)) + np.linspace(0, 2, 47001)
+    fs = 4096
+    for ov in (0.5, 0.0, 0.75):
+        for detrend in ("constant", "linear"):
+            cnt, f, p = psd(x, fs, axis=-1, resolution=1.0, overlap=ov, detrend=detrend)
+            c2, f2, p2 = orc.psd(x, fs, resolution=1.0, overlap=ov, detrend=detrend)
+            assert cnt == c2 and np.array_equal(f, f2)
+            assert rel_err(p, p2) < RTOL
+    # per-segment producers, chunksize that splits segments across pushes
+    pro = producer(x, 5000, -1)
+    f, wp = osz.welch(pro, fs, 4096, "hamming", 0.5, -1, "linear", "spectrum")
+    segs = list(wp)
+    f2, ref = orc.welch_segments(x, fs, 4096, "hamming", 0.5, "linear", "spectrum")
+    assert len(segs) == len(ref)
+    for a, b in zip(segs, ref):
+        assert rel_err(a, b) < RTOL
+    f, t, X = stft(x, fs, axis=-1, resolution=1.0, boundary=True, padded=True)
+    f2, t2, X2 = orc.stft(x, fs, resolution=1.0, boundary=True, padded=True)
+    assert X.shape == X2.shape and np.allclose(t, t2)
+    assert np.max(np.abs(X - X2)) < RTOL * np.max(np.abs(X2))
+    # fused and rocFFT paths agree
+    os.environ["OSZ_SPEC_FUSED"] = "0"
+    try:
+        cnt0, _, p0 = psd(x, fs, axis=-1, resolution=1.0)
+    finally:
+        del os.environ["OSZ_SPEC_FUSED"]
+    cnt1, _, p1 = psd(x, fs, axis=-1, resolution=1.0)
+    assert cnt0 == cnt1 and rel_err(p1, p0) < 1e-12
+
+
 # ------------------------------------------- device-resident chain + masking
 def test_device_resident_chain(osz, golden):
     """CUDA tensors in -> CUDA tensors out, FIR -> sosfiltfilt chained as
