@@ -74,7 +74,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
