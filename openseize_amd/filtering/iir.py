@@ -2,6 +2,7 @@
 SciPy's ``*ord`` helpers, coefficients from ``scipy.signal.iirfilter``
 (``IIR._build``)."""
 
+import numpy as np
 import scipy.signal as sps
 
 from openseize_amd.filtering.bases import IIR
@@ -45,3 +46,22 @@ class Ellip(IIR):
     def order(self):
         return sps.ellipord(self.fpass, self.fstop, self.gpass, self.gstop,
                             fs=self.fs)
+
+
+class Notch(IIR):
+    """Second-order notch in transfer-function ('ba') format
+    (filtering/iir.py:354-404): -3 dB at fstop +- width/2."""
+
+    def __init__(self, fstop, width, fs):
+        fpass = np.array([fstop - width / 2, fstop + width / 2])
+        fstops = np.array([fstop, fstop])
+        self.width = width
+        super().__init__(fpass, fstops, gpass=3, gstop=None, fs=fs, fmt="ba")
+
+    @property
+    def order(self):
+        return len(self.coeffs[0]) - 1, self.fstop[0] - self.width / 2
+
+    def _build(self):
+        center = self.fstop[0]
+        return sps.iirnotch(center, center / self.width, fs=self.fs)

@@ -51,6 +51,9 @@ def _lib():
                                          ctypes.c_int, ctypes.c_int, dp,
                                          ctypes.c_long]
         lib.osz_ref_resample.restype = None
+        lib.osz_ref_lfilter.argtypes = [dp, dp, ctypes.c_int, dp, ctypes.c_ssize_t,
+                                        dp, ctypes.c_ssize_t, ctypes.c_long, dp]
+        lib.osz_ref_lfilter.restype = None
         _LIB = lib
     return _LIB
 
@@ -266,6 +269,77 @@ def sosfiltfilt(x, sos, chunksize):
         else:
             za = np.ascontiguousarray(zi * a[:, -1:][None, :, :]).copy()
             out.append(_sosfilt_block(sos, a, za, reverse=True))
+    return np.concatenate(out, axis=-1)
+
+
+# ---------------------------------------------------------------------------
+# 8f rank 1: transfer-function filters (core/numerical.py:414-520)
+# ---------------------------------------------------------------------------
+def _norm_ba(b, a):
+    b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+    a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+    K = max(len(b), len(a)) - 1
+    bb, aa = np.zeros(K + 1), np.zeros(K + 1)
+    bb[:len(b)], aa[:len(a)] = b / a[0], a / a[0]
+    return bb, aa, K
+
+
+def _lfilter_block(b, a, K, x, z, reverse=False):
+    """One scipy.signal.lfilter call on (C, n) data, state z (C, K) in place."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    C, n = x.shape
+    y = np.empty_like(x)
+    for c in range(C):
+        zc = np.ascontiguousarray(z[c])
+        if reverse:
+            _lib().osz_ref_lfilter(_dp(b), _dp(a), K, _dp(x[c, n - 1:]), -1,
+                                   _dp(y[c, n - 1:]), -1, n, _dp(zc))
+        else:
+            _lib().osz_ref_lfilter(_dp(b), _dp(a), K, _dp(x[c]), 1, _dp(y[c]), 1,
+                                   n, _dp(zc))
+        z[c] = zc
+    return y
+
+
+def lfilter_zi(b, a):
+    """Steady-state unit-step state of the direct form (what
+    scipy.signal.lfilter_zi returns at core/numerical.py:487): with DC gain
+    g = sum(b)/sum(a), z[k] = sum_{i>k} (b[i] - a[i] g)."""
+    b, a, K = _norm_ba(b, a)
+    g = b.sum() / a.sum()
+    return np.array([np.sum(b[k + 1:] - a[k + 1:] * g) for k in range(K)])
+
+
+def lfilter(x, coeffs, chunksize, zi=None):
+    """core/numerical.py:414-446 on (C, n); zi (C, K) or None."""
+    b, a, K = _norm_ba(*coeffs)
+    x = np.asarray(x, dtype=np.float64)
+    z = np.zeros((x.shape[0], K)) if zi is None else np.array(zi, dtype=np.float64)
+    out = [_lfilter_block(b, a, K, x[:, s:s + int(chunksize)], z)
+           for s in range(0, x.shape[1], int(chunksize))]
+    return np.concatenate(out, axis=-1), z
+
+
+def filtfilt(x, coeffs, chunksize):
+    """core/numerical.py:449-520: as sosfiltfilt, with lfilter and lfilter_zi."""
+    b, a, K = _norm_ba(*coeffs)
+    x = np.asarray(x, dtype=np.float64)
+    C, N = x.shape
+    cs = int(chunksize)
+    zi = lfilter_zi(b, a)[None, :]
+    z = np.ascontiguousarray(zi * x[:, :1])
+    fwd = [_lfilter_block(b, a, K, x[:, s:s + cs], z) for s in range(0, N, cs)]
+    n = int(math.ceil(N / cs))
+    out = []
+    for idx, xa in enumerate(fwd, 1):
+        if idx < n:
+            yb = fwd[idx]
+            zb = np.ascontiguousarray(zi * yb[:, -1:])
+            _lfilter_block(b, a, K, yb, zb, reverse=True)
+            out.append(_lfilter_block(b, a, K, xa, zb, reverse=True))
+        else:
+            za = np.ascontiguousarray(zi * xa[:, -1:])
+            out.append(_lfilter_block(b, a, K, xa, za, reverse=True))
     return np.concatenate(out, axis=-1)
 
 

@@ -87,3 +87,24 @@ void osz_ref_resample(const double *x, long n, const double *h, long m, int L,
         y[j] = acc;
     }
 }
+
+/*
+ * Direct-form-II-transposed filter of order K for one channel: restates
+ * scipy.signal.lfilter as the reference calls it at core/numerical.py:445
+ * (forward, carried zi) and :508/:511/:519 (backward passes of filtfilt).
+ * b, a: K+1 coefficients each (a[0] divided out by the caller); z: K states.
+ */
+void osz_ref_lfilter(const double *b, const double *a, int K, const double *x,
+                     ptrdiff_t sx, double *y, ptrdiff_t sy, long n, double *z)
+{
+    for (long i = 0; i < n; ++i) {
+        const double v = x[i * sx];
+        /* operand order as in SciPy's C loop: z[k] = z[k+1] + b x - a y */
+        const double out = K > 0 ? z[0] + b[0] * v : b[0] * v;
+        for (int k = 0; k + 1 < K; ++k)
+            z[k] = z[k + 1] + b[k + 1] * v - a[k + 1] * out;
+        if (K > 0)
+            z[K - 1] = b[K] * v - a[K] * out;
+        y[i * sy] = out;
+    }
+}

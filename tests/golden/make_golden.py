@@ -320,6 +320,39 @@ def g9_design():
     save("g9_design.npz", **out)
 
 
+# --------------------------------------------------------------------------
+# G10 transfer-function (ba) filters: lfilter / filtfilt
+# --------------------------------------------------------------------------
+def g10_ba():
+    rng = np.random.default_rng(1010)
+    x = rng.random((2, 9001))
+    out = {"x": x}
+    filts = {
+        "butter_lp": ref_iir.Butter(fpass=100, fstop=200, fs=500, fmt="ba"),
+        "cheby1_bp": ref_iir.Cheby1(fpass=[200, 600], fstop=[150, 650], fs=2500,
+                                    fmt="ba"),
+        "ellip_lp": ref_iir.Ellip(fpass=100, fstop=200, fs=500, fmt="ba"),
+        "butter_bp": ref_iir.Butter(fpass=[300, 900], fstop=[150, 1050], fs=3000,
+                                    fmt="ba"),
+        "notch": ref_iir.Notch(60, 8, 500),
+    }
+    for name, f in filts.items():
+        b, a = f.coeffs
+        out[f"b_{name}"], out[f"a_{name}"] = b, a
+        for cs in (1000, 4000):
+            out[f"lfilter_{name}_cs{cs}"] = f(x, chunksize=cs, axis=-1, dephase=False)
+            out[f"filtfilt_{name}_cs{cs}"] = f(x, chunksize=cs, axis=-1, dephase=True)
+    # user zi for the second-order notch, sample axis first
+    b, a = filts["notch"].coeffs
+    zi = rng.standard_normal((2, 2))
+    out["notch_zi"] = zi
+    out["notch_lfilter_zi"] = np.concatenate(list(nm.lfilter(
+        producer(x, 1000, axis=-1), (b, a), -1, zi=zi)), axis=-1)
+    xt = np.ascontiguousarray(x.T)
+    out["notch_axis0"] = filts["notch"](xt, chunksize=1500, axis=0, dephase=True)
+    save("g10_ba.npz", **out)
+
+
 if __name__ == "__main__":
     g1_producer()
     g2_fir()
@@ -330,3 +363,4 @@ if __name__ == "__main__":
     g7_welch()
     g8_stft()
     g9_design()
+    g10_ba()

@@ -157,6 +157,35 @@ def test_iir_class_api(osz, golden):
     assert rel_err(y, g["cls_causal"]) < RTOL
 
 
+@pytest.mark.parametrize("name", ["butter_lp", "cheby1_bp", "ellip_lp", "butter_bp", "notch"])
+def test_ba_filters_golden(osz, golden, name):
+    """lfilter / filtfilt (ba format) run as a biquad cascade on the device.
+    Tolerance 1e-7: the cascade and the reference's direct form are two
+    realisations of the same transfer function (measured <= 3e-8 apart on
+    these filters, the 18th-order direct form being the inaccurate one)."""
+    from openseize_amd.filtering.bases import IIR
+    g = golden("g10_ba.npz")
+    x, coeffs = g["x"], (g[f"b_{name}"], g[f"a_{name}"])
+    for cs in (1000, 4000):
+        y = np.concatenate(list(osz.lfilter(producer(x, cs, -1), coeffs, -1)), -1)
+        assert rel_err(y, g[f"lfilter_{name}_cs{cs}"]) < 1e-7
+        y = np.concatenate(list(osz.filtfilt(producer(x, cs, -1), coeffs, -1)), -1)
+        assert rel_err(y, g[f"filtfilt_{name}_cs{cs}"]) < 1e-7
+    if name == "notch":
+        y = np.concatenate(list(osz.lfilter(producer(x, 1000, -1), coeffs, -1,
+                                            zi=g["notch_zi"])), -1)
+        assert rel_err(y, g["notch_lfilter_zi"]) < RTOL
+        from openseize_amd.filtering.iir import Notch
+        notch = Notch(60, 8, 500)
+        assert np.array_equal(notch.coeffs[0], coeffs[0])
+        y = notch(np.ascontiguousarray(x.T), chunksize=1500, axis=0, dephase=True)
+        assert rel_err(y, g["notch_axis0"]) < 1e-7
+    else:
+        with pytest.raises(NotImplementedError):
+            list(osz.lfilter(producer(x, 1000, -1), coeffs, -1,
+                             zi=np.zeros((2, len(coeffs[1]) - 1))))
+
+
 def test_sos_stress_narrowband(osz):
     """Poles close to the unit circle (0.5-4 Hz band at fs = 5 kHz): the
     block-parallel scan must stay within tolerance of the serial recurrence."""

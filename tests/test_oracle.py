@@ -163,3 +163,22 @@ def test_stft(golden):
     f, t, X = orc.stft(x, 256, resolution=0.5, overlap=0.75, detrend="linear",
                        window="hamming")
     assert np.allclose(t, g["pro_t"]) and np.max(np.abs(X - g["pro_X"])) < 1e-12
+
+
+BA = ["butter_lp", "cheby1_bp", "ellip_lp", "butter_bp", "notch"]
+
+
+@pytest.mark.parametrize("name", BA)
+def test_ba_filters(golden, name):
+    g = golden("g10_ba.npz")
+    x, coeffs = g["x"], (g[f"b_{name}"], g[f"a_{name}"])
+    for cs in (1000, 4000):
+        y, _ = orc.lfilter(x, coeffs, cs)
+        assert np.array_equal(y, g[f"lfilter_{name}_cs{cs}"])       # bit-exact DF2T
+        # filtfilt starts from lfilter_zi: closed form here, a linear solve in
+        # SciPy -- the 18th-order direct form amplifies that to ~1e-8
+        assert close(orc.filtfilt(x, coeffs, cs), g[f"filtfilt_{name}_cs{cs}"], 1e-7)
+    if name == "notch":
+        y, _ = orc.lfilter(x, coeffs, 1000, zi=g["notch_zi"])
+        assert close(y, g["notch_lfilter_zi"], 1e-12)
+        assert close(orc.filtfilt(x, coeffs, 1500).T, g["notch_axis0"], 1e-12)
