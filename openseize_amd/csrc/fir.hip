@@ -37,7 +37,7 @@ struct FirArgs {
     const double *x;
     double *y;
     int64_t ldx, ldy, n, skip;
-    int wlen, step, R, nruns;
+    int wlen, step, R, nruns, accum;   // accum: y += (partitioned filters), else y =
     int64_t nblocks;
     const double *H;  // [4096][2], already divided by 4096
     fft::Tables tb;
@@ -131,9 +131,9 @@ __global__ __launch_bounds__(256) void fir_oa_kernel(FirArgs a) {
         for (int j = 0; j < 16; ++j) {
             const int p = 256 * j + t;
             const int64_t oa = start_a + p - a.skip;
-            if (p < len_a && oa >= 0) yr[oa] = re[j];
+            if (p < len_a && oa >= 0) yr[oa] = a.accum ? yr[oa] + re[j] : re[j];
             const int64_t ob = start_b + p - a.skip;
-            if (p < len_b && ob >= 0) yr[ob] = im[j];
+            if (p < len_b && ob >= 0) yr[ob] = a.accum ? yr[ob] + im[j] : im[j];
         }
         __syncthreads();
     }
@@ -181,6 +181,56 @@ __global__ void fir_seam_kernel(SeamArgs a) {
     if (pos < a.n && pos >= a.skip) yr[pos - a.skip] += v;
 }
 
+// ---- partitioned filters (ntaps > 2049): the taps are cut into P pieces of
+// kFirPart taps; piece p is an ordinary overlap-add stream whose output is
+// delayed by p*kFirPart samples.  A push accumulates all pieces into a work
+// row W = [deferred sums | n new positions]; the first n columns are the
+// finished samples, the rest is deferred to the next push.
+__global__ void fir_w_init_kernel(double *W, int64_t ldw, const double *D, int64_t dlen) {
+    const int c = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ldw;
+         i += (int64_t)gridDim.x * blockDim.x)
+        W[(int64_t)c * ldw + i] = i < dlen ? D[(int64_t)c * dlen + i] : 0.0;
+}
+
+__global__ void fir_w_drain_kernel(const double *W, int64_t ldw, int64_t n, int64_t skip,
+                                   double *y, int64_t ldy, double *D, int64_t dlen) {
+    const int c = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ldw;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = W[(int64_t)c * ldw + i];
+        if (i < n) {
+            if (i >= skip) y[(int64_t)c * ldy + i - skip] = v;
+        } else {
+            D[(int64_t)c * dlen + (i - n)] = v;
+        }
+    }
+}
+
+struct FlushArgs {
+    double *y;
+    int64_t ldy, skip, cnt;
+    const double *D;
+    int64_t dlen;
+    int nparts, part;          // part = taps per piece (offset unit)
+    const double *state[16];   // live tail of each piece
+    int wm1[16];               // its length
+};
+
+// y[c, i - skip] = deferred[i] + sum_p tail_p[i - p*part]
+__global__ void fir_flush_kernel(FlushArgs a) {
+    const int c = blockIdx.y;
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= a.cnt) return;
+    const int64_t i = o + a.skip;
+    double v = i < a.dlen ? a.D[(int64_t)c * a.dlen + i] : 0.0;
+    for (int p = 0; p < a.nparts; ++p) {
+        const int64_t q = i - (int64_t)p * a.part;
+        if (q >= 0 && q < a.wm1[p]) v += a.state[p][(int64_t)c * a.wm1[p] + q];
+    }
+    a.y[(int64_t)c * a.ldy + o] = v;
+}
+
 // Process-wide twiddle tables on the device (one per process per device).
 struct FftTablesDev {
     double *t1 = nullptr, *t2 = nullptr;
@@ -223,34 +273,33 @@ int get_fft_tables(fft::Tables &out) {
 
 using namespace osz;
 
+constexpr int kFirPart = 2048;   // taps per piece of a partitioned filter
+constexpr int kFirMaxParts = 16; // => up to 32768 taps
+
+struct FirPart {
+    int ntaps, step;
+    double *dH;         // [4096][2]
+    double *dstate[2];  // ping-pong carried tails [nch][ntaps-1]
+    int cur;
+};
+
 struct osz_fir_s {
-    int ntaps, nch, step;
-    double *dH;        // [4096][2]
-    double *dstate[2]; // ping-pong carried tails [nch][ntaps-1]
-    int cur;           // which dstate holds the live tail
-    double *dtails;    // workspace [nch][nruns_cap][ntaps-1]
-    int nruns_cap;
+    int ntaps, nch;
+    std::vector<FirPart> parts;
+    double *dtails;     // run-tail workspace [nch][nruns_cap][<= 2048]
+    int64_t tails_cap;  // doubles
+    double *dD;         // partitioned: deferred sums [nch][(P-1)*kFirPart]
+    int64_t dlen;
+    double *dW;         // partitioned: work rows
+    int64_t w_cap;      // doubles
     fft::Tables tb;
 };
 
-extern "C" {
-
-int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch) {
-    OSZ_REQUIRE(h && taps, "osz_fir_create: null argument");
-    OSZ_REQUIRE(nch >= 1, "osz_fir_create: nch=%d must be positive", nch);
-    OSZ_REQUIRE(ntaps >= 1, "osz_fir_create: ntaps=%d must be positive", ntaps);
-    if (ntaps > kFirMaxTaps)
-        return fail(OSZ_ERR_UNSUPPORTED, "osz_fir_create: %d taps > %d supported by the on-chip "
-                    "4096-point transform", ntaps, kFirMaxTaps);
-    osz_fir_s *p = new osz_fir_s();
-    p->ntaps = ntaps;
-    p->nch = nch;
-    p->step = fft::N - ntaps + 1;
-    p->cur = 0;
-    p->dtails = nullptr;
-    p->nruns_cap = 0;
-    int rc = get_fft_tables(p->tb);
-    if (rc) { delete p; return rc; }
+static int fir_build_part(FirPart &pt, const double *taps, int ntaps, int nch) {
+    pt.ntaps = ntaps;
+    pt.step = fft::N - ntaps + 1;
+    pt.cur = 0;
+    pt.dH = pt.dstate[0] = pt.dstate[1] = nullptr;
     // H[k] = sum_m h[m] W4096^(k m) / 4096, long double accumulation
     const long double PI = acosl(-1.0L);
     std::vector<long double> wc(fft::N), ws(fft::N);
@@ -271,43 +320,20 @@ int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch) {
         H[2 * k + 1] = (double)(si / fft::N);
     }
     const size_t sb = sizeof(double) * (size_t)nch * (ntaps > 1 ? ntaps - 1 : 1);
-    OSZ_HIP(hipMalloc(&p->dH, H.size() * sizeof(double)));
-    OSZ_HIP(hipMalloc(&p->dstate[0], sb));
-    OSZ_HIP(hipMalloc(&p->dstate[1], sb));
-    OSZ_HIP(hipMemcpy(p->dH, H.data(), H.size() * sizeof(double), hipMemcpyHostToDevice));
-    OSZ_HIP(hipMemset(p->dstate[0], 0, sb));
-    OSZ_HIP(hipMemset(p->dstate[1], 0, sb));
-    *h = p;
+    OSZ_HIP(hipMalloc(&pt.dH, H.size() * sizeof(double)));
+    OSZ_HIP(hipMalloc(&pt.dstate[0], sb));
+    OSZ_HIP(hipMalloc(&pt.dstate[1], sb));
+    OSZ_HIP(hipMemcpy(pt.dH, H.data(), H.size() * sizeof(double), hipMemcpyHostToDevice));
+    OSZ_HIP(hipMemset(pt.dstate[0], 0, sb));
+    OSZ_HIP(hipMemset(pt.dstate[1], 0, sb));
     return OSZ_OK;
 }
 
-int osz_fir_destroy(osz_fir_t h) {
-    if (!h) return OSZ_OK;
-    (void)hipFree(h->dH);
-    (void)hipFree(h->dstate[0]);
-    (void)hipFree(h->dstate[1]);
-    (void)hipFree(h->dtails);
-    delete h;
-    return OSZ_OK;
-}
-
-int osz_fir_reset(osz_fir_t h, void *stream) {
-    OSZ_REQUIRE(h, "osz_fir_reset: null handle");
-    const size_t sb = sizeof(double) * (size_t)h->nch * (h->ntaps > 1 ? h->ntaps - 1 : 1);
-    OSZ_HIP(hipMemsetAsync(h->dstate[h->cur], 0, sb, as_stream(stream)));
-    return OSZ_OK;
-}
-
-int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y, int64_t ldy,
-                 int64_t skip, void *stream) {
-    OSZ_REQUIRE(h && x, "osz_fir_push: null argument");
-    OSZ_REQUIRE(n >= 0 && ldx >= n, "osz_fir_push: n=%lld ldx=%lld", (long long)n, (long long)ldx);
-    OSZ_REQUIRE(skip >= 0 && skip <= n, "osz_fir_push: skip=%lld not in [0, n]", (long long)skip);
-    OSZ_REQUIRE(skip == n || (y && ldy >= n - skip), "osz_fir_push: bad output");
-    if (n == 0) return OSZ_OK;
-    hipStream_t st = as_stream(stream);
-    const int wm1 = h->ntaps - 1;
-    const int64_t nblocks = (n + h->step - 1) / h->step;
+// one overlap-add stream: main kernel + seam kernel
+static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx, int64_t n,
+                         double *y, int64_t ldy, int64_t skip, int accum, hipStream_t st) {
+    const int wm1 = pt.ntaps - 1;
+    const int64_t nblocks = (n + pt.step - 1) / pt.step;
     // run length: enough workgroups to fill 256 CUs x 2, runs of an even number of blocks
     int64_t R = (nblocks * h->nch) / 2048;
     if (R > 32) R = 32;
@@ -315,17 +341,17 @@ int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y
     R &= ~1LL;
     int64_t nruns = nblocks / R;
     if (nruns < 1) nruns = 1;
-    if (nruns > h->nruns_cap) {
+    const int64_t need = (int64_t)h->nch * nruns * (wm1 > 0 ? wm1 : 1);
+    if (need > h->tails_cap) {
         // grow-only workspace; freeing waits for work that may still use it
         if (h->dtails) {
             OSZ_HIP(hipStreamSynchronize(st));
             OSZ_HIP(hipFree(h->dtails));
             h->dtails = nullptr;
         }
-        const size_t tb = sizeof(double) * (size_t)h->nch * nruns * (wm1 > 0 ? wm1 : 1);
-        hipError_t e = hipMalloc(&h->dtails, tb);
-        if (e != hipSuccess) return fail(OSZ_ERR_NOMEM, "osz_fir_push: tails workspace %zu B", tb);
-        h->nruns_cap = (int)nruns;
+        if (hipMalloc(&h->dtails, sizeof(double) * need) != hipSuccess)
+            return fail(OSZ_ERR_NOMEM, "osz_fir_push: tails workspace %lld doubles", (long long)need);
+        h->tails_cap = need;
     }
     static bool attr_set = false;
     static bool pow_tw = true;    // pass-1 twiddles as products of 4 loaded powers (OSZ_FIR_T1POW=0: table)
@@ -346,12 +372,13 @@ int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y
     a.ldy = ldy;
     a.n = n;
     a.skip = skip;
-    a.wlen = h->ntaps;
-    a.step = h->step;
+    a.wlen = pt.ntaps;
+    a.step = pt.step;
     a.R = (int)R;
     a.nruns = (int)nruns;
+    a.accum = accum;
     a.nblocks = nblocks;
-    a.H = h->dH;
+    a.H = pt.dH;
     a.tb = h->tb;
     a.tails = h->dtails;
     const size_t lds_used = sizeof(double) * (2 * fft::PLANE + (wm1 > 0 ? wm1 : 1));
@@ -371,13 +398,13 @@ int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y
         s.ldy = ldy;
         s.n = n;
         s.skip = skip;
-        s.wlen = h->ntaps;
-        s.step = h->step;
+        s.wlen = pt.ntaps;
+        s.step = pt.step;
         s.R = (int)R;
         s.nruns = (int)nruns;
         s.tails = h->dtails;
-        s.state_old = h->dstate[h->cur];
-        s.state_new = h->dstate[h->cur ^ 1];
+        s.state_old = pt.dstate[pt.cur];
+        s.state_new = pt.dstate[pt.cur ^ 1];
         {
             KernelTimer kt("fir_seam", st);
             hipLaunchKernelGGL(fir_seam_kernel,
@@ -385,8 +412,106 @@ int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y
                                st, s);
         }
         OSZ_HIP(hipGetLastError());
-        h->cur ^= 1;
+        pt.cur ^= 1;
     }
+    return OSZ_OK;
+}
+
+extern "C" {
+
+int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch) {
+    OSZ_REQUIRE(h && taps, "osz_fir_create: null argument");
+    OSZ_REQUIRE(nch >= 1, "osz_fir_create: nch=%d must be positive", nch);
+    OSZ_REQUIRE(ntaps >= 1, "osz_fir_create: ntaps=%d must be positive", ntaps);
+    const int nparts = ntaps <= kFirMaxTaps ? 1 : (ntaps + kFirPart - 1) / kFirPart;
+    if (nparts > kFirMaxParts)
+        return fail(OSZ_ERR_UNSUPPORTED, "osz_fir_create: %d taps > %d supported", ntaps,
+                    kFirMaxParts * kFirPart);
+    osz_fir_s *p = new osz_fir_s();
+    p->ntaps = ntaps;
+    p->nch = nch;
+    p->dtails = p->dD = p->dW = nullptr;
+    p->tails_cap = p->w_cap = 0;
+    p->dlen = 0;
+    int rc = get_fft_tables(p->tb);
+    if (rc) { delete p; return rc; }
+    p->parts.resize(nparts);
+    for (int q = 0; q < nparts; ++q) {
+        const int off = nparts == 1 ? 0 : q * kFirPart;
+        const int len = nparts == 1 ? ntaps : (ntaps - off < kFirPart ? ntaps - off : kFirPart);
+        rc = fir_build_part(p->parts[q], taps + off, len, nch);
+        if (rc) return rc;
+    }
+    if (nparts > 1) {
+        p->dlen = (int64_t)(nparts - 1) * kFirPart;
+        OSZ_HIP(hipMalloc(&p->dD, sizeof(double) * (size_t)nch * p->dlen));
+        OSZ_HIP(hipMemset(p->dD, 0, sizeof(double) * (size_t)nch * p->dlen));
+    }
+    *h = p;
+    return OSZ_OK;
+}
+
+int osz_fir_destroy(osz_fir_t h) {
+    if (!h) return OSZ_OK;
+    for (auto &pt : h->parts) {
+        (void)hipFree(pt.dH);
+        (void)hipFree(pt.dstate[0]);
+        (void)hipFree(pt.dstate[1]);
+    }
+    (void)hipFree(h->dtails);
+    (void)hipFree(h->dD);
+    (void)hipFree(h->dW);
+    delete h;
+    return OSZ_OK;
+}
+
+int osz_fir_reset(osz_fir_t h, void *stream) {
+    OSZ_REQUIRE(h, "osz_fir_reset: null handle");
+    hipStream_t st = as_stream(stream);
+    for (auto &pt : h->parts)
+        OSZ_HIP(hipMemsetAsync(pt.dstate[pt.cur], 0,
+                               sizeof(double) * (size_t)h->nch * (pt.ntaps > 1 ? pt.ntaps - 1 : 1),
+                               st));
+    if (h->dD) OSZ_HIP(hipMemsetAsync(h->dD, 0, sizeof(double) * (size_t)h->nch * h->dlen, st));
+    return OSZ_OK;
+}
+
+int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y, int64_t ldy,
+                 int64_t skip, void *stream) {
+    OSZ_REQUIRE(h && x, "osz_fir_push: null argument");
+    OSZ_REQUIRE(n >= 0 && ldx >= n, "osz_fir_push: n=%lld ldx=%lld", (long long)n, (long long)ldx);
+    OSZ_REQUIRE(skip >= 0 && skip <= n, "osz_fir_push: skip=%lld not in [0, n]", (long long)skip);
+    OSZ_REQUIRE(skip == n || (y && ldy >= n - skip), "osz_fir_push: bad output");
+    if (n == 0) return OSZ_OK;
+    hipStream_t st = as_stream(stream);
+    if (h->parts.size() == 1)
+        return fir_part_push(h, h->parts[0], x, ldx, n, y, ldy, skip, 0, st);
+    // partitioned: accumulate every piece into W = [deferred | n new positions]
+    const int64_t ldw = n + h->dlen;
+    const int64_t need = (int64_t)h->nch * ldw;
+    if (need > h->w_cap) {
+        if (h->dW) {
+            OSZ_HIP(hipStreamSynchronize(st));
+            OSZ_HIP(hipFree(h->dW));
+            h->dW = nullptr;
+        }
+        if (hipMalloc(&h->dW, sizeof(double) * need) != hipSuccess)
+            return fail(OSZ_ERR_NOMEM, "osz_fir_push: work rows %lld doubles", (long long)need);
+        h->w_cap = need;
+    }
+    int64_t bx = (ldw + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(fir_w_init_kernel, dim3((unsigned)bx, h->nch), dim3(256), 0, st, h->dW, ldw,
+                       h->dD, h->dlen);
+    OSZ_HIP(hipGetLastError());
+    for (size_t q = 0; q < h->parts.size(); ++q) {
+        int rc = fir_part_push(h, h->parts[q], x, ldx, n, h->dW + (int64_t)q * kFirPart, ldw, 0, 1,
+                               st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(fir_w_drain_kernel, dim3((unsigned)bx, h->nch), dim3(256), 0, st, h->dW, ldw,
+                       n, skip, y, ldy, h->dD, h->dlen);
+    OSZ_HIP(hipGetLastError());
     return OSZ_OK;
 }
 
@@ -398,9 +523,22 @@ int osz_fir_flush(osz_fir_t h, double *y, int64_t ldy, int64_t skip, int64_t dro
     const int64_t cnt = wm1 - skip - drop;
     if (cnt == 0) return OSZ_OK;
     OSZ_REQUIRE(y && ldy >= cnt, "osz_fir_flush: bad output");
-    OSZ_HIP(hipMemcpy2DAsync(y, ldy * sizeof(double), h->dstate[h->cur] + skip,
-                             wm1 * sizeof(double), cnt * sizeof(double), h->nch,
-                             hipMemcpyDeviceToDevice, as_stream(stream)));
+    FlushArgs a{};
+    a.y = y;
+    a.ldy = ldy;
+    a.skip = skip;
+    a.cnt = cnt;
+    a.D = h->dD;
+    a.dlen = h->dlen;
+    a.nparts = (int)h->parts.size();
+    a.part = kFirPart;
+    for (int q = 0; q < a.nparts; ++q) {
+        a.state[q] = h->parts[q].dstate[h->parts[q].cur];
+        a.wm1[q] = h->parts[q].ntaps - 1;
+    }
+    hipLaunchKernelGGL(fir_flush_kernel, dim3((unsigned)((cnt + 255) / 256), h->nch), dim3(256), 0,
+                       as_stream(stream), a);
+    OSZ_HIP(hipGetLastError());
     return OSZ_OK;
 }
 

@@ -99,6 +99,22 @@ def test_oaconvolve_edges(osz):
         assert rel_err(y, orc.convolve_direct(xx, h, "full")) < RTOL
 
 
+def test_oaconvolve_long_filters(osz):
+    """More than 2049 taps: the filter is cut into 2048-tap pieces whose
+    delayed outputs are accumulated (partitioned overlap-add)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((2, 30011))
+    for taps, cs in ((2050, 100000), (4097, 3000), (5000, 777), (9001, 12000)):
+        h = rng.standard_normal(taps) / taps
+        for mode in ("full", "same", "valid"):
+            y = np.concatenate(list(osz.oaconvolve(producer(x, cs, -1), h, -1, mode)), -1)
+            assert rel_err(y, orc.convolve_direct(x, h, mode)) < RTOL
+    with pytest.raises(NotImplementedError):
+        list(osz.oaconvolve(producer(rng.standard_normal((1, 40000)), 5000, -1),
+                            np.ones(16 * 2048 + 1), -1, "full"))
+
+
 # --------------------------------------------------------------------- SOS
 FILTERS = ["butter_lp", "butter_bp6", "cheby1_bp", "butter_cls6"]
 
