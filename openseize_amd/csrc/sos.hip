@@ -92,7 +92,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 // checks, no predication); GUARD = true handles a ragged remainder.
 template <int T, int NW, bool REV, bool GUARD>
 __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__restrict__ sec,
-                                         const int c) {
+                                         const int c, const bool zero_init = false,
+                                         const int64_t skip_store_tiles = 0) {
     constexpr int ROW = T + kSosPad;
     constexpr int WAVE_ELEMS = 64 * T;
     extern __shared__ double lds[];
@@ -111,7 +112,9 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
     if (threadIdx.x < a.nsec) {
         const int s = threadIdx.x;
         double z0, z1;
-        if (a.state_in) {
+        if (zero_init) {
+            z0 = z1 = 0.0;
+        } else if (a.state_in) {
             z0 = a.state_in[((int64_t)s * a.nch + c) * 2 + 0];
             z1 = a.state_in[((int64_t)s * a.nch + c) * 2 + 1];
         } else {
@@ -304,7 +307,7 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
         parity ^= 1;
 
         // ---- registers -> LDS rows -> HBM (wave private: no workgroup barrier)
-        if (yrow) {
+        if (yrow && t >= skip_store_tiles) {
             double *blk = wl + (REV ? (63 - l) : l) * ROW;
 #pragma unroll
             for (int j = 0; j < T; ++j) blk[REV ? (T - 1 - j) : j] = v[j];
@@ -330,6 +333,38 @@ template <int T, int NW, bool REV, bool GUARD>
 __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
                                                       const SosSection *__restrict__ sec) {
     sos_body<T, NW, REV, GUARD>(a, sec, blockIdx.x);
+}
+
+// Few channels: a chunk is cut into `nseg` time segments that run as separate
+// workgroups (grid (nch, nseg)).  Segment s > 0 starts from a ZERO state
+// `pre` samples early and discards those outputs; `pre` = the handle's
+// warm_len, the point where the cascade's transition matrix has decayed below
+// 1e-18, so the state it reaches at its first kept sample equals the carried
+// one to float64 (see sos_warmup_len).  Segment 0 starts from the true state,
+// the last segment writes the carried state.  All lengths are whole tiles.
+template <int T, int NW, bool REV>
+__global__ __launch_bounds__(NW * 64) void sos_split_kernel(SosArgs a,
+                                                            const SosSection *__restrict__ sec,
+                                                            int nseg, int64_t seglen,
+                                                            int64_t pre) {
+    const int s = blockIdx.y;
+    const int64_t begin = (int64_t)s * seglen;               // processing-order start
+    const int64_t len = (s == nseg - 1) ? a.n - begin : seglen;
+    const int64_t p = s > 0 ? pre : 0;
+    SosArgs b = a;
+    b.n = len + p;
+    if (REV) {
+        // processing order runs down from a.n: kept samples are memory
+        // [a.n - begin - len, a.n - begin), the pre-roll lies just above
+        const int64_t lo = a.n - begin - len;
+        b.x = a.x + lo;
+        if (a.y) b.y = a.y + lo;
+    } else {
+        b.x = a.x + begin - p;
+        if (a.y) b.y = a.y + begin - p;
+    }
+    if (s != nseg - 1) b.state_out = nullptr;
+    sos_body<T, NW, REV, false>(b, sec, blockIdx.x, s > 0, p / ((int64_t)NW * 64 * T));
 }
 
 // Forward pass of one chunk and backward pass of another in ONE launch:
@@ -497,13 +532,46 @@ static int sos_launch_one(const SosArgs &a, hipStream_t st) {
 // One logical pass = the hot kernel over the whole tiles + a guarded kernel
 // over the ragged remainder; the cascade state travels through `carry`
 // (nsec, nch, 2) between the two launches.
+// whole-tile pass, cut into time segments when there are too few channels to
+// fill the chip (see sos_split_kernel)
 template <int T, int NW, bool REV>
-static int sos_launch_tn(const SosArgs &a0, double *carry, hipStream_t st) {
+static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
+    const int64_t tile = (int64_t)NW * 64 * T;
+    const int64_t ntiles = a.n / tile, pre_tiles = warm_len / tile;
+    int64_t nseg = 1;
+    if (a.nch < 512 && pre_tiles >= 1 && pre_tiles * tile == warm_len) {
+        nseg = (512 + a.nch - 1) / a.nch;                    // aim at 2 workgroups per CU
+        const int64_t max_seg = ntiles / (4 * pre_tiles);    // pre-roll <= 25 % extra work
+        if (nseg > max_seg) nseg = max_seg;
+    }
+    if (nseg <= 1) return sos_launch_one<T, NW, REV, false>(a, st);
+    const int64_t seg_tiles = (ntiles + nseg - 1) / nseg;
+    nseg = (ntiles + seg_tiles - 1) / seg_tiles;
+    auto kern = sos_split_kernel<T, NW, REV>;
+    static bool attr_set = false;
+    const size_t lds = sizeof(double) * ((size_t)NW * 64 * (T + kSosPad) + 2 * NW * 2 +
+                                         2 * kSosMaxSec * 2);
+    if (!attr_set) {
+        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    {
+        KernelTimer kt(REV ? (a.y ? "sos_bwd_split" : "sos_warmup") : "sos_fwd_split", st);
+        hipLaunchKernelGGL(kern, dim3(a.nch, (unsigned)nseg), dim3(NW * 64), lds, st, a, a.sec,
+                           (int)nseg, seg_tiles * tile, warm_len);
+    }
+    OSZ_HIP(hipGetLastError());
+    return OSZ_OK;
+}
+
+template <int T, int NW, bool REV>
+static int sos_launch_tn(const SosArgs &a0, double *carry, int64_t warm_len, hipStream_t st) {
     const int64_t tile = (int64_t)NW * 64 * T;
     const int64_t nfull = (a0.n / tile) * tile, rem = a0.n - nfull;
     if (nfull == 0 || rem == 0) {
         return rem ? sos_launch_one<T, NW, REV, true>(a0, st)
-                   : sos_launch_one<T, NW, REV, false>(a0, st);
+                   : sos_launch_main<T, NW, REV>(a0, warm_len, st);
     }
     SosArgs m = a0, r = a0;  // main (whole tiles) first in processing order, then remainder
     m.n = nfull;
@@ -517,16 +585,17 @@ static int sos_launch_tn(const SosArgs &a0, double *carry, hipStream_t st) {
     }
     m.state_out = carry;
     r.state_in = carry;
-    int rc = sos_launch_one<T, NW, REV, false>(m, st);
+    int rc = sos_launch_main<T, NW, REV>(m, warm_len, st);
     if (rc) return rc;
     return sos_launch_one<T, NW, REV, true>(r, st);
 }
 
 template <bool REV>
-static int sos_launch(const SosArgs &a, double *carry, int T, int NW, hipStream_t st) {
-    if (T == 32 && NW == 4) return sos_launch_tn<32, 4, REV>(a, carry, st);
-    if (T == 32 && NW == 8) return sos_launch_tn<32, 8, REV>(a, carry, st);
-    if (T == 16 && NW == 8) return sos_launch_tn<16, 8, REV>(a, carry, st);
+static int sos_launch(const SosArgs &a, double *carry, int T, int NW, int64_t warm_len,
+                      hipStream_t st) {
+    if (T == 32 && NW == 4) return sos_launch_tn<32, 4, REV>(a, carry, warm_len, st);
+    if (T == 32 && NW == 8) return sos_launch_tn<32, 8, REV>(a, carry, warm_len, st);
+    if (T == 16 && NW == 8) return sos_launch_tn<16, 8, REV>(a, carry, warm_len, st);
     return fail(OSZ_ERR_INVALID, "sos: unsupported geometry T=%d NW=%d", T, NW);
 }
 
@@ -683,7 +752,7 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y, int64_
     a.state_out = h->dstate;
     a.nsec = h->nsec;
     a.nch = h->nch;
-    return sos_launch<false>(a, h->dcarry, h->T, h->NW, as_stream(stream));
+    return sos_launch<false>(a, h->dcarry, h->T, h->NW, h->warm_len, as_stream(stream));
 }
 
 int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, double *f,
@@ -695,7 +764,8 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
     OSZ_REQUIRE(na >= 1 && ldfa >= na && ldy >= na, "osz_sosfiltfilt_step: bad chunk a");
     OSZ_REQUIRE(!fb || (nb >= 1 && ldfb >= nb), "osz_sosfiltfilt_step: bad chunk b");
     const int64_t tile = (int64_t)h->NW * 64 * h->T;
-    const bool fusable = h->T == 32 && h->NW == 4 && nx % tile == 0 && na % tile == 0;
+    const bool fusable = h->T == 32 && h->NW == 4 && nx % tile == 0 && na % tile == 0 &&
+                         h->nch >= 96;   // fewer channels: time-split launches fill the chip better
     if (!fusable) {
         int rc = osz_sos_forward(h, x, ldx, f, ldf, nx, stream);
         if (rc) return rc;
@@ -712,7 +782,7 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
         w.ldx = ldfb;
         w.n = nb < h->warm_len ? nb : h->warm_len;
         w.state_out = h->dtmp;
-        int rc = sos_launch<true>(w, h->dcarry, h->T, h->NW, st);
+        int rc = sos_launch<true>(w, h->dcarry, h->T, h->NW, h->warm_len, st);
         if (rc) return rc;
         bw.state_in = h->dtmp;
     }
@@ -753,7 +823,7 @@ int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t n
         a.ldy = 0;
         a.state_in = nullptr;
         a.state_out = h->dtmp;
-        int rc = sos_launch<true>(a, h->dcarry, h->T, h->NW, st);
+        int rc = sos_launch<true>(a, h->dcarry, h->T, h->NW, h->warm_len, st);
         if (rc) return rc;
         a.state_in = h->dtmp;
     } else {
@@ -765,7 +835,7 @@ int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t n
     a.y = y;
     a.ldy = ldy;
     a.state_out = nullptr;
-    return sos_launch<true>(a, h->dcarry, h->T, h->NW, st);
+    return sos_launch<true>(a, h->dcarry, h->T, h->NW, h->warm_len, st);
 }
 
 }  // extern "C"

@@ -238,6 +238,30 @@ def test_sosfiltfilt_warmup_truncation(osz, golden):
         assert rel_err(y, orc.sosfiltfilt(x, sos, 30000)) < 1e-12
 
 
+def test_sos_time_split_few_channels(osz, golden):
+    """With few channels a chunk is cut into time segments that start from a
+    zero state warmup_len samples early (sos_split_kernel): forward, carried
+    state and forward-backward results must still equal the serial oracle."""
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    import torch
+    g = golden("g4_sosfiltfilt.npz")
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((3, 300001)) + 2.0
+    for name in ("butter_bp6", "butter_lp"):
+        sos = g[f"sos_{name}"]
+        ref, zf = orc.sosfilt(x, sos, 300001)
+        y = np.concatenate(list(osz.sosfilt(producer(x, 131072, -1), sos, -1)), -1)
+        assert rel_err(y, ref) < 1e-12
+        st = dev.SosStream(sos, 3)
+        xd = torch.from_numpy(x).cuda()
+        st.forward(xd[:, :262144].contiguous())
+        assert rel_err(st.get_state(), orc.sosfilt(x[:, :262144], sos, 262144)[1]) < 1e-9
+        st.close()
+        y = np.concatenate(list(osz.sosfiltfilt(producer(x, 131072, -1), sos, -1)), -1)
+        assert rel_err(y, orc.sosfiltfilt(x, sos, 131072)) < 1e-12
+
+
 # --------------------------------------------------------------- resampling
 @pytest.mark.parametrize("LM", [(1, 5), (3, 1), (3, 2), (2, 7), (3, 11)])
 def test_resample_golden(osz, golden, LM):
