@@ -539,8 +539,13 @@ static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
     const int64_t tile = (int64_t)NW * 64 * T;
     const int64_t ntiles = a.n / tile, pre_tiles = warm_len / tile;
     int64_t nseg = 1;
-    if (a.nch < 512 && pre_tiles >= 1 && pre_tiles * tile == warm_len) {
-        nseg = (512 + a.nch - 1) / a.nch;                    // aim at 2 workgroups per CU
+    static int target_wgs = 0;   // tuning knob OSZ_SOS_WGS (default 512 = 2 workgroups per CU)
+    if (!target_wgs) {
+        const char *e = getenv("OSZ_SOS_WGS");
+        target_wgs = (e && atoi(e) > 0) ? atoi(e) : 512;
+    }
+    if (a.nch < target_wgs && pre_tiles >= 1 && pre_tiles * tile == warm_len) {
+        nseg = (target_wgs + a.nch - 1) / a.nch;
         const int64_t max_seg = ntiles / (4 * pre_tiles);    // pre-roll <= 25 % extra work
         if (nseg > max_seg) nseg = max_seg;
     }
@@ -596,6 +601,7 @@ static int sos_launch(const SosArgs &a, double *carry, int T, int NW, int64_t wa
     if (T == 32 && NW == 4) return sos_launch_tn<32, 4, REV>(a, carry, warm_len, st);
     if (T == 32 && NW == 8) return sos_launch_tn<32, 8, REV>(a, carry, warm_len, st);
     if (T == 16 && NW == 8) return sos_launch_tn<16, 8, REV>(a, carry, warm_len, st);
+    if (T == 16 && NW == 4) return sos_launch_tn<16, 4, REV>(a, carry, warm_len, st);
     return fail(OSZ_ERR_INVALID, "sos: unsupported geometry T=%d NW=%d", T, NW);
 }
 
@@ -631,7 +637,7 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     int T = kSosT, NW = kSosNW;
     if (const char *e = getenv("OSZ_SOS_T")) T = atoi(e);
     if (const char *e = getenv("OSZ_SOS_NW")) NW = atoi(e);
-    OSZ_REQUIRE((T == 32 && (NW == 4 || NW == 8)) || (T == 16 && NW == 8),
+    OSZ_REQUIRE((T == 32 && (NW == 4 || NW == 8)) || (T == 16 && (NW == 8 || NW == 4)),
                 "osz_sos_create: unsupported OSZ_SOS_T=%d / OSZ_SOS_NW=%d", T, NW);
     std::vector<SosSection> secs(nsec);
     for (int s = 0; s < nsec; ++s) build_section(sos + 6 * s, secs[s], T);
