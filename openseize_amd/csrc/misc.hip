@@ -107,7 +107,7 @@ int osz_checksum(const double *x, int64_t ldx, int nch, int64_t n, uint64_t *bit
     OSZ_HIP(hipMemsetAsync(d, 0, sizeof(Acc), st));
     if (n > 0) {
         int64_t bx = (n + 255) / 256;
-        if (bx > 1024) bx = 1024;
+        if (bx > 16) bx = 16;   // few blocks per row: the two atomics per wave stay cheap
         hipLaunchKernelGGL(checksum_kernel, dim3((unsigned)bx, nch), dim3(256), 0, st, x, ldx, n,
                            &d->bits, &d->fsum);
     }
