@@ -75,6 +75,42 @@ def main():
     out.append({"workload": "K7 take 256 ch x 2^20, every 2nd sample",
                 "ms_per_chunk": dt * 1e3, "Msamples_s": CH * N / dt / 1e6,
                 "algorithmic_GBps": 12 * CH * N / dt / 1e9})
+    # practical ceiling: device-to-device copy of one chunk (read 8 + write 8 B)
+    y = torch.empty_like(x)
+    dt = timed(lambda: y.copy_(x), 10)
+    out.append({"workload": "d2d copy 256 ch x 2^20 (practical HBM ceiling)",
+                "ms_per_chunk": dt * 1e3, "algorithmic_GBps": 16 * CH * N / dt / 1e9})
+
+    # cfg-1, HOST-FED through the public API (ndarray in -> ndarray out):
+    # 16 ch x 1e6, 256-tap FIR, chunksize 30000, mode same.  PCIe + per-chunk
+    # launch overhead included; the reference needs 0.309 s for this.
+    from openseize_amd import producer
+    from openseize_amd.core import numerical as nm
+    xh = np.random.default_rng(0).standard_normal((16, 1_000_000))
+    hh = sps.firwin(256, 0.2)
+
+    def cfg1():
+        return np.concatenate(list(nm.oaconvolve(producer(xh, 30000, -1), hh, -1, "same")), -1)
+
+    cfg1()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        yh = cfg1()
+    dt = (time.perf_counter() - t0) / 3
+    out.append({"workload": "cfg-1 host-fed oaconvolve 16 ch x 1e6, 256 taps, chunksize 30000",
+                "seconds": dt, "Msamples_s": xh.size / dt / 1e6,
+                "max_abs_err_vs_numpy": float(np.max(np.abs(
+                    yh[0] - np.convolve(xh[0], hh, "same"))))})
+    # same data, one big chunk (what a user with enough memory would do)
+    def cfg1_big():
+        return np.concatenate(list(nm.oaconvolve(producer(xh, 1_000_000, -1), hh, -1, "same")), -1)
+    cfg1_big()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        cfg1_big()
+    dt = (time.perf_counter() - t0) / 3
+    out.append({"workload": "cfg-1 host-fed, chunksize 1e6", "seconds": dt,
+                "Msamples_s": xh.size / dt / 1e6})
     for o in out:
         print(json.dumps(o))
 
