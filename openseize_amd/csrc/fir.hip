@@ -109,22 +109,36 @@ __global__ __launch_bounds__(256) void fir_oa_kernel(FirArgs a) {
         __syncthreads();
         fft::i1<POW>(t, re, im, a.tb, pr, pi);
         __syncthreads();
-        // ---- overlap add.  re[j] = a[256 j + t], im[j] = b[256 j + t]
+        // ---- overlap add.  re[j] = a[256 j + t], im[j] = b[256 j + t].
+        // Only a few of the 16 register rows take part (j < ceil(wm1/256) for
+        // the heads, the rows covering [len, len + wm1) for the tails): the
+        // row tests are wave-uniform scalar branches, the lane tests stay inside.
         double *xb = pr;  // a's tail handed to b's head
+        const int jhead = (wm1 + 255) >> 8;
+        const int ja0 = len_a >> 8, ja1 = (len_a + wm1 + 255) >> 8;
+        const int jb0 = len_b >> 8, jb1 = (len_b + wm1 + 255) >> 8;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int p = 256 * j + t;
-            if (p < wm1) re[j] += carry[p];
-            const int q = p - len_a;
-            if (q >= 0 && q < wm1) xb[q] = re[j];
+            if (j < jhead) {
+                if (p < wm1) re[j] += carry[p];
+            }
+            if (j >= ja0 && j < ja1) {
+                const int q = p - len_a;
+                if (q >= 0 && q < wm1) xb[q] = re[j];
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int p = 256 * j + t;
-            if (p < wm1) im[j] += xb[p];
-            const int q = p - len_b;
-            if (q >= 0 && q < wm1) carry[q] = im[j];
+            if (j < jhead) {
+                if (p < wm1) im[j] += xb[p];
+            }
+            if (j >= jb0 && j < jb1) {
+                const int q = p - len_b;
+                if (q >= 0 && q < wm1) carry[q] = im[j];
+            }
         }
         // ---- write the finished samples (full-convolution positions start_a + p)
 #pragma unroll
