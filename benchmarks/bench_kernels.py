@@ -59,6 +59,17 @@ def main():
                 "algorithmic_GBps": 9.6 * CH * N / dt / 1e9})
     poly.close()
 
+    # rational resampling 3/2 (upsampling path of the same kernel)
+    cut = 5000 / 6
+    h32 = Kaiser(cut - cut / 10, cut + cut / 10, 5000, gpass=0.1, gstop=40).coeffs
+    xs2 = x[:, : 1 << 19].contiguous()
+    poly = dev.PolyStream(h32, 3, 2, CH)
+    dt = timed(lambda: poly.push(xs2, final=False), 5)
+    out.append({"workload": f"resample 3/2 ({len(h32)} taps) 256 ch x 2^19",
+                "ms_per_chunk": dt * 1e3, "Msamples_s": CH * xs2.shape[1] / dt / 1e6,
+                "algorithmic_GBps": 20 * CH * xs2.shape[1] / dt / 1e9})
+    poly.close()
+
     # cfg-5 part 2: STFT segments (complex128 out), nfft 4096, 50 % (24 B / sample)
     xs = x[:, : 1 << 18].contiguous()
     stft = dev.SpecStream(nfft, nfft, nfft // 2, w, scale, "constant",

@@ -50,27 +50,42 @@ __global__ __launch_bounds__(256) void poly_kernel(PolyArgs a) {
     }
 }
 
-// Fast path for decimation (L == 1):  out[j] = sum_k hL[k] x[j M + half - k].
-// A 256-thread workgroup produces 256*R consecutive outputs of one channel:
-// the input window (256 R M + ntaps - M samples) is staged once in LDS with
-// coalesced loads; thread t accumulates outputs j0 + t + 256 r, r < R, reading
-// its taps from LDS (lane stride M doubles: conflict free for odd M) while the
-// coefficient of each tap is wave-uniform (scalar load).  HBM sees every input
-// once and every output once.
+// LDS-tiled polyphase kernel.  Output j only meets the taps k = phi + L k',
+// phi = (j M + half) mod L, and phi depends on j mod L alone, so the outputs
+// of one residue class r = j mod L form a plain decimating FIR
+//     out[jf + L q] = sum_k' hL[phi + L k'] * x[itop + M q - k'],
+//     itop = (jf M + half - phi) / L,
+// with its own sub-filter.  Grid (tiles, nch, L): a 256-thread workgroup
+// produces 256*R consecutive outputs of ONE residue class of one channel: the
+// input window (256 R M + ceil(m/L) - M samples) is staged once in LDS with
+// coalesced loads; thread t accumulates R outputs reading its taps from LDS
+// (lane stride M doubles: conflict free for odd M) while the coefficient of
+// each tap is wave-uniform (scalar load).  For decimation (L = 1, the EEG case)
+// HBM sees every input once and every output once; for L > 1 the L residue
+// classes re-read the same window through L2.
 template <int R>
-__global__ __launch_bounds__(256) void poly_decim_kernel(PolyArgs a,
+__global__ __launch_bounds__(256) void poly_phase_kernel(PolyArgs a,
                                                          const double *__restrict__ hL) {
     extern __shared__ double win[];
     const int c = blockIdx.y;
     const int t = threadIdx.x;
+    const int r = blockIdx.z;                           // residue class j mod L
     const double *xr = a.x + (int64_t)c * a.ldx;
     const double *hr = a.hist + (int64_t)c * a.H;
     double *yr = a.y + (int64_t)c * a.ldy;
-    const int64_t jt = a.j0 + (int64_t)blockIdx.x * (256 * R);   // first output of this tile
-    const int nj = (int)((a.j1 - jt) < (256 * R) ? (a.j1 - jt) : (256 * R));
+    // first output of this class at or after j0, and the class' sub-filter
+    int64_t jf = a.j0 + (((int64_t)r - a.j0) % a.L + a.L) % a.L;
+    const int phi = (int)(((int64_t)r * a.M + a.half) % a.L);
+    const int msub = phi < a.m ? (a.m - phi + a.L - 1) / a.L : 0;
+    const int64_t nq_all = jf < a.j1 ? (a.j1 - jf + a.L - 1) / a.L : 0;
+    const int64_t qt = (int64_t)blockIdx.x * (256 * R);
+    if (qt >= nq_all) return;
+    const int nj = (int)((nq_all - qt) < (256 * R) ? (nq_all - qt) : (256 * R));
+    jf += qt * a.L;                                     // first output of this tile
+    const int64_t itop = (jf * a.M + a.half - phi) / a.L;
     // window: inputs [i0, i0 + wlen)
-    const int64_t i0 = jt * a.M + a.half - (a.m - 1);
-    const int wlen = (nj - 1) * a.M + a.m;
+    const int64_t i0 = itop - (msub - 1);
+    const int wlen = (nj - 1) * a.M + msub;
     for (int q = t; q < wlen; q += 256) {
         const int64_t i = i0 + q;
         double v = 0.0;
@@ -79,25 +94,26 @@ __global__ __launch_bounds__(256) void poly_decim_kernel(PolyArgs a,
         win[q] = v;
     }
     __syncthreads();
-    // output j = jt + t + 256 r reads win[(t + 256 r) M + (m - 1) - k]
+    // output q = t + 256 s reads win[q M + (msub - 1) - k']
     double acc[R];
     const double *base[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        acc[r] = 0.0;
-        const int o = t + 256 * r;
-        base[r] = win + (o < nj ? o : 0) * a.M + (a.m - 1);
+    for (int s = 0; s < R; ++s) {
+        acc[s] = 0.0;
+        const int o = t + 256 * s;
+        base[s] = win + (o < nj ? o : 0) * a.M + (msub - 1);
     }
+    const double *hs = hL + phi;
 #pragma unroll 4
-    for (int k = 0; k < a.m; ++k) {
-        const double ck = hL[k];
+    for (int k = 0; k < msub; ++k) {
+        const double ck = hs[(int64_t)k * a.L];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fma(ck, base[r][-k], acc[r]);
+        for (int s = 0; s < R; ++s) acc[s] = fma(ck, base[s][-k], acc[s]);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int o = t + 256 * r;
-        if (o < nj) yr[(jt - a.j0) + o] = acc[r];
+    for (int s = 0; s < R; ++s) {
+        const int o = t + 256 * s;
+        if (o < nj) yr[(jf - a.j0) + (int64_t)o * a.L] = acc[s];
     }
 }
 
@@ -214,13 +230,15 @@ int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n, int fin
         a.H = h->H;
         a.half = h->half;
         constexpr int R = 4;
-        const size_t lds = sizeof(double) * ((size_t)(256 * R - 1) * h->M + h->m);
-        if (h->L == 1 && lds <= 64 * 1024) {
-            // decimation fast path: LDS-tiled, 256*R outputs per workgroup
-            const int64_t bx = (cnt + 256 * R - 1) / (256 * R);
-            KernelTimer kt("poly_decim", st);
-            hipLaunchKernelGGL(poly_decim_kernel<R>, dim3((unsigned)bx, h->nch), dim3(256), lds, st,
-                               a, h->dhL);
+        const int msub = (h->m + h->L - 1) / h->L;
+        const size_t lds = sizeof(double) * ((size_t)(256 * R - 1) * h->M + msub);
+        if (lds <= 64 * 1024 && h->L <= 64) {
+            // LDS-tiled path: 256*R outputs of one residue class per workgroup
+            const int64_t nq = (cnt + h->L - 1) / h->L + 1;
+            const int64_t bx = (nq + 256 * R - 1) / (256 * R);
+            KernelTimer kt("poly_phase", st);
+            hipLaunchKernelGGL(poly_phase_kernel<R>, dim3((unsigned)bx, h->nch, h->L), dim3(256),
+                               lds, st, a, h->dhL);
         } else {
             int64_t bx = (cnt + 255) / 256;
             if (bx > 4096) bx = 4096;
