@@ -218,6 +218,8 @@ class FirStream(_Handle):
 
     def push(self, x2d, skip=0, out=None):
         n = x2d.shape[1]
+        if not 0 <= skip <= n:
+            raise ValueError(f"skip={skip} not in [0, {n}]")
         y = out if out is not None else torch.empty(
             (self.nch, n - skip), dtype=torch.float64, device=x2d.device)
         _lib.check(self.lib.osz_fir_push(

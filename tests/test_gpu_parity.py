@@ -423,6 +423,67 @@ def test_device_resident_chain(osz, golden):
     assert rel_err(y, ref) < RTOL
 
 
+def test_device_resident_api(osz, golden):
+    """Every public entry point accepts a CUDA tensor and answers with CUDA
+    tensors equal to the host-fed (ndarray) result."""
+    import torch
+    from openseize_amd.filtering.fir import Kaiser
+    from openseize_amd.filtering.iir import Butter
+    from openseize_amd.resampling.resampling import downsample, resample
+    from openseize_amd.spectra.estimators import psd, stft
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal((3, 30000))
+    xd = torch.from_numpy(x).cuda()
+    kais = Kaiser(fpass=200, fstop=400, fs=5000, gpass=0.5, gstop=40)
+    butter = Butter(fpass=[8, 30], fstop=[3, 60], fs=500, gpass=1, gstop=40)
+    pairs = [
+        (kais(xd, 7000, axis=-1, mode="same"), kais(x, 7000, axis=-1, mode="same")),
+        (butter(xd, 7000, axis=-1, dephase=True), butter(x, 7000, axis=-1, dephase=True)),
+        (butter(xd, 7000, axis=-1, dephase=False), butter(x, 7000, axis=-1, dephase=False)),
+        (downsample(xd, 5, 5000, 7000), downsample(x, 5, 5000, 7000)),
+        (resample(xd, 3, 2, 5000, 7000), resample(x, 3, 2, 5000, 7000)),
+        (psd(xd, 1000, resolution=2.0)[2], psd(x, 1000, resolution=2.0)[2]),
+        (stft(xd, 500, resolution=1.0)[2], stft(x, 500, resolution=1.0)[2]),
+    ]
+    for got, want in pairs:
+        assert torch.is_tensor(got) and got.is_cuda
+        g = got.cpu().numpy()
+        assert g.shape == want.shape
+        assert np.max(np.abs(g - want)) <= 1e-12 * max(np.max(np.abs(want)), 1e-300)
+    # a producer over a device tensor stays a producer of device tensors
+    pro = butter(producer(xd, 7000, -1), 7000, axis=-1)
+    assert all(c.is_cuda for c in pro)
+
+
+def test_c_abi_error_codes(osz):
+    """Status codes of the C ABI map to the exception types of the Python
+    boundary; handles refuse inconsistent arguments instead of faulting."""
+    import ctypes
+    import torch
+    from openseize_amd import _device as dev, _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    bad = np.ones((1, 6))
+    bad[0, 3] = 2.0                                   # a0 != 1
+    assert lib.osz_sos_create(ctypes.byref(h), dev.host_dp(bad), 1, 4) == _lib.OSZ_ERR_INVALID
+    assert b"should be all ones" in lib.osz_last_error()
+    with pytest.raises(ValueError):
+        dev.SosStream(np.ones((2, 5)), 4)             # wrong sos shape
+    with pytest.raises(ValueError):
+        dev.SosStream(np.array([[1.0, 0, 0, 1, 0, 0]]), 4).set_state(np.zeros((1, 3, 2)))
+    with pytest.raises(ValueError):
+        dev.SpecStream(128, 64, 32, np.ones(128), 1.0, "constant", 0, 2)   # nfft < nwin
+    with pytest.raises(ValueError):
+        dev.SpecStream(64, 64, 32, np.ones(64), 1.0, "cubic", 0, 2)        # unknown detrend
+    fir = dev.FirStream(np.ones(8), 2)
+    x = torch.zeros((2, 100), dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):
+        fir.push(x, skip=101)
+    fir.close()
+    with pytest.raises(NotImplementedError):
+        dev.FirStream(np.ones(16 * 2048 + 1), 1)
+
+
 def test_masked_producer_device(osz, golden):
     import torch
     g = golden("g1_producer.npz")
