@@ -16,12 +16,16 @@
 // The inverse runs the same passes backwards with conjugated twiddles
 // (1/4096 is folded into the caller's spectrum).
 //
-// LDS: separate re/im planes of doubles (ds_read/write_b64).  Exchange 1 uses
-// slot1 = k0*258 + n1*16 + n0, exchange 2 uses slot2 = n0*272 + k1*16 + k0:
-// the writer side is always lane-contiguous, the reader side strides 258
-// (= 2 mod 32) resp. 272 (= 16 mod 32) doubles, which keeps the 32-lane b64
-// read groups conflict free.  (Measured: the alternative with layout B as
-// t = n0 + 16 k0 and strides 272 / 273 is 20 % slower.)
+// LDS: separate re/im planes of doubles.  Exchange 1 is a 16x16 transpose
+// between lanes (n0 fast) and lanes (k0 fast):
+//   slot1 = k0*272 + n1*16 + ((n0 + k0) & 15)
+// the rotation by k0 keeps BOTH sides conflict free under both banking rules
+// the compiler may pick (32-lane/64-bank ds_read_b64, 16-lane/32-bank
+// ds_read2_b64 / ds_write*): writers touch 16 rotated-consecutive doubles,
+// readers hit column (n0 + k0) & 15 of row k0, all distinct, and the two n0
+// rows of a 32-lane half differ in 16*(k0 & 1).  Exchange 2,
+//   slot2 = n0*272 + k1*16 + k0,
+// is lane-contiguous on both sides (rows n0 and n0+1 are 16 mod 32 apart).
 //
 // The phase functions are __host__ __device__ so tests/fft_host_check.cpp can
 // replay the 256 threads on the CPU and pin the index math without a GPU.
@@ -39,7 +43,7 @@ namespace fft {
 
 constexpr int N = 4096;
 constexpr int NT = 256;          // threads per transform
-constexpr int S1 = 258;          // exchange-1 row stride (doubles), = 2 mod 32
+constexpr int S1 = 272;          // exchange-1 row stride (doubles); columns rotated by k0
 constexpr int S2 = 272;          // exchange-2 row stride (doubles), = 16 mod 32
 constexpr int PLANE = 16 * S2;   // doubles per plane (>= 16*S1)
 
@@ -167,18 +171,20 @@ OSZ_HD void f1(int t, double *re, double *im, const Tables &tb, double *pr, doub
             re[r] = a * wr - b * wi;
             im[r] = a * wi + b * wr;
         }
-        pr[k0 * S1 + t] = re[r];
-        pi[k0 * S1 + t] = im[r];
+        const int slot = k0 * S1 + (t & ~15) + ((t + k0) & 15);
+        pr[slot] = re[r];
+        pi[slot] = im[r];
     }
 }
 
 // F2: load layout B (register j = n1), pass 2, twiddle, (caller barriers), store exchange 2.
 OSZ_HD void f2_load(int t, double *re, double *im, const double *pr, const double *pi) {
     const int k0 = t & 15, n0 = t >> 4;
+    const int base = k0 * S1 + ((n0 + k0) & 15);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        re[j] = pr[k0 * S1 + j * 16 + n0];
-        im[j] = pi[k0 * S1 + j * 16 + n0];
+        re[j] = pr[base + j * 16];
+        im[j] = pi[base + j * 16];
     }
 }
 
@@ -253,10 +259,11 @@ OSZ_HD void i2_compute_store(int t, double *re, double *im, double *pr, double *
     inv16(re, im);
     if (!do_store) return;
     const int k0 = t & 15, n0 = t >> 4;
+    const int base = k0 * S1 + ((n0 + k0) & 15);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {  // register j = n1
-        pr[k0 * S1 + j * 16 + n0] = re[j];
-        pi[k0 * S1 + j * 16 + n0] = im[j];
+        pr[base + j * 16] = re[j];
+        pi[base + j * 16] = im[j];
     }
 }
 
@@ -278,7 +285,8 @@ OSZ_HD void i1(int t, double *re, double *im, const Tables &tb, const double *pr
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int k0 = dr(r);
-        double a = pr[k0 * S1 + t], b = pi[k0 * S1 + t];
+        const int slot = k0 * S1 + (t & ~15) + ((t + k0) & 15);
+        double a = pr[slot], b = pi[slot];
         if (k0 != 0) {
             const double wr = twr[k0], wi = -twi[k0];
             const double a2 = a * wr - b * wi;
