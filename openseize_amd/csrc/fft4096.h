@@ -146,6 +146,103 @@ OSZ_HD void t1_powers(int t, const Tables &tb, double *wr, double *wi) {
 #undef OSZ_MUL
 }
 
+// ---- twiddles kept resident in registers ---------------------------------
+// Both twiddle sets a thread ever needs are powers of ONE complex number each:
+// T1[k0][t] = (W4096^t)^k0 and T2[n0][k1] = (W256^n0)^k1.  A kernel that loops
+// over many transforms loads the powers 1, 2, 4, 8 of both once (32 VGPRs,
+// exact table values) and rebuilds the other eleven with <= 3 complex
+// multiplies each time: no table load sits on the per-transform critical path.
+struct TwBase {
+    double r1[4], i1[4];   // W4096^(t * {1,2,4,8})
+    double r2[4], i2[4];   // W256^(n0 * {1,2,4,8}),  n0 = t >> 4
+};
+
+OSZ_HD void tw_load_base(int t, const Tables &tb, TwBase &b) {
+    const int n0 = t >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = 1 << q;
+        b.r1[q] = tb.t1[(k * 256 + t) * 2];
+        b.i1[q] = tb.t1[(k * 256 + t) * 2 + 1];
+        b.r2[q] = tb.t2[(n0 * 16 + k) * 2];
+        b.i2[q] = tb.t2[(n0 * 16 + k) * 2 + 1];
+    }
+}
+
+// wr/wi[k] = base^k for k = 1..15 from the powers 1, 2, 4, 8
+OSZ_HD void tw_expand(const double *br, const double *bi, double *wr, double *wi) {
+#define OSZ_MUL(C, A, B) wr[C] = wr[A] * wr[B] - wi[A] * wi[B]; wi[C] = wr[A] * wi[B] + wi[A] * wr[B];
+    wr[1] = br[0]; wi[1] = bi[0]; wr[2] = br[1]; wi[2] = bi[1];
+    wr[4] = br[2]; wi[4] = bi[2]; wr[8] = br[3]; wi[8] = bi[3];
+    OSZ_MUL(3, 1, 2) OSZ_MUL(5, 1, 4) OSZ_MUL(6, 2, 4) OSZ_MUL(7, 3, 4)
+    OSZ_MUL(9, 1, 8) OSZ_MUL(10, 2, 8) OSZ_MUL(11, 3, 8) OSZ_MUL(12, 4, 8)
+    OSZ_MUL(13, 5, 8) OSZ_MUL(14, 6, 8) OSZ_MUL(15, 7, 8)
+#undef OSZ_MUL
+}
+
+// in-register twiddle multiply of the radix-16 outputs: register r holds
+// logical index dr(r); CONJ for the inverse passes
+template <bool CONJ>
+OSZ_HD void tw_apply(double *re, double *im, const double *wr, const double *wi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = dr(r);
+        if (k != 0) {
+            const double a = re[r], b = im[r], c = wr[k], d = CONJ ? -wi[k] : wi[k];
+            re[r] = a * c - b * d;
+            im[r] = a * d + b * c;
+        }
+    }
+}
+
+// Resident-twiddle versions of the phases (same data movement as below).
+OSZ_HD void f1_w(int t, double *re, double *im, const TwBase &b, double *pr, double *pi) {
+    double wr[16], wi[16];
+    tw_expand(b.r1, b.i1, wr, wi);
+    fwd16(re, im);
+    tw_apply<false>(re, im, wr, wi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int slot = dr(r) * S1 + (t & ~15) + ((t + dr(r)) & 15);
+        pr[slot] = re[r];
+        pi[slot] = im[r];
+    }
+}
+
+OSZ_HD void f2_compute_w(double *re, double *im, const TwBase &b) {
+    double wr[16], wi[16];
+    tw_expand(b.r2, b.i2, wr, wi);
+    fwd16(re, im);
+    tw_apply<false>(re, im, wr, wi);
+}
+
+OSZ_HD void i2_load_w(int t, double *re, double *im, const TwBase &b, const double *pr,
+                      const double *pi) {
+    const int k0 = t & 15, n0 = t >> 4;
+    double wr[16], wi[16];
+    tw_expand(b.r2, b.i2, wr, wi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        re[r] = pr[n0 * S2 + dr(r) * 16 + k0];
+        im[r] = pi[n0 * S2 + dr(r) * 16 + k0];
+    }
+    tw_apply<true>(re, im, wr, wi);
+}
+
+OSZ_HD void i1_w(int t, double *re, double *im, const TwBase &b, const double *pr,
+                 const double *pi) {
+    double wr[16], wi[16];
+    tw_expand(b.r1, b.i1, wr, wi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int slot = dr(r) * S1 + (t & ~15) + ((t + dr(r)) & 15);
+        re[r] = pr[slot];
+        im[r] = pi[slot];
+    }
+    tw_apply<true>(re, im, wr, wi);
+    inv16(re, im);
+}
+
 // ---- forward phases ----------------------------------------------------
 // F1: registers hold x[256 j + t] at register j (layout A).  Pass 1, twiddle,
 // store to exchange 1.

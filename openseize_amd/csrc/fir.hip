@@ -45,7 +45,7 @@ struct FirArgs {
 };
 
 template <bool POW>
-__global__ __launch_bounds__(256) void fir_oa_kernel(FirArgs a) {
+__global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     extern __shared__ double lds[];
     double *pr = lds;
     double *pi = lds + fft::PLANE;
@@ -64,6 +64,9 @@ __global__ __launch_bounds__(256) void fir_oa_kernel(FirArgs a) {
     for (int i = t; i < wm1; i += 256) carry[i] = 0.0;
     __syncthreads();
 
+    fft::TwBase tw;
+    constexpr bool RES = false;   // resident twiddle bases: measured to spill under the 256-VGPR cap
+    if (RES) fft::tw_load_base(t, a.tb, tw);
     double re[16], im[16];
     for (int64_t blk = blk0; blk < blk1; blk += 2) {
         const int64_t start_a = blk * a.step;
@@ -83,31 +86,38 @@ __global__ __launch_bounds__(256) void fir_oa_kernel(FirArgs a) {
             im[j] = p < len_b ? xr[start_b + p] : 0.0;
         }
         // ---- forward transform
-        fft::f1<POW>(t, re, im, a.tb, pr, pi);
+        if (RES) fft::f1_w(t, re, im, tw, pr, pi); else fft::f1<POW>(t, re, im, a.tb, pr, pi);
         __syncthreads();
         fft::f2_load(t, re, im, pr, pi);
-        fft::f2_compute(t, re, im, a.tb);
+        if (RES) fft::f2_compute_w(re, im, tw); else fft::f2_compute(t, re, im, a.tb);
         __syncthreads();
         fft::f2_store(t, re, im, pr, pi);
+        // filter spectrum of this thread's bins: issued before the barrier so
+        // the L2 latency overlaps the exchange and pass 3
+        double hr[16], hi[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = t + 256 * fft::dr(r);
+            hr[r] = a.H[2 * k];
+            hi[r] = a.H[2 * k + 1];
+        }
         __syncthreads();
         fft::f3(t, re, im, pr, pi);
         // ---- multiply by the filter spectrum
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int k = t + 256 * fft::dr(r);
-            const double hr = a.H[2 * k], hi = a.H[2 * k + 1];
             const double u = re[r], v = im[r];
-            re[r] = u * hr - v * hi;
-            im[r] = u * hi + v * hr;
+            re[r] = u * hr[r] - v * hi[r];
+            im[r] = u * hi[r] + v * hr[r];
         }
         // ---- inverse transform (each thread overwrites only the slots it read)
         fft::i3(t, re, im, pr, pi);
         __syncthreads();
-        fft::i2_load(t, re, im, a.tb, pr, pi);
+        if (RES) fft::i2_load_w(t, re, im, tw, pr, pi); else fft::i2_load(t, re, im, a.tb, pr, pi);
         __syncthreads();
         fft::i2_compute_store(t, re, im, pr, pi, true);
         __syncthreads();
-        fft::i1<POW>(t, re, im, a.tb, pr, pi);
+        if (RES) fft::i1_w(t, re, im, tw, pr, pi); else fft::i1<POW>(t, re, im, a.tb, pr, pi);
         __syncthreads();
         // ---- overlap add.  re[j] = a[256 j + t], im[j] = b[256 j + t].
         // Only a few of the 16 register rows take part (j < ceil(wm1/256) for
