@@ -541,3 +541,61 @@ def test_fullsize_properties(osz):
     assert float((run_sos(a, 1) - run_sos(a, 7)).abs().max()) < 1e-10
     # order-independent checksum is reproducible
     assert dev.checksum(a)[0] == dev.checksum(dev.synth_normal(C, n, seed=1))[0]
+
+
+def test_fullsize_properties_resample_spectra(osz):
+    """BASELINE shapes for the other kernels (256 ch x 2^20 per GPU shard):
+    size-independent properties that need no CPU reference.
+    * decimation by 5 of a slow sinusoid (far inside the pass band) returns the
+      sinusoid sampled every 5th point, and the resampler is linear;
+    * Welch PSD (nfft 4096, 50 %): Parseval -- the one-sided density of white
+      noise integrates to its variance; a pure tone puts its power in one bin;
+    * the segment average is invariant to how the stream is cut into pushes."""
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev, _lib
+    from openseize_amd.filtering.fir import Kaiser
+    C, n = 256, 1 << 20
+    # ---- polyphase
+    cutoff = 5000 / 10
+    h = Kaiser(cutoff - cutoff / 10, cutoff + cutoff / 10, 5000, gpass=0.1, gstop=40).coeffs
+    tt = torch.arange(n, dtype=torch.float64, device="cuda")
+    tone = torch.sin(2 * np.pi * 3.0 / 5000 * tt).repeat(C, 1)     # 3 Hz at fs 5000
+    a = dev.synth_normal(C, n, seed=5)
+
+    def down(x):
+        p = dev.PolyStream(h, 1, 5, C)
+        y = p.push(x, final=True)
+        p.close()
+        return y
+
+    yt = down(tone)
+    assert yt.shape == (C, -(-n // 5))
+    ref = tone[:, ::5]
+    core = slice(200, yt.shape[1] - 200)                  # away from the zero-padded edges
+    gain = float(np.sum(h))                               # DC gain of the Kaiser design
+    assert float((yt[:, core] - gain * ref[:, core]).abs().max()) < 2e-3   # pass-band ripple 0.1 dB
+    assert float((down(a + 3.0 * tone) - (down(a) + 3.0 * yt)).abs().max()) < 1e-11
+    # ---- Welch
+    nfft, fs = 4096, 4096.0
+    w = sps.get_window("hann", nfft)
+    scale = float(np.sqrt(1 / (fs * np.sum(w ** 2))))
+
+    def welch(x, cuts):
+        s = dev.SpecStream(nfft, nfft, nfft // 2, w, scale, "constant", _lib.SPEC_PSD_MEAN, C)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            s.push(x[:, lo:hi].contiguous())
+        cnt, mean = s.mean()
+        s.close()
+        return cnt, mean
+
+    cnt, p = welch(a, [0, n])
+    assert cnt == (n - nfft) // (nfft // 2) + 1
+    var = p.sum(axis=1) * (fs / nfft)                     # integral of the density
+    assert np.all(np.abs(var - 1.0) < 0.02)               # N(0,1): variance 1 (511 segments)
+    cnt2, p2 = welch(a, [0, 5000, 5001, 300000, 777777, n])
+    assert cnt2 == cnt and np.max(np.abs(p2 - p)) < 1e-12 * np.max(p)
+    tone2 = torch.sin(2 * np.pi * 512.0 / fs * tt).repeat(C, 1)    # exactly bin 512
+    _, pt = welch(tone2, [0, n])
+    assert np.all(np.argmax(pt, axis=1) == 512)
+    assert np.all(np.abs(pt.sum(axis=1) * (fs / nfft) - 0.5) < 1e-6)    # power of a unit sine
