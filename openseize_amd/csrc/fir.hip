@@ -445,7 +445,7 @@ extern "C" {
 
 int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch) {
     OSZ_REQUIRE(h && taps, "osz_fir_create: null argument");
-    OSZ_REQUIRE(nch >= 1, "osz_fir_create: nch=%d must be positive", nch);
+    OSZ_REQUIRE(nch >= 1 && nch <= 65535, "osz_fir_create: nch=%d not in [1, 65535]", nch);
     OSZ_REQUIRE(ntaps >= 1, "osz_fir_create: ntaps=%d must be positive", ntaps);
     const int nparts = ntaps <= kFirMaxTaps ? 1 : (ntaps + kFirPart - 1) / kFirPart;
     if (nparts > kFirMaxParts)

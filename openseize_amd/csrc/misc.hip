@@ -72,7 +72,7 @@ extern "C" {
 int osz_take(const double *x, int64_t ldx, int nch, const int64_t *idx, int64_t nidx, double *y,
              int64_t ldy, void *stream) {
     OSZ_REQUIRE(x && idx && y, "osz_take: null argument");
-    OSZ_REQUIRE(nch >= 1 && nidx >= 0 && ldy >= nidx, "osz_take: bad sizes");
+    OSZ_REQUIRE(nch >= 1 && nch <= 65535 && nidx >= 0 && ldy >= nidx, "osz_take: bad sizes");
     if (nidx == 0) return OSZ_OK;
     int64_t bx = (nidx + 255) / 256;
     if (bx > 2048) bx = 2048;

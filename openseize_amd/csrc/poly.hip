@@ -157,7 +157,8 @@ extern "C" {
 
 int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M, int nch) {
     OSZ_REQUIRE(h && taps, "osz_poly_create: null argument");
-    OSZ_REQUIRE(ntaps >= 1 && L >= 1 && M >= 1 && nch >= 1, "osz_poly_create: bad sizes");
+    OSZ_REQUIRE(ntaps >= 1 && L >= 1 && M >= 1 && nch >= 1 && nch <= 65535,
+                "osz_poly_create: bad sizes (ntaps=%d L=%d M=%d nch=%d; nch <= 65535)", ntaps, L, M, nch);
     osz_poly_s *p = new osz_poly_s();
     p->m = ntaps;
     p->L = L;

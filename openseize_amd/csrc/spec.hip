@@ -357,7 +357,8 @@ extern "C" {
 int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride, const double *window,
                     double scale, int detrend, int mode, int nch) {
     OSZ_REQUIRE(h && window, "osz_spec_create: null argument");
-    OSZ_REQUIRE(nwin >= 1 && nfft >= nwin && stride >= 1 && stride <= nwin && nch >= 1,
+    OSZ_REQUIRE(nwin >= 1 && nfft >= nwin && stride >= 1 && stride <= nwin && nch >= 1 &&
+                    nch <= 65535,
                 "osz_spec_create: nwin=%d nfft=%d stride=%d nch=%d", nwin, nfft, stride, nch);
     OSZ_REQUIRE(detrend == OSZ_DETREND_CONSTANT || detrend == OSZ_DETREND_LINEAR,
                 "osz_spec_create: unknown detrend %d", detrend);

@@ -599,3 +599,29 @@ def test_fullsize_properties_resample_spectra(osz):
     _, pt = welch(tone2, [0, n])
     assert np.all(np.argmax(pt, axis=1) == 512)
     assert np.all(np.abs(pt.sum(axis=1) * (fs / nfft) - 0.5) < 1e-6)    # power of a unit sine
+
+
+def test_shapes_and_dtypes(osz):
+    """1-D input, float32 input, a non-contiguous view and a 4-D array with the
+    sample axis in the middle all go through the same (channels, samples)
+    normalisation."""
+    import scipy.signal as sps
+    from oracle import oracle as orc
+    rng = np.random.default_rng(51)
+    sos = sps.butter(4, 0.2, output="sos")
+    h = sps.firwin(31, 0.3)
+    x1 = rng.standard_normal(5000)
+    y = np.concatenate(list(osz.sosfilt(producer(x1, 1200, 0), sos, 0)))
+    assert y.shape == x1.shape and rel_err(y, orc.sosfilt(x1[None], sos, 5000)[0][0]) < RTOL
+    x32 = rng.standard_normal((2, 3000)).astype(np.float32)
+    y = np.concatenate(list(osz.oaconvolve(producer(x32, 700, -1), h, -1, "same")), -1)
+    assert y.dtype == np.float64
+    assert rel_err(y, orc.convolve_direct(x32.astype(np.float64), h, "same")) < RTOL
+    big = rng.standard_normal((4, 6000))
+    view = big[::2, 1::2]                                     # non-contiguous
+    y = np.concatenate(list(osz.sosfilt(producer(view, 1000, -1), sos, -1)), -1)
+    assert rel_err(y, orc.sosfilt(np.ascontiguousarray(view), sos, 3000)[0]) < RTOL
+    x4 = rng.standard_normal((2, 3, 2500, 2))
+    y = np.concatenate(list(osz.oaconvolve(producer(x4, 600, 2), h, 2, "full")), 2)
+    ref = orc.convolve_direct(np.moveaxis(x4, 2, -1), h, "full")
+    assert rel_err(np.moveaxis(y, 2, -1), ref) < RTOL
