@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
                     fft::i2_load(t, re, im, tb, pr, pi);
                 }
                 BAR();
-                fft::i2_compute_store(t, re, im, pr, pi, true);
+                fft::i2_compute_store(t, re, im, pr, pi);
                 BAR();
                 if (V == NO_TW) {
 #pragma unroll
@@ -141,9 +141,11 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
     }
 }
 
+static size_t g_extra_lds = 0;   // pad the allocation to force 1 workgroup per CU
+
 template <int V>
 float run(Args a, int nch, const char *name) {
-    const size_t lds = sizeof(double) * (2 * fft::PLANE + 1024);
+    const size_t lds = sizeof(double) * (2 * fft::PLANE + 1024) + g_extra_lds;
     hipFuncSetAttribute(reinterpret_cast<const void *>(fir_kernel<V>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
@@ -209,6 +211,11 @@ int main() {
     run<NO_OA>(a, nch, "no_oa");
     run<NO_BARRIER>(a, nch, "no_barrier");
     run<NO_LDS>(a, nch, "no_lds");
+    run<COPY>(a, nch, "copy_only");
+    g_extra_lds = 20 * 1024;   // 98 KB per workgroup: only one fits per CU
+    printf("-- one workgroup per CU\n");
+    run<FULL>(a, nch, "full");
+    run<NO_GLOBAL>(a, nch, "no_global");
     run<COPY>(a, nch, "copy_only");
     return 0;
 }

@@ -351,10 +351,8 @@ OSZ_HD void i2_load(int t, double *re, double *im, const Tables &tb, const doubl
     }
 }
 
-OSZ_HD void i2_compute_store(int t, double *re, double *im, double *pr, double *pi,
-                             bool do_store) {
+OSZ_HD void i2_compute_store(int t, double *re, double *im, double *pr, double *pi) {
     inv16(re, im);
-    if (!do_store) return;
     const int k0 = t & 15, n0 = t >> 4;
     const int base = k0 * S1 + ((n0 + k0) & 15);
 #pragma unroll

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
         __syncthreads();
         if (RES) fft::i2_load_w(t, re, im, tw, pr, pi); else fft::i2_load(t, re, im, a.tb, pr, pi);
         __syncthreads();
-        fft::i2_compute_store(t, re, im, pr, pi, true);
+        fft::i2_compute_store(t, re, im, pr, pi);
         __syncthreads();
         if (RES) fft::i1_w(t, re, im, tw, pr, pi); else fft::i1<POW>(t, re, im, a.tb, pr, pi);
         __syncthreads();

@@ -164,8 +164,8 @@ struct FusedArgs {
 
 constexpr int kNF = 2049;   // nfft / 2 + 1
 
-template <int MODE>
-__global__ __launch_bounds__(256) void spec_fused_kernel(FusedArgs a) {
+template <int MODE, bool LINEAR>
+__global__ __launch_bounds__(256, 2) void spec_fused_kernel(FusedArgs a) {
     extern __shared__ double lds[];
     double *pr = lds;
     double *pi = lds + fft::PLANE;
@@ -200,15 +200,19 @@ __global__ __launch_bounds__(256) void spec_fused_kernel(FusedArgs a) {
             im[j] = has_b ? (ib < a.ncarry ? cr[ib] : xr[ib - a.ncarry]) : 0.0;
             sum_a += re[j];
             sum_b += im[j];
-            lin_a += (i - mid) * re[j];
-            lin_b += (i - mid) * im[j];
+            if (LINEAR) {
+                lin_a += (i - mid) * re[j];
+                lin_b += (i - mid) * im[j];
+            }
         }
         // ---- trend: block sums
         for (int off = 32; off > 0; off >>= 1) {
             sum_a += __shfl_down(sum_a, off, 64);
             sum_b += __shfl_down(sum_b, off, 64);
-            lin_a += __shfl_down(lin_a, off, 64);
-            lin_b += __shfl_down(lin_b, off, 64);
+            if (LINEAR) {
+                lin_a += __shfl_down(lin_a, off, 64);
+                lin_b += __shfl_down(lin_b, off, 64);
+            }
         }
         if ((t & 63) == 0) {
             red[t >> 6][0] = sum_a;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void spec_fused_kernel(FusedArgs a) {
         const double mean_a = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) / fft::N;
         const double mean_b = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) / fft::N;
         double slope_a = 0.0, slope_b = 0.0;
-        if (a.detrend == OSZ_DETREND_LINEAR) {
+        if (LINEAR) {
             const double sxx = (double)fft::N * ((double)fft::N * fft::N - 1.0) / 12.0;
             slope_a = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) / sxx;
             slope_b = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) / sxx;
@@ -229,8 +233,13 @@ __global__ __launch_bounds__(256) void spec_fused_kernel(FusedArgs a) {
         for (int j = 0; j < 16; ++j) {
             const int i = 256 * j + t;
             const double w = a.window[i];
-            re[j] = (re[j] - mean_a - slope_a * (i - mid)) * w;
-            im[j] = has_b ? (im[j] - mean_b - slope_b * (i - mid)) * w : 0.0;
+            if (LINEAR) {
+                re[j] = (re[j] - mean_a - slope_a * (i - mid)) * w;
+                im[j] = has_b ? (im[j] - mean_b - slope_b * (i - mid)) * w : 0.0;
+            } else {
+                re[j] = (re[j] - mean_a) * w;
+                im[j] = has_b ? (im[j] - mean_b) * w : 0.0;
+            }
         }
         // ---- forward transform of a + i b
         fft::f1<true>(t, re, im, a.tb, pr, pi);
@@ -480,24 +489,24 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
         }
         const size_t lds = sizeof(double) * 2 * fft::PLANE;
         static bool attr_set = false;
+        using kern_t = void (*)(FusedArgs);
+        static const kern_t kerns[3][2] = {
+            {spec_fused_kernel<0, false>, spec_fused_kernel<0, true>},
+            {spec_fused_kernel<1, false>, spec_fused_kernel<1, true>},
+            {spec_fused_kernel<2, false>, spec_fused_kernel<2, true>}};
         if (!attr_set) {
-            OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spec_fused_kernel<0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spec_fused_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spec_fused_kernel<2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            for (int m = 0; m < 3; ++m)
+                for (int l = 0; l < 2; ++l)
+                    OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[m][l]),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)lds));
             attr_set = true;
         }
         {
             KernelTimer kt("spec_fused", st);
             const dim3 grid((unsigned)nruns, h->nch), block(256);
-            if (h->mode == OSZ_SPEC_PSD_MEAN)
-                hipLaunchKernelGGL(spec_fused_kernel<OSZ_SPEC_PSD_MEAN>, grid, block, lds, st, fa);
-            else if (h->mode == OSZ_SPEC_PSD_SEGMENTS)
-                hipLaunchKernelGGL(spec_fused_kernel<OSZ_SPEC_PSD_SEGMENTS>, grid, block, lds, st, fa);
-            else
-                hipLaunchKernelGGL(spec_fused_kernel<OSZ_SPEC_DFT_SEGMENTS>, grid, block, lds, st, fa);
+            hipLaunchKernelGGL(kerns[h->mode][h->detrend == OSZ_DETREND_LINEAR ? 1 : 0], grid, block,
+                               lds, st, fa);
         }
         OSZ_HIP(hipGetLastError());
         if (h->mode == OSZ_SPEC_PSD_MEAN) {

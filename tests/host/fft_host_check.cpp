@@ -74,7 +74,7 @@ int main() {
     for (int t = 0; t < NT; ++t) {
         i2_load(t, &re[t * 16], &im[t * 16], tb, pr.data(), pi.data());
     }
-    for (int t = 0; t < NT; ++t) i2_compute_store(t, &re[t * 16], &im[t * 16], pr.data(), pi.data(), true);
+    for (int t = 0; t < NT; ++t) i2_compute_store(t, &re[t * 16], &im[t * 16], pr.data(), pi.data());
     for (int t = 0; t < NT; ++t) i1(t, &re[t * 16], &im[t * 16], tb, pr.data(), pi.data());
     double ierr = 0;
     for (int t = 0; t < NT; ++t)
@@ -102,7 +102,7 @@ int main() {
     for (int t = 0; t < NT; ++t) f3(t, &re[t * 16], &im[t * 16], pr.data(), pi.data());
     for (int t = 0; t < NT; ++t) i3(t, &re[t * 16], &im[t * 16], pr.data(), pi.data());
     for (int t = 0; t < NT; ++t) i2_load_w(t, &re[t * 16], &im[t * 16], tw[t], pr.data(), pi.data());
-    for (int t = 0; t < NT; ++t) i2_compute_store(t, &re[t * 16], &im[t * 16], pr.data(), pi.data(), true);
+    for (int t = 0; t < NT; ++t) i2_compute_store(t, &re[t * 16], &im[t * 16], pr.data(), pi.data());
     for (int t = 0; t < NT; ++t) i1_w(t, &re[t * 16], &im[t * 16], tw[t], pr.data(), pi.data());
     double werr = 0;
     for (int t = 0; t < NT; ++t)

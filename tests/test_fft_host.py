@@ -1,0 +1,20 @@
+"""CPU replay of the 256-thread 4096-point FFT used by the FIR and spectra
+kernels (openseize_amd/csrc/fft4096.h): the phase functions are
+__host__ __device__, so the index algebra, twiddles and LDS slot maps are
+checked here without a GPU (g++ build of tests/host/fft_host_check.cpp)."""
+
+import os
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fft4096_host_replay():
+    src = os.path.join(ROOT, "tests", "host", "fft_host_check.cpp")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "fft_host_check")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK" in out.stdout
