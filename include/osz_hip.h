@@ -220,6 +220,22 @@ int osz_spec_mean(osz_spec_t h, double *mean, int64_t *count, void *stream);
 int osz_take(const double *x, int64_t ldx, int nch, const int64_t *idx,
              int64_t nidx, double *y, int64_t ldy, void *stream);
 
+/* ---- EDF record decode ----------------------------- */
+/*
+ * Replaces the host-side unpacking of edf.Reader (reference
+ * file_io/edf.py:452-483 _records, :382-419 _decipher, :506-556 _read_array):
+ * the file's little-endian int16 records go to the device as they are (2 B per
+ * sample over PCIe instead of 8) and are de-interleaved and scaled there.
+ * raw: device int16, records [rec0, ...) of `reclen` samples each; per-channel
+ * device arrays choff/spr (int32), slope/offset (f64), len (int64: samples the
+ * channel can fill; the rest of the `width` columns get padvalue*slope+offset,
+ * as the reference pads before deciphering).  out: (nch, width) f64.
+ */
+int osz_edf_decode(const int16_t *raw, int reclen, int nch, const int32_t *choff,
+                   const int32_t *spr, const double *slope, const double *offset,
+                   const int64_t *len, int64_t rec0, int64_t start, int64_t width,
+                   double padvalue, double *out, int64_t ldo, void *stream);
+
 /* ---- synthetic device-resident source (benchmarks, tests) ------------- */
 /* x[c, j] = N(0,1) keyed by (seed, ch0 + c, n0 + j): counter-based, so any
  * shard or chunk is reproducible on CPU and GPU alike. */

@@ -100,6 +100,9 @@ SIGNATURES = {
     "osz_spec_mean": (ctypes.c_int, [c_vp, c_dp, ctypes.POINTER(c_i64), c_vp]),
     "osz_take": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp,
                                 c_i64, c_vp]),
+    "osz_edf_decode": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp,
+                                      c_vp, c_vp, c_i64, c_i64, c_i64, ctypes.c_double,
+                                      c_vp, c_i64, c_vp]),
     "osz_synth_normal": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64,
                                         ctypes.c_uint64, c_i64, c_i64, c_vp]),
     "osz_checksum": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64,

@@ -17,6 +17,45 @@ __global__ void take_kernel(const double *x, int64_t ldx, const int64_t *idx, in
         yr[j] = xr[idx[j]];
 }
 
+// EDF records -> physical float64 samples (reference file_io/edf.py:452-556):
+// a record holds spr[c] little-endian int16 samples of every signal one after
+// the other; out[c, i] = raw * slope[c] + offset[c] for sample start + i of
+// channel c (two roundings, as the reference's `arr * slopes; += offsets`);
+// positions a channel cannot fill get padvalue pushed through the same map
+// (the reference pads BEFORE deciphering, edf.py:553-556).
+struct EdfArgs {
+    const int16_t *raw;      // records [rec0, rec0 + nrec) of the file
+    const int32_t *choff;    // offset of channel c inside a record (samples)
+    const int32_t *spr;      // samples per record of channel c
+    const double *slope, *offset;
+    const int64_t *len;      // valid output samples of channel c
+    double *out;
+    int64_t ldo, rec0, start, width;
+    int reclen;
+    double padvalue;
+};
+
+__global__ void edf_decode_kernel(EdfArgs a) {
+#pragma clang fp contract(off)   // keep the reference's two roundings: no fused multiply-add
+    const int c = blockIdx.y;
+    const int spr = a.spr[c];
+    const double slope = a.slope[c], offset = a.offset[c];
+    const int64_t len = a.len[c];
+    const int16_t *raw = a.raw + a.choff[c];
+    double *o = a.out + (int64_t)c * a.ldo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.width;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        double d = a.padvalue;
+        if (i < len) {
+            const int64_t s = a.start + i;
+            const int64_t rec = s / spr - a.rec0;
+            d = (double)raw[rec * a.reclen + (s % spr)];
+        }
+        const double scaled = d * slope;
+        o[i] = scaled + offset;
+    }
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     // splitmix64 finaliser
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -78,6 +117,36 @@ int osz_take(const double *x, int64_t ldx, int nch, const int64_t *idx, int64_t 
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(take_kernel, dim3((unsigned)bx, nch), dim3(256), 0, as_stream(stream), x,
                        ldx, idx, nidx, y, ldy);
+    OSZ_HIP(hipGetLastError());
+    return OSZ_OK;
+}
+
+int osz_edf_decode(const int16_t *raw, int reclen, int nch, const int32_t *choff,
+                   const int32_t *spr, const double *slope, const double *offset,
+                   const int64_t *len, int64_t rec0, int64_t start, int64_t width, double padvalue,
+                   double *out, int64_t ldo, void *stream) {
+    OSZ_REQUIRE(raw && choff && spr && slope && offset && len && out, "osz_edf_decode: null argument");
+    OSZ_REQUIRE(nch >= 1 && nch <= 65535 && reclen >= 1 && width >= 0 && ldo >= width,
+                "osz_edf_decode: bad sizes");
+    if (width == 0) return OSZ_OK;
+    EdfArgs a{};
+    a.raw = raw;
+    a.choff = choff;
+    a.spr = spr;
+    a.slope = slope;
+    a.offset = offset;
+    a.len = len;
+    a.out = out;
+    a.ldo = ldo;
+    a.rec0 = rec0;
+    a.start = start;
+    a.width = width;
+    a.reclen = reclen;
+    a.padvalue = padvalue;
+    int64_t bx = (width + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(edf_decode_kernel, dim3((unsigned)bx, nch), dim3(256), 0, as_stream(stream),
+                       a);
     OSZ_HIP(hipGetLastError());
     return OSZ_OK;
 }

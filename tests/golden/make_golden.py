@@ -353,6 +353,74 @@ def g10_ba():
     save("g10_ba.npz", **out)
 
 
+# --------------------------------------------------------------------------
+# G11 EDF decode: a synthetic EDF written byte by byte from
+# the published EDF layout (256-byte fixed header, 256 bytes per signal,
+# little-endian int16 records) and read back with the reference's Reader.
+# --------------------------------------------------------------------------
+def write_synthetic_edf(path, rng):
+    names = ["EEG Fp1", "EEG Cz", "EMG slow", "EEG O2", "EDF Annotations"]
+    spr = [500, 500, 250, 500, 30]
+    pmin = [-3276.8, -500.0, -1000.0, -200.0, -1.0]
+    pmax = [3276.7, 500.0, 1000.0, 250.0, 1.0]
+    dmin, dmax = [-32768] * 5, [32767] * 5
+    nrec, ns = 20, len(names)
+
+    def field(val, width):
+        return str(val).ljust(width)[:width].encode("ascii")
+
+    head = b"".join([
+        field("0", 8), field("synthetic patient", 80), field("synthetic recording", 80),
+        field("01.01.26", 8), field("00.00.00", 8), field(256 + 256 * ns, 8),
+        field("", 44), field(nrec, 8), field(1, 8), field(ns, 4),
+        b"".join(field(n, 16) for n in names),
+        b"".join(field("AgAgCl", 80) for _ in names),
+        b"".join(field("uV", 8) for _ in names),
+        b"".join(field(v, 8) for v in pmin), b"".join(field(v, 8) for v in pmax),
+        b"".join(field(v, 8) for v in dmin), b"".join(field(v, 8) for v in dmax),
+        b"".join(field("HP:0.1Hz", 80) for _ in names),
+        b"".join(field(v, 8) for v in spr), b"".join(field("", 32) for _ in names)])
+    assert len(head) == 256 + 256 * ns
+    recs = rng.integers(-32768, 32768, size=(nrec, sum(spr)), dtype=np.int16)
+    with open(path, "wb") as fp:
+        fp.write(head)
+        fp.write(recs.astype("<i2").tobytes())
+
+
+def g11_edf():
+    from openseize.file_io import edf as ref_edf
+    rng = np.random.default_rng(1111)
+    path = os.path.join(OUT, "synthetic.edf")
+    write_synthetic_edf(path, rng)
+    out = {}
+    with ref_edf.Reader(path) as reader:
+        hdr = reader.header
+        out["channels"] = np.array(hdr.channels)
+        out["samples"] = np.array(hdr.samples)
+        out["slopes"] = np.array(hdr.slopes)
+        out["offsets"] = np.array(hdr.offsets)
+        out["shape"] = np.array(reader.shape)
+        out["read_all"] = reader.read(0)
+        out["read_123_4567"] = reader.read(123, 4567)
+        out["read_4900_5200"] = reader.read(4900, 5200)     # slow channel runs out
+        out["read_9990_end"] = reader.read(9990)
+        out["read_pad0"] = reader.read(4000, 6000, padvalue=0.0)
+        reader.channels = [0, 3]
+        out["read_ch03"] = reader.read(250, 2750)
+        reader.channels = [2]
+        out["read_ch2"] = reader.read(100, 4000)
+        reader.channels = hdr.channels
+    # ReaderProducer chunk lengths
+    rd = ref_edf.Reader(path)
+    pro = producer(rd, chunksize=1700, axis=-1)
+    out["pro_shape"] = np.array(pro.shape)
+    out["pro_len"] = lengths(pro)
+    pro2 = producer(ref_edf.Reader(path), chunksize=1700, axis=-1, start=300, stop=8000)
+    out["pro2_len"] = lengths(pro2)
+    out["pro2_cat"] = np.concatenate(list(pro2), axis=-1)
+    save("g11_edf.npz", **out)
+
+
 if __name__ == "__main__":
     g1_producer()
     g2_fir()
@@ -364,3 +432,4 @@ if __name__ == "__main__":
     g8_stft()
     g9_design()
     g10_ba()
+    g11_edf()

@@ -231,3 +231,30 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} not exported"
     assert lib.osz_version() >= 100
+
+
+# ------------------------------------------------------------ EDF header / plan
+def test_edf_header_and_plan(golden):
+    """Header parsing and record location of the EDF reader are pure host
+    logic (the decode itself is a device kernel, tested with -m gpu)."""
+    from openseize_amd.file_io.edf import Reader
+    g = golden("g11_edf.npz")
+    path = os.path.join(ROOT, "tests", "golden", "synthetic.edf")
+    with Reader(path) as reader:
+        hdr = reader.header
+        assert hdr.channels == list(g["channels"]) and hdr.annotated
+        assert list(hdr.samples) == list(g["samples"])
+        assert np.array_equal(hdr.slopes, g["slopes"])
+        assert np.array_equal(hdr.offsets, g["offsets"])
+        assert tuple(reader.shape) == tuple(g["shape"])
+        p = reader.plan(4900, 5200, reader.channels)
+        assert p["rec0"] == 9 and p["nrec"] == 11 and p["width"] == 300
+        assert list(p["len"]) == [300, 300, 100, 300]        # slow channel runs out
+        pro = producer(reader, 1700, axis=-1)
+        assert tuple(pro.shape) == tuple(g["pro_shape"])
+        pro2 = producer(Reader(path), 1700, axis=-1, start=300, stop=8000)
+        assert pro2.shape == (4, 7700)
+        q = pickle.loads(pickle.dumps(pro2))                 # closed reader pickles
+        assert q.shape == pro2.shape
+        with pytest.raises(ValueError):
+            reader.channels = 3
