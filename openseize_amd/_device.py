@@ -51,6 +51,40 @@ def zeros_like_kind(ref, shape, value=0.0):
     return value * np.ones(shape)
 
 
+# -- small kind-agnostic array helpers for the producer-level glue (protools)
+def expand_dims(a, axes):
+    if is_tensor(a):
+        for ax in sorted(ax % (a.ndim + len(axes)) for ax in axes):
+            a = a.unsqueeze(ax)
+        return a
+    return np.expand_dims(a, axes)
+
+
+def squeeze(a, axis=None):
+    if is_tensor(a):
+        return a.squeeze() if axis is None else a.squeeze(axis)
+    return np.squeeze(a, axis)
+
+
+def mean(a, axis, keepdims=False, ignore_nan=True):
+    if is_tensor(a):
+        fn = torch.nanmean if ignore_nan else torch.mean
+        return fn(a, dim=axis, keepdim=keepdims)
+    return (np.nanmean if ignore_nan else np.mean)(a, axis=axis, keepdims=keepdims)
+
+
+def std(a, axis, keepdims=False, ignore_nan=True):
+    if is_tensor(a):
+        mu = mean(a, axis, True, ignore_nan)
+        out = torch.sqrt(mean((a - mu) ** 2, axis, True, ignore_nan))
+        return out if keepdims else out.squeeze(axis)
+    return (np.nanstd if ignore_nan else np.std)(a, axis=axis, keepdims=keepdims)
+
+
+def sqrt(a):
+    return torch.sqrt(a) if is_tensor(a) else np.sqrt(a)
+
+
 def require_gpu():
     lib = _lib.load()          # raises OszLibraryError when the .so is missing
     if torch is None or not torch.cuda.is_available():

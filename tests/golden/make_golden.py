@@ -421,6 +421,41 @@ def g11_edf():
     save("g11_edf.npz", **out)
 
 
+# --------------------------------------------------------------------------
+# G12 protools glue
+# --------------------------------------------------------------------------
+def g12_protools():
+    from openseize.core import protools as ref_pt
+    rng = np.random.default_rng(1212)
+    x = rng.standard_normal((3, 1, 4001))
+    x[1, 0, 77] = np.nan
+    out = {"x": x}
+    pro = producer(x, 900, axis=-1)
+    sq = ref_pt.squeeze(pro)
+    out["squeeze_shape"], out["squeeze_axis"] = np.array(sq.shape), np.array(sq.axis)
+    ex = ref_pt.expand_dims(producer(x[:, 0], 900, axis=-1), (0, -1))
+    out["expand_shape"], out["expand_axis"] = np.array(ex.shape), np.array(ex.axis)
+    out["expand_arr"] = ex.to_array()
+    other = rng.standard_normal((3, 1, 1))
+    out["other"] = other
+    out["add_arr"] = ref_pt.add(pro, other).to_array()
+    out["mul_pro"] = ref_pt.multiply(pro, producer(2 * x, 500, axis=-1)).to_array()
+    w = rng.standard_normal(4001)
+    out["w"] = w
+    out["mul_along_prod"] = ref_pt.multiply_along_axis(pro, w, -1).to_array()
+    out["mul_along_other"] = ref_pt.multiply_along_axis(pro, np.array([1.0, 2.0, 3.0]), 0).to_array()
+    out["slice_prod"] = ref_pt.slice_along_axis(pro, 10, 3000, 3, axis=-1).to_array()
+    out["slice_other"] = ref_pt.slice_along_axis(pro, 1, None, None, axis=0).to_array()
+    for ignore in (True, False):
+        out[f"mean_prod_{int(ignore)}"] = ref_pt.mean(pro, -1, ignore, keepdims=True)
+        out[f"std_prod_{int(ignore)}"] = ref_pt.std(pro, -1, ignore, keepdims=True)
+    out["mean_other"] = ref_pt.mean(pro, 0)
+    out["std_other"] = ref_pt.std(pro, 0)
+    out["standardize_prod"] = ref_pt.standardize(pro, -1).to_array()
+    out["standardize_other"] = ref_pt.standardize(pro, 0).to_array()
+    save("g12_protools.npz", **out)
+
+
 if __name__ == "__main__":
     g1_producer()
     g2_fir()
@@ -433,3 +468,4 @@ if __name__ == "__main__":
     g9_design()
     g10_ba()
     g11_edf()
+    g12_protools()

@@ -666,3 +666,29 @@ def test_edf_reader_device_decode(osz, golden):
     from oracle import oracle as orc
     ref, _ = orc.sosfilt(g["pro2_cat"][:, :4700], sos, 4700)
     assert rel_err(torch.cat(chunks, -1).cpu().numpy(), ref) < RTOL
+
+
+def test_protools_device(osz, golden):
+    """The producer-level glue keeps device-resident producers on the device
+    and gives the reference's results."""
+    import torch
+    from openseize_amd.core import protools
+    g = golden("g12_protools.npz")
+    xd = torch.from_numpy(g["x"]).cuda()
+    pro = producer(xd, 900, axis=-1)
+
+    def eq(got, want):
+        got = got.cpu().numpy() if torch.is_tensor(got) else got
+        return np.allclose(got, want, rtol=1e-12, atol=1e-12, equal_nan=True)
+
+    assert eq(protools.squeeze(pro).to_array(), g["x"][:, 0])
+    assert eq(protools.add(pro, g["other"]).to_array(), g["add_arr"])
+    assert eq(protools.multiply_along_axis(pro, g["w"], -1).to_array(), g["mul_along_prod"])
+    assert eq(protools.slice_along_axis(pro, 10, 3000, 3, axis=-1).to_array(), g["slice_prod"])
+    assert eq(protools.mean(pro, -1, True, keepdims=True), g["mean_prod_1"])
+    assert eq(protools.std(pro, -1, True, keepdims=True), g["std_prod_1"])
+    assert eq(protools.std(pro, 0), g["std_other"])
+    out = protools.standardize(pro, -1)
+    chunks = list(out)
+    assert all(c.is_cuda for c in chunks)
+    assert eq(torch.cat(chunks, -1), g["standardize_prod"])

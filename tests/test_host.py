@@ -258,3 +258,38 @@ def test_edf_header_and_plan(golden):
         assert q.shape == pro2.shape
         with pytest.raises(ValueError):
             reader.channels = 3
+
+
+# ------------------------------------------------------------ protools glue
+def test_protools_golden(golden):
+    """Producer-level glue on host arrays against the reference's results
+    (pure chunk mapping / per-channel moments, no DSP numerics)."""
+    g = golden("g12_protools.npz")
+    x = g["x"]
+    pro = producer(x, 900, axis=-1)
+    eq = partial(np.allclose, rtol=1e-13, atol=1e-13, equal_nan=True)
+    sq = protools.squeeze(pro)
+    assert tuple(sq.shape) == tuple(g["squeeze_shape"]) and sq.axis == int(g["squeeze_axis"])
+    assert np.array_equal(sq.to_array(), x[:, 0], equal_nan=True)
+    with pytest.raises(ValueError):
+        protools.squeeze(pro, axis=0)
+    ex = protools.expand_dims(producer(x[:, 0], 900, axis=-1), (0, -1))
+    assert tuple(ex.shape) == tuple(g["expand_shape"]) and ex.axis == int(g["expand_axis"])
+    assert np.array_equal(ex.to_array(), g["expand_arr"], equal_nan=True)
+    assert eq(protools.add(pro, g["other"]).to_array(), g["add_arr"])
+    assert eq(protools.multiply(pro, producer(2 * x, 500, axis=-1)).to_array(), g["mul_pro"])
+    with pytest.raises(ValueError):
+        list(protools.add(pro, producer(x[:2], 900, axis=-1)))
+    assert eq(protools.multiply_along_axis(pro, g["w"], -1).to_array(), g["mul_along_prod"])
+    assert eq(protools.multiply_along_axis(pro, np.array([1.0, 2.0, 3.0]), 0).to_array(),
+              g["mul_along_other"])
+    assert np.array_equal(protools.slice_along_axis(pro, 10, 3000, 3, axis=-1).to_array(),
+                          g["slice_prod"], equal_nan=True)
+    assert np.array_equal(protools.slice_along_axis(pro, 1, None, None, axis=0).to_array(),
+                          g["slice_other"], equal_nan=True)
+    for ignore in (True, False):
+        assert eq(protools.mean(pro, -1, ignore, keepdims=True), g[f"mean_prod_{int(ignore)}"])
+        assert eq(protools.std(pro, -1, ignore, keepdims=True), g[f"std_prod_{int(ignore)}"])
+    assert eq(protools.mean(pro, 0), g["mean_other"]) and eq(protools.std(pro, 0), g["std_other"])
+    assert eq(protools.standardize(pro, -1).to_array(), g["standardize_prod"])
+    assert eq(protools.standardize(pro, 0).to_array(), g["standardize_other"])
