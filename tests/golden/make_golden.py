@@ -456,6 +456,19 @@ def g12_protools():
     save("g12_protools.npz", **out)
 
 
+# --------------------------------------------------------------------------
+# G13 Hilbert transformer
+# --------------------------------------------------------------------------
+def g13_hilbert():
+    from openseize.filtering.special import Hilbert
+    rng = np.random.default_rng(1313)
+    x = rng.standard_normal((2, 8000))
+    filt = Hilbert(width=12.5, fs=500)
+    out = {"x": x, "coeffs": filt.coeffs}
+    out["imag_same"] = filt(x, chunksize=3000, axis=-1, mode="same")
+    save("g13_hilbert.npz", **out)
+
+
 if __name__ == "__main__":
     g1_producer()
     g2_fir()
@@ -469,3 +482,4 @@ if __name__ == "__main__":
     g10_ba()
     g11_edf()
     g12_protools()
+    g13_hilbert()

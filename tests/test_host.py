@@ -188,6 +188,12 @@ def test_design_classes(golden):
                           g["kaiser_down5_fs5000"])
     with pytest.raises(ValueError, match="same shape"):
         iir.Butter(fpass=[1, 2], fstop=3, fs=100)
+    from openseize_amd.filtering.special import Hilbert
+    gh = golden("g13_hilbert.npz")
+    hil = Hilbert(width=12.5, fs=500)
+    assert len(hil.coeffs) % 2 == 1 and np.allclose(hil.coeffs, gh["coeffs"], rtol=0, atol=1e-15)
+    # (the reference tapers with a *periodic* Kaiser window, so the taps are
+    # antisymmetric only to ~6e-4; that behaviour is kept)
 
 
 def test_pickleable_pipeline():
