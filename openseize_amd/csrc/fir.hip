@@ -44,7 +44,13 @@ struct FirArgs {
     double *tails;    // [nch][nruns][wlen-1]
 };
 
-template <bool POW>
+// NR = rows of 256 samples per block (block length step = 256 NR, chosen by
+// the host as the largest multiple of 256 with step + ntaps - 1 <= 4096).  A
+// pair of two whole blocks past the left cut -- every pair but the ragged last
+// one of a push -- takes the FAST path: which register rows carry samples is a
+// compile-time fact, so loads, stores and the first butterfly stage (whose
+// rows >= NR are literal zeros) need no predication.
+template <bool POW, int NR>
 __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     extern __shared__ double lds[];
     double *pr = lds;
@@ -79,11 +85,21 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
             len_b = rem_b < a.step ? (int)rem_b : a.step;
         }
         // ---- load two zero-padded real blocks as one complex block
+        const bool fast = len_a == 256 * NR && len_b == 256 * NR && start_a >= a.skip && !a.accum;
+        if (fast) {
+            const double *pa = xr + start_a + t, *pb = xr + start_b + t;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = 256 * j + t;
-            re[j] = p < len_a ? xr[start_a + p] : 0.0;
-            im[j] = p < len_b ? xr[start_b + p] : 0.0;
+            for (int j = 0; j < 16; ++j) {
+                re[j] = j < NR ? pa[256 * j] : 0.0;
+                im[j] = j < NR ? pb[256 * j] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int p = 256 * j + t;
+                re[j] = p < len_a ? xr[start_a + p] : 0.0;
+                im[j] = p < len_b ? xr[start_b + p] : 0.0;
+            }
         }
         // ---- forward transform
         if (RES) fft::f1_w(t, re, im, tw, pr, pi); else fft::f1<POW>(t, re, im, a.tb, pr, pi);
@@ -120,44 +136,76 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
         if (RES) fft::i1_w(t, re, im, tw, pr, pi); else fft::i1<POW>(t, re, im, a.tb, pr, pi);
         __syncthreads();
         // ---- overlap add.  re[j] = a[256 j + t], im[j] = b[256 j + t].
-        // Only a few of the 16 register rows take part (j < ceil(wm1/256) for
-        // the heads, the rows covering [len, len + wm1) for the tails): the
-        // row tests are wave-uniform scalar branches, the lane tests stay inside.
         double *xb = pr;  // a's tail handed to b's head
-        const int jhead = (wm1 + 255) >> 8;
-        const int ja0 = len_a >> 8, ja1 = (len_a + wm1 + 255) >> 8;
-        const int jb0 = len_b >> 8, jb1 = (len_b + wm1 + 255) >> 8;
+        if (fast) {
+            // whole blocks: the tail occupies rows NR..15 and lands in rows
+            // 0..15-NR of the next block (wm1 <= 256 (16 - NR) by construction)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = 256 * j + t;
-            if (j < jhead) {
-                if (p < wm1) re[j] += carry[p];
+            for (int j = 0; j < 16 - NR; ++j) {
+                const int p = 256 * j + t;
+                if (p < wm1) {
+                    re[j] += carry[p];
+                    xb[p] = re[j + NR];
+                }
             }
-            if (j >= ja0 && j < ja1) {
-                const int q = p - len_a;
-                if (q >= 0 && q < wm1) xb[q] = re[j];
-            }
-        }
-        __syncthreads();
+            __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = 256 * j + t;
-            if (j < jhead) {
-                if (p < wm1) im[j] += xb[p];
+            for (int j = 0; j < 16 - NR; ++j) {
+                const int p = 256 * j + t;
+                if (p < wm1) {
+                    im[j] += xb[p];
+                    carry[p] = im[j + NR];
+                }
             }
-            if (j >= jb0 && j < jb1) {
-                const int q = p - len_b;
-                if (q >= 0 && q < wm1) carry[q] = im[j];
+        } else {
+            // Only a few of the 16 register rows take part (j < ceil(wm1/256)
+            // for the heads, the rows covering [len, len + wm1) for the tails):
+            // the row tests are wave-uniform scalar branches, the lane tests
+            // stay inside.
+            const int jhead = (wm1 + 255) >> 8;
+            const int ja0 = len_a >> 8, ja1 = (len_a + wm1 + 255) >> 8;
+            const int jb0 = len_b >> 8, jb1 = (len_b + wm1 + 255) >> 8;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int p = 256 * j + t;
+                if (j < jhead) {
+                    if (p < wm1) re[j] += carry[p];
+                }
+                if (j >= ja0 && j < ja1) {
+                    const int q = p - len_a;
+                    if (q >= 0 && q < wm1) xb[q] = re[j];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int p = 256 * j + t;
+                if (j < jhead) {
+                    if (p < wm1) im[j] += xb[p];
+                }
+                if (j >= jb0 && j < jb1) {
+                    const int q = p - len_b;
+                    if (q >= 0 && q < wm1) carry[q] = im[j];
+                }
             }
         }
         // ---- write the finished samples (full-convolution positions start_a + p)
+        if (fast) {
+            double *qa = yr + (start_a - a.skip) + t, *qb = yr + (start_b - a.skip) + t;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = 256 * j + t;
-            const int64_t oa = start_a + p - a.skip;
-            if (p < len_a && oa >= 0) yr[oa] = a.accum ? yr[oa] + re[j] : re[j];
-            const int64_t ob = start_b + p - a.skip;
-            if (p < len_b && ob >= 0) yr[ob] = a.accum ? yr[ob] + im[j] : im[j];
+            for (int j = 0; j < NR; ++j) {
+                qa[256 * j] = re[j];
+                qb[256 * j] = im[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int p = 256 * j + t;
+                const int64_t oa = start_a + p - a.skip;
+                if (p < len_a && oa >= 0) yr[oa] = a.accum ? yr[oa] + re[j] : re[j];
+                const int64_t ob = start_b + p - a.skip;
+                if (p < len_b && ob >= 0) yr[ob] = a.accum ? yr[ob] + im[j] : im[j];
+            }
         }
         __syncthreads();
     }
@@ -321,7 +369,8 @@ struct osz_fir_s {
 
 static int fir_build_part(FirPart &pt, const double *taps, int ntaps, int nch) {
     pt.ntaps = ntaps;
-    pt.step = fft::N - ntaps + 1;
+    pt.step = ((fft::N - ntaps + 1) / 256) * 256;   // whole rows of 256: see fir_oa_kernel
+    if (pt.step > 15 * 256) pt.step = 15 * 256;
     pt.cur = 0;
     pt.dH = pt.dstate[0] = pt.dstate[1] = nullptr;
     // H[k] = sum_m h[m] W4096^(k m) / 4096, long double accumulation
@@ -377,17 +426,12 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
             return fail(OSZ_ERR_NOMEM, "osz_fir_push: tails workspace %lld doubles", (long long)need);
         h->tails_cap = need;
     }
-    static bool attr_set = false;
     static bool pow_tw = true;    // pass-1 twiddles as products of 4 loaded powers (OSZ_FIR_T1POW=0: table)
-    const size_t lds = sizeof(double) * (2 * fft::PLANE + 2048);
-    if (!attr_set) {
-        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fir_oa_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fir_oa_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static bool env_read = false;
+    if (!env_read) {
         const char *e = getenv("OSZ_FIR_T1POW");
         pow_tw = !(e && atoi(e) == 0);   // default on: measured 2.4 % faster
-        attr_set = true;
+        env_read = true;
     }
     FirArgs a{};
     a.x = x;
@@ -407,13 +451,26 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
     a.tails = h->dtails;
     const size_t lds_used = sizeof(double) * (2 * fft::PLANE + (wm1 > 0 ? wm1 : 1));
     {
+        using kern_t = void (*)(FirArgs);
+        // rows per block: 8 (2049 taps) .. 15 (<= 257 taps)
+        static const kern_t kerns[2][8] = {
+            {fir_oa_kernel<false, 8>, fir_oa_kernel<false, 9>, fir_oa_kernel<false, 10>,
+             fir_oa_kernel<false, 11>, fir_oa_kernel<false, 12>, fir_oa_kernel<false, 13>,
+             fir_oa_kernel<false, 14>, fir_oa_kernel<false, 15>},
+            {fir_oa_kernel<true, 8>, fir_oa_kernel<true, 9>, fir_oa_kernel<true, 10>,
+             fir_oa_kernel<true, 11>, fir_oa_kernel<true, 12>, fir_oa_kernel<true, 13>,
+             fir_oa_kernel<true, 14>, fir_oa_kernel<true, 15>}};
+        static bool attr_set[2][8] = {};
+        const int nr = pt.step / 256;
+        kern_t kern = kerns[pow_tw ? 1 : 0][nr - 8];
+        if (!attr_set[pow_tw ? 1 : 0][nr - 8]) {
+            const size_t lds_max = sizeof(double) * (2 * fft::PLANE + 2048);
+            OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            attr_set[pow_tw ? 1 : 0][nr - 8] = true;
+        }
         KernelTimer kt("fir_oa", st);
-        if (pow_tw)
-            hipLaunchKernelGGL(fir_oa_kernel<true>, dim3((unsigned)nruns, h->nch), dim3(256),
-                               lds_used, st, a);
-        else
-            hipLaunchKernelGGL(fir_oa_kernel<false>, dim3((unsigned)nruns, h->nch), dim3(256),
-                               lds_used, st, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nruns, h->nch), dim3(256), lds_used, st, a);
     }
     OSZ_HIP(hipGetLastError());
     if (wm1 > 0) {
