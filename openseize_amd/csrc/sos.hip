@@ -80,6 +80,23 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// In-kernel phase stamps for the diagnostic build only
+// (benchmarks/sos_stamps.hip defines OSZ_SOS_STAMPS); the library build has none.
+#ifdef OSZ_SOS_STAMPS
+__device__ unsigned long long *g_sos_stamps = nullptr;   // [waves][8] cycle sums
+#define OSZ_STAMP(slot)                                                              \
+    do {                                                                             \
+        unsigned long long now_;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        stamp_acc[slot] += now_ - stamp_last;                                        \
+        stamp_last = now_;                                                           \
+    } while (0)
+#else
+#define OSZ_STAMP(slot) do { } while (0)
+#endif
+
 // wave-private LDS hand-offs need no workgroup barrier: LDS executes one
 // wave's instructions in order; this only stops the compiler reordering them
 __device__ __forceinline__ void wave_lds_fence() {
@@ -152,6 +169,10 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
         }
     };
     fetch(0);
+#ifdef OSZ_SOS_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
 
     for (int64_t t = 0; t < ntiles; ++t) {
         const int64_t pw = t * tile_elems + (int64_t)w * WAVE_ELEMS;  // processing-order start of this wave
@@ -171,6 +192,7 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
 #pragma unroll
             for (int j = 0; j < T; ++j) v[j] = blk[REV ? (T - 1 - j) : j];
         }
+        OSZ_STAMP(0);   // stage in: registers -> LDS -> lane blocks (waits for the prefetch)
         if (t + 1 < ntiles) fetch(t + 1);
 
         // valid samples in this lane (prefix of its block)
@@ -218,6 +240,7 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
             // per-lane constants for later (issued early: the load flies meanwhile)
             const double pl0 = S->PL16[l & 15][0], pl1 = S->PL16[l & 15][1];
             const double pl2 = S->PL16[l & 15][2], pl3 = S->PL16[l & 15][3];
+            OSZ_STAMP(1);   // zero-state pass
             // 2a. inclusive scan of end states inside each 16-lane row (DPP)
             double e0 = z0, e1 = z1;
 #define OSZ_SCAN_STEP(K, D)                                   \
@@ -249,7 +272,9 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
                     agg[(aggbuf * NW + w) * 2 + 1] = y1;
                 }
             }
+            OSZ_STAMP(2);   // row scan + row totals + aggregate
             __syncthreads();
+            OSZ_STAMP(3);   // workgroup barrier
             // 2b. wave-level replay (every wave, uniform values)
             double s0 = sst[(parity * kSosMaxSec + s) * 2 + 0];
             double s1 = sst[(parity * kSosMaxSec + s) * 2 + 1];
@@ -280,6 +305,7 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
             const double xr1 = row == 0 ? sw1 : (row == 1 ? x11 : (row == 2 ? x21 : x31));
             double ls0 = fma(pl0, xr0, fma(pl1, xr1, p0));
             double ls1 = fma(pl2, xr0, fma(pl3, xr1, p1));
+            OSZ_STAMP(4);   // wave replay + lane start state
             // 3. homogeneous fix-up, octet by octet: y[8q + r] += row0(A^r) (A^8)^q s
             {
                 double h0 = ls0, h1 = ls1;
@@ -303,6 +329,7 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
                 a.state_out[((int64_t)s * a.nch + c) * 2 + 0] = f0 + e0raw;
                 a.state_out[((int64_t)s * a.nch + c) * 2 + 1] = f1 + e1raw;
             }
+            OSZ_STAMP(5);   // fix-up (the final-state store included)
         }
         parity ^= 1;
 
@@ -326,7 +353,14 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
             }
             wave_lds_fence();
         }
+        OSZ_STAMP(6);   // stage out: lane blocks -> LDS -> HBM stores issued
     }
+#ifdef OSZ_SOS_STAMPS
+    if (l == 0 && g_sos_stamps) {
+        unsigned long long *o = g_sos_stamps + ((size_t)c * NW + w) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = stamp_acc[i];
+    }
+#endif
 }
 
 template <int T, int NW, bool REV, bool GUARD>
