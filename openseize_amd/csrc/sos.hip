@@ -107,15 +107,20 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // GUARD = false: n is a whole number of tiles (the hot kernel: no bounds
 // checks, no predication); GUARD = true handles a ragged remainder.
-template <int T, int NW, bool REV, bool GUARD>
+// LEAN = true: no register prefetch and the HBM<->lane-block transposition is
+// staged through LDS in two halves of 32 rows: ~150 VGPRs and 34 KB of LDS per
+// workgroup, so three to four workgroups share a CU (a single wave issues one
+// float64 op per ~9 cycles; the f64 pipe needs several waves per SIMD).
+template <int T, int NW, bool REV, bool GUARD, bool LEAN = false>
 __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__restrict__ sec,
                                          const int c, const bool zero_init = false,
                                          const int64_t skip_store_tiles = 0) {
     constexpr int ROW = T + kSosPad;
     constexpr int WAVE_ELEMS = 64 * T;
+    constexpr int STAGE_ROWS = LEAN ? 32 : 64;       // rows of the staging tile per wave
     extern __shared__ double lds[];
-    double *tile = lds;                              // NW * 64 * ROW
-    double *agg = tile + NW * 64 * ROW;              // [2][NW][2]
+    double *tile = lds;                              // NW * STAGE_ROWS * ROW
+    double *agg = tile + NW * STAGE_ROWS * ROW;      // [2][NW][2]
     double *sst = agg + 2 * NW * 2;                  // [2][kSosMaxSec][2]
 
     const int w = threadIdx.x >> 6;
@@ -123,7 +128,7 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
     const int64_t n = a.n;
     const double *xrow = a.x + (int64_t)c * a.ldx;
     double *yrow = a.y ? a.y + (int64_t)c * a.ldy : nullptr;
-    double *wl = tile + w * 64 * ROW;                // this wave's private staging rows
+    double *wl = tile + w * STAGE_ROWS * ROW;        // this wave's private staging rows
 
     // ---- initial state of every section -> LDS slot 0
     if (threadIdx.x < a.nsec) {
@@ -151,20 +156,23 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
 
     // HBM -> registers for one tile: consecutive lanes, consecutive samples.
     // Issued one tile ahead so the loads fly while the current tile computes.
-    double nx[T];
+    double nx[LEAN ? 1 : T];
     auto fetch = [&](int64_t t) {
+        if constexpr (LEAN) return;
         const int64_t pw = t * tile_elems + (int64_t)w * WAVE_ELEMS;
         const int64_t mem_base = REV ? (n - pw - WAVE_ELEMS) : pw;
         const bool full = !GUARD || (REV ? (mem_base >= 0) : (pw + WAVE_ELEMS <= n));
-        if (full) {
-            const double *p = xrow + mem_base + l;   // one base, immediate offsets
+        if constexpr (!LEAN) {
+            if (full) {
+                const double *p = xrow + mem_base + l;   // one base, immediate offsets
 #pragma unroll
-            for (int i = 0; i < T; ++i) nx[i] = p[i * 64];
-        } else {
+                for (int i = 0; i < T; ++i) nx[i] = p[i * 64];
+            } else {
 #pragma unroll
-            for (int i = 0; i < T; ++i) {
-                const int64_t g = mem_base + i * 64 + l;
-                nx[i] = (g >= 0 && g < n) ? xrow[g] : 0.0;
+                for (int i = 0; i < T; ++i) {
+                    const int64_t g = mem_base + i * 64 + l;
+                    nx[i] = (g >= 0 && g < n) ? xrow[g] : 0.0;
+                }
             }
         }
     };
@@ -183,14 +191,41 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
         // lane l, step i <-> element m = 64 i + l of the wave window: row m / T, col m % T
         double *stage = wl + (l / T) * ROW + (l % T);
         constexpr int STEP = (64 / T) * ROW;
-#pragma unroll
-        for (int i = 0; i < T; ++i) stage[i * STEP] = nx[i];
-        wave_lds_fence();
         double v[T];
-        {
-            const double *blk = wl + (REV ? (63 - l) : l) * ROW;
+        const int myrow = REV ? (63 - l) : l;        // which row of the wave window is mine
+        if constexpr (!LEAN) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) stage[i * STEP] = nx[i];
+            wave_lds_fence();
+            const double *blk = wl + myrow * ROW;
 #pragma unroll
             for (int j = 0; j < T; ++j) v[j] = blk[REV ? (T - 1 - j) : j];
+        } else {
+            constexpr int HALF = 32 * T;             // samples per half window
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                double tmp[T / 2];
+                if (full) {
+                    const double *p = xrow + mem_base + hh * HALF + l;
+#pragma unroll
+                    for (int i = 0; i < T / 2; ++i) tmp[i] = p[i * 64];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < T / 2; ++i) {
+                        const int64_t g = mem_base + hh * HALF + i * 64 + l;
+                        tmp[i] = (g >= 0 && g < n) ? xrow[g] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < T / 2; ++i) stage[i * STEP] = tmp[i];
+                wave_lds_fence();
+                if ((myrow >> 5) == hh) {
+                    const double *blk = wl + (myrow & 31) * ROW;
+#pragma unroll
+                    for (int j = 0; j < T; ++j) v[j] = blk[REV ? (T - 1 - j) : j];
+                }
+                wave_lds_fence();
+            }
         }
         OSZ_STAMP(0);   // stage in: registers -> LDS -> lane blocks (waits for the prefetch)
         if (t + 1 < ntiles) fetch(t + 1);
@@ -334,7 +369,32 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
         parity ^= 1;
 
         // ---- registers -> LDS rows -> HBM (wave private: no workgroup barrier)
-        if (yrow && t >= skip_store_tiles) {
+        if constexpr (LEAN) {
+            if (yrow && t >= skip_store_tiles) {
+                constexpr int HALF = 32 * T;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    if ((myrow >> 5) == hh) {
+                        double *blk = wl + (myrow & 31) * ROW;
+#pragma unroll
+                        for (int j = 0; j < T; ++j) blk[REV ? (T - 1 - j) : j] = v[j];
+                    }
+                    wave_lds_fence();
+                    if (full) {
+                        double *q = yrow + mem_base + hh * HALF + l;
+#pragma unroll
+                        for (int i = 0; i < T / 2; ++i) q[i * 64] = stage[i * STEP];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < T / 2; ++i) {
+                            const int64_t g = mem_base + hh * HALF + i * 64 + l;
+                            if (g >= 0 && g < n) yrow[g] = stage[i * STEP];
+                        }
+                    }
+                    wave_lds_fence();
+                }
+            }
+        } else if (yrow && t >= skip_store_tiles) {
             double *blk = wl + (REV ? (63 - l) : l) * ROW;
 #pragma unroll
             for (int j = 0; j < T; ++j) blk[REV ? (T - 1 - j) : j] = v[j];
@@ -369,19 +429,15 @@ __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
     sos_body<T, NW, REV, GUARD>(a, sec, blockIdx.x);
 }
 
-// Few channels: a chunk is cut into `nseg` time segments that run as separate
-// workgroups (grid (nch, nseg)).  Segment s > 0 starts from a ZERO state
-// `pre` samples early and discards those outputs; `pre` = the handle's
-// warm_len, the point where the cascade's transition matrix has decayed below
-// 1e-18, so the state it reaches at its first kept sample equals the carried
-// one to float64 (see sos_warmup_len).  Segment 0 starts from the true state,
-// the last segment writes the carried state.  All lengths are whole tiles.
-template <int T, int NW, bool REV>
-__global__ __launch_bounds__(NW * 64) void sos_split_kernel(SosArgs a,
-                                                            const SosSection *__restrict__ sec,
-                                                            int nseg, int64_t seglen,
-                                                            int64_t pre) {
-    const int s = blockIdx.y;
+// Time segments of one pass as separate workgroups.  Segment s > 0 starts from
+// a ZERO state `pre` samples early and discards those outputs; `pre` = the
+// handle's warm_len, the point where the cascade's transition matrix has
+// decayed below 1e-18, so the state it reaches at its first kept sample equals
+// the carried one to float64 (see sos_warmup_len).  Segment 0 starts from the
+// true state, the last segment writes the carried state.  Whole tiles only.
+template <int T, int NW, bool REV, bool LEAN>
+__device__ __forceinline__ void sos_segment(const SosArgs &a, const SosSection *__restrict__ sec,
+                                            int c, int s, int nseg, int64_t seglen, int64_t pre) {
     const int64_t begin = (int64_t)s * seglen;               // processing-order start
     const int64_t len = (s == nseg - 1) ? a.n - begin : seglen;
     const int64_t p = s > 0 ? pre : 0;
@@ -398,7 +454,23 @@ __global__ __launch_bounds__(NW * 64) void sos_split_kernel(SosArgs a,
         if (a.y) b.y = a.y + begin - p;
     }
     if (s != nseg - 1) b.state_out = nullptr;
-    sos_body<T, NW, REV, false>(b, sec, blockIdx.x, s > 0, p / ((int64_t)NW * 64 * T));
+    sos_body<T, NW, REV, false, LEAN>(b, sec, c, s > 0, p / ((int64_t)NW * 64 * T));
+}
+
+// One pass, grid (nch, nseg): fills the chip when there are few channels.
+template <int T, int NW, bool REV>
+__global__ __launch_bounds__(NW * 64) void sos_split_kernel(SosArgs a,
+                                                            const SosSection *__restrict__ sec,
+                                                            int nseg, int64_t seglen,
+                                                            int64_t pre) {
+    sos_segment<T, NW, REV, false>(a, sec, blockIdx.x, blockIdx.y, nseg, seglen, pre);
+}
+
+// Lean variant (see sos_body): <= 168 VGPRs, 34 KB LDS -> three workgroups per CU.
+template <int T, int NW, bool REV>
+__global__ __launch_bounds__(NW * 64, 3) void sos_split_lean_kernel(
+    SosArgs a, const SosSection *__restrict__ sec, int nseg, int64_t seglen, int64_t pre) {
+    sos_segment<T, NW, REV, true>(a, sec, blockIdx.x, blockIdx.y, nseg, seglen, pre);
 }
 
 // Forward pass of one chunk and backward pass of another in ONE launch:
@@ -412,6 +484,19 @@ __global__ __launch_bounds__(NW * 64, 2) void sos_dual_kernel(SosArgs f, SosArgs
         sos_body<T, NW, false, false>(f, sec, blockIdx.x);
     else
         sos_body<T, NW, true, false>(b, sec, blockIdx.x);
+}
+
+// Same with every pass cut into nseg time segments, lean bodies: grid
+// (nch, 2 nseg) -> three workgroups per CU share the float64 pipe.
+template <int T, int NW>
+__global__ __launch_bounds__(NW * 64, 3) void sos_dual_lean_kernel(
+    SosArgs f, SosArgs b, const SosSection *__restrict__ sec, int nseg, int64_t seglen_f,
+    int64_t seglen_b, int64_t pre) {
+    const int pass = blockIdx.y / nseg, s = blockIdx.y % nseg;
+    if (pass == 0)
+        sos_segment<T, NW, false, true>(f, sec, blockIdx.x, s, nseg, seglen_f, pre);
+    else
+        sos_segment<T, NW, true, true>(b, sec, blockIdx.x, s, nseg, seglen_b, pre);
 }
 
 // The constant matrices are powers of the companion matrix A.  For poles close
@@ -566,6 +651,18 @@ static int sos_launch_one(const SosArgs &a, hipStream_t st) {
 // One logical pass = the hot kernel over the whole tiles + a guarded kernel
 // over the ragged remainder; the cascade state travels through `carry`
 // (nsec, nch, 2) between the two launches.
+// lean bodies (no register prefetch, half-tile staging) at three workgroups
+// per CU: default on (measured 3-5 % faster); OSZ_SOS_LEAN=0 selects the
+// prefetching bodies at two workgroups per CU
+static bool sos_lean() {
+    static int lean = -1;
+    if (lean < 0) {
+        const char *e = getenv("OSZ_SOS_LEAN");
+        lean = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return lean == 1;
+}
+
 // whole-tile pass, cut into time segments when there are too few channels to
 // fill the chip (see sos_split_kernel)
 template <int T, int NW, bool REV>
@@ -573,10 +670,10 @@ static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
     const int64_t tile = (int64_t)NW * 64 * T;
     const int64_t ntiles = a.n / tile, pre_tiles = warm_len / tile;
     int64_t nseg = 1;
-    static int target_wgs = 0;   // tuning knob OSZ_SOS_WGS (default 512 = 2 workgroups per CU)
+    static int target_wgs = 0;   // tuning knob OSZ_SOS_WGS (default: 2 or, lean, 3 workgroups per CU)
     if (!target_wgs) {
         const char *e = getenv("OSZ_SOS_WGS");
-        target_wgs = (e && atoi(e) > 0) ? atoi(e) : 512;
+        target_wgs = (e && atoi(e) > 0) ? atoi(e) : (sos_lean() ? 768 : 512);
     }
     if (a.nch < target_wgs && pre_tiles >= 1 && pre_tiles * tile == warm_len) {
         nseg = (target_wgs + a.nch - 1) / a.nch;
@@ -586,14 +683,15 @@ static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
     if (nseg <= 1) return sos_launch_one<T, NW, REV, false>(a, st);
     const int64_t seg_tiles = (ntiles + nseg - 1) / nseg;
     nseg = (ntiles + seg_tiles - 1) / seg_tiles;
-    auto kern = sos_split_kernel<T, NW, REV>;
+    const bool lean = sos_lean();
+    auto kern = lean ? sos_split_lean_kernel<T, NW, REV> : sos_split_kernel<T, NW, REV>;
     static bool attr_set = false;
-    const size_t lds = sizeof(double) * ((size_t)NW * 64 * (T + kSosPad) + 2 * NW * 2 +
-                                         2 * kSosMaxSec * 2);
+    const size_t lds = sizeof(double) * ((size_t)NW * (lean ? 32 : 64) * (T + kSosPad) +
+                                         2 * NW * 2 + 2 * kSosMaxSec * 2);
     if (!attr_set) {
         OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set = true;   // `lean` is fixed for the life of the process
     }
     {
         KernelTimer kt(REV ? (a.y ? "sos_bwd_split" : "sos_warmup") : "sos_fwd_split", st);
@@ -838,6 +936,32 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
     bw.ldx = ldfa;
     bw.ldy = ldy;
     bw.n = na;
+    if (sos_lean() && h->warm_len == tile && (nx / tile) >= 8 && (na / tile) >= 8) {
+        // lean bodies: both passes cut into time segments, 3 workgroups per CU
+        int nseg = (768 + 2 * h->nch - 1) / (2 * h->nch);
+        const int64_t tmin = (nx < na ? nx : na) / tile;
+        if (nseg > tmin / 4) nseg = (int)(tmin / 4);
+        if (nseg >= 2) {
+            const int64_t sf = ((nx / tile + nseg - 1) / nseg) * tile;
+            const int64_t sb = ((na / tile + nseg - 1) / nseg) * tile;
+            auto kern = sos_dual_lean_kernel<32, 4>;
+            static bool attr_set = false;
+            const size_t lds = sizeof(double) * ((size_t)4 * 32 * (32 + kSosPad) + 2 * 4 * 2 +
+                                                 2 * kSosMaxSec * 2);
+            if (!attr_set) {
+                OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            {
+                KernelTimer kt("sos_dual", st);
+                hipLaunchKernelGGL(kern, dim3(h->nch, 2 * nseg), dim3(256), lds, st, fw, bw,
+                                   h->dsec, nseg, sf, sb, h->warm_len);
+            }
+            OSZ_HIP(hipGetLastError());
+            return OSZ_OK;
+        }
+    }
     return sos_launch_dual<32, 4>(fw, bw, st);
 }
 
