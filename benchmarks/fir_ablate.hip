@@ -26,8 +26,11 @@ struct Args {
 
 enum { FULL = 0, NO_GLOBAL = 1, NO_H = 2, NO_TW = 3, NO_OA = 4, NO_LDS = 5, NO_BARRIER = 6, COPY = 7 };
 
+__device__ unsigned long long g_cycles[4];   // [0] sum of per-wave cycles, [1] waves
+
 template <int V>
 __global__ __launch_bounds__(256) void fir_kernel(Args a) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     extern __shared__ double lds[];
     double *pr = lds, *pi = lds + fft::PLANE, *carry = lds + 2 * fft::PLANE;
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y, wm1 = a.wlen - 1;
@@ -139,6 +142,10 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
         }
         if (V != NO_LDS) BAR();
     }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_cycles[0], __builtin_amdgcn_s_memtime() - c0);
+        atomicAdd(&g_cycles[1], 1ull);
+    }
 }
 
 static size_t g_extra_lds = 0;   // pad the allocation to force 1 workgroup per CU
@@ -160,7 +167,12 @@ float run(Args a, int nch, const char *name) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     ms /= 5;
-    printf("%-12s %.3f ms  %s\n", name, ms, hipGetErrorString(hipGetLastError()));
+    unsigned long long hc[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
+    hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_cycles), sizeof(hc));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_cycles), zero, sizeof(zero));
+    const double cyc_per_wave = hc[1] ? (double)hc[0] / hc[1] : 0.0;
+    printf("%-12s %.3f ms  mean wave lifetime %.0f cycles (%.2f us at 2.1 GHz)  %s\n", name, ms,
+           cyc_per_wave, cyc_per_wave / 2100.0, hipGetErrorString(hipGetLastError()));
     return ms;
 }
 

@@ -44,6 +44,16 @@ struct FirArgs {
     double *tails;    // [nch][nruns][wlen-1]
 };
 
+// Runs are balanced: run r owns the block PAIRS [r*npairs/nruns, (r+1)*npairs/nruns),
+// i.e. it starts at block 2*floor(r*npairs/nruns).  (A remainder lumped into the
+// last run makes that workgroup up to twice as long as the others and the
+// whole launch waits for it.)
+__host__ __device__ __forceinline__ int64_t fir_run_start(int64_t r, int64_t nblocks, int nruns) {
+    const int64_t npairs = (nblocks + 1) / 2;
+    const int64_t b = 2 * ((r * npairs) / nruns);
+    return b < nblocks ? b : nblocks;
+}
+
 // NR = rows of 256 samples per block (block length step = 256 NR, chosen by
 // the host as the largest multiple of 256 with step + ntaps - 1 <= 4096).  A
 // pair of two whole blocks past the left cut -- every pair but the ragged last
@@ -64,8 +74,8 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     const double *xr = a.x + (int64_t)c * a.ldx;
     double *yr = a.y + (int64_t)c * a.ldy;
 
-    const int64_t blk0 = (int64_t)run * a.R;
-    const int64_t blk1 = (run == a.nruns - 1) ? a.nblocks : blk0 + a.R;
+    const int64_t blk0 = fir_run_start(run, a.nblocks, a.nruns);
+    const int64_t blk1 = fir_run_start(run + 1, a.nblocks, a.nruns);
 
     for (int i = t; i < wm1; i += 256) carry[i] = 0.0;
     __syncthreads();
@@ -220,7 +230,8 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
 struct SeamArgs {
     double *y;
     int64_t ldy, n, skip;
-    int wlen, step, R, nruns;
+    int wlen, step, nruns;
+    int64_t nblocks;
     const double *tails;      // [nch][nruns][wlen-1]
     const double *state_old;  // [nch][wlen-1]
     double *state_new;        // [nch][wlen-1]
@@ -247,7 +258,7 @@ __global__ void fir_seam_kernel(SeamArgs a) {
         off = 0;
     } else {
         v = a.tails[((int64_t)c * a.nruns + src - 1) * wm1 + i];
-        off = (int64_t)src * a.R * a.step;
+        off = fir_run_start(src, a.nblocks, a.nruns) * a.step;
     }
     const int64_t pos = off + i;
     if (pos < a.n && pos >= a.skip) yr[pos - a.skip] += v;
@@ -412,7 +423,38 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
     if (R > 32) R = 32;
     if (R < 2) R = 2;
     R &= ~1LL;
-    int64_t nruns = nblocks / R;
+    int64_t nruns = (nblocks + R - 1) / R;       // balanced runs of <= R blocks
+    {
+        // whole "rounds" of resident workgroups: with W workgroups on S slots the
+        // launch takes ceil(W / S) rounds, so prefer a run count that wastes
+        // little of the last round (slots = CUs x workgroups per CU by LDS)
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess &&
+                hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cus = prop.multiProcessorCount;
+            if (cus <= 0) cus = 256;
+        }
+        const size_t lds_wg = sizeof(double) * (2 * fft::PLANE + (wm1 > 0 ? wm1 : 1));
+        const int64_t slots = (int64_t)cus * (2 * lds_wg <= 160 * 1024 ? 2 : 1);
+        int64_t best = nruns;
+        double best_waste = 2.0;
+        for (int64_t cand = nruns; cand < nruns + 8; ++cand) {
+            const int64_t w = cand * h->nch, rounds = (w + slots - 1) / slots;
+            const double waste = 1.0 - (double)w / (double)(rounds * slots);
+            if (waste < best_waste - 1e-9) {
+                best_waste = waste;
+                best = cand;
+            }
+        }
+        nruns = best;
+    }
+    // every run must hold at least one whole block (>= ntaps - 1 samples) so that
+    // tails never reach past the run that follows: at most one run per pair of
+    // blocks whose first block is whole
+    if (nruns > nblocks / 2) nruns = nblocks / 2;
     if (nruns < 1) nruns = 1;
     const int64_t need = (int64_t)h->nch * nruns * (wm1 > 0 ? wm1 : 1);
     if (need > h->tails_cap) {
@@ -481,8 +523,8 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
         s.skip = skip;
         s.wlen = pt.ntaps;
         s.step = pt.step;
-        s.R = (int)R;
         s.nruns = (int)nruns;
+        s.nblocks = nblocks;
         s.tails = h->dtails;
         s.state_old = pt.dstate[pt.cur];
         s.state_new = pt.dstate[pt.cur ^ 1];
