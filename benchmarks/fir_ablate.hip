@@ -24,7 +24,7 @@ struct Args {
 
 #define KEEP(v) asm volatile("" ::"v"(v))
 
-enum { FULL = 0, NO_GLOBAL = 1, NO_H = 2, NO_TW = 3, NO_OA = 4, NO_LDS = 5, NO_BARRIER = 6, COPY = 7 };
+enum { FULL = 0, NO_GLOBAL = 1, NO_H = 2, NO_TW = 4, NO_OA = 8, NO_LDS = 16, NO_BARRIER = 32, COPY = 64 };
 
 __device__ unsigned long long g_cycles[4];   // [0] sum of per-wave cycles, [1] waves
 
@@ -36,8 +36,10 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y, wm1 = a.wlen - 1;
     const double *xr = a.x + (int64_t)c * a.ldx;
     double *yr = a.y + (int64_t)c * a.ldy;
-    const int64_t blk0 = (int64_t)run * a.R;
-    const int64_t blk1 = (run == a.nruns - 1) ? a.nblocks : blk0 + a.R;
+    const int64_t npairs = (a.nblocks + 1) / 2;
+    const int64_t blk0 = 2 * (((int64_t)run * npairs) / a.nruns);
+    int64_t blk1 = 2 * (((int64_t)(run + 1) * npairs) / a.nruns);
+    if (blk1 > a.nblocks) blk1 = a.nblocks;
     for (int i = t; i < wm1; i += 256) carry[i] = 0.0;
     __syncthreads();
     fft::Tables tb = a.tb;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int p = 256 * j + t;
-            if (V == NO_GLOBAL) {
+            if (V & NO_GLOBAL) {
                 re[j] = p * 1e-3;
                 im[j] = p * 2e-3;
             } else {
@@ -57,12 +59,12 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
                 im[j] = p < len_b ? xr[start_b + p] : 0.0;
             }
         }
-        if (V != COPY) {
-#define BAR() do { if (V != NO_BARRIER && V != NO_LDS) __syncthreads(); } while (0)
-            if (V == NO_LDS) {
+        if (!(V & COPY)) {
+#define BAR() do { if (!(V & NO_BARRIER) && !(V & NO_LDS)) __syncthreads(); } while (0)
+            if (V & NO_LDS) {
                 fft::fwd16(re, im); fft::fwd16(re, im); fft::fwd16(re, im);
             } else {
-                if (V == NO_TW) {
+                if (V & NO_TW) {
                     fft::fwd16(re, im);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { pr[fft::dr(r) * fft::S1 + t] = re[r]; pi[fft::dr(r) * fft::S1 + t] = im[r]; }
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
                 }
                 BAR();
                 fft::f2_load(t, re, im, pr, pi);
-                if (V == NO_TW) fft::fwd16(re, im); else fft::f2_compute(t, re, im, tb);
+                if (V & NO_TW) fft::fwd16(re, im); else fft::f2_compute(t, re, im, tb);
                 BAR();
                 fft::f2_store(t, re, im, pr, pi);
                 BAR();
@@ -81,17 +83,17 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
             for (int r = 0; r < 16; ++r) {
                 const int k = t + 256 * fft::dr(r);
                 double hr = 0.5, hi = 0.25;
-                if (V != NO_H) { hr = a.H[2 * k]; hi = a.H[2 * k + 1]; }
+                if (!(V & NO_H)) { hr = a.H[2 * k]; hi = a.H[2 * k + 1]; }
                 const double u = re[r], v = im[r];
                 re[r] = u * hr - v * hi;
                 im[r] = u * hi + v * hr;
             }
-            if (V == NO_LDS) {
+            if (V & NO_LDS) {
                 fft::inv16(re, im); fft::inv16(re, im); fft::inv16(re, im);
             } else {
                 fft::i3(t, re, im, pr, pi);
                 BAR();
-                if (V == NO_TW) {
+                if (V & NO_TW) {
                     const int k0 = t & 15, n0 = t >> 4;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { re[r] = pr[n0 * fft::S2 + fft::dr(r) * 16 + k0]; im[r] = pi[n0 * fft::S2 + fft::dr(r) * 16 + k0]; }
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
                 BAR();
                 fft::i2_compute_store(t, re, im, pr, pi);
                 BAR();
-                if (V == NO_TW) {
+                if (V & NO_TW) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { re[r] = pr[fft::dr(r) * fft::S1 + t]; im[r] = pi[fft::dr(r) * fft::S1 + t]; }
                     fft::inv16(re, im);
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
                 }
                 BAR();
             }
-            if (V != NO_OA && V != NO_LDS) {
+            if (!(V & NO_OA) && !(V & NO_LDS)) {
                 double *xb = pr;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int p = 256 * j + t;
-            if (V == NO_GLOBAL) {
+            if (V & NO_GLOBAL) {
                 KEEP(re[j]);
                 KEEP(im[j]);
             } else {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void fir_kernel(Args a) {
                 if (p < len_b) yr[start_b + p] = im[j];
             }
         }
-        if (V != NO_LDS) BAR();
+        if (!(V & NO_LDS)) BAR();
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&g_cycles[0], __builtin_amdgcn_s_memtime() - c0);
@@ -185,7 +187,7 @@ int main() {
     a.nblocks = n / a.step;  // whole blocks only
     a.n = a.nblocks * a.step;
     a.R = 32;
-    a.nruns = (int)(a.nblocks / a.R);
+    a.nruns = (int)((a.nblocks + a.R - 1) / a.R);
     a.ldx = a.ldy = n;
     double *x, *y, *H, *t1, *t2;
     hipMalloc(&x, sizeof(double) * nch * n);
@@ -224,10 +226,19 @@ int main() {
     run<NO_BARRIER>(a, nch, "no_barrier");
     run<NO_LDS>(a, nch, "no_lds");
     run<COPY>(a, nch, "copy_only");
+    printf("-- compute only (no global loads/stores), two workgroups per CU\n");
+    run<NO_GLOBAL | NO_H>(a, nch, "c-no_H");
+    run<NO_GLOBAL | NO_TW>(a, nch, "c-no_tw");
+    run<NO_GLOBAL | NO_H | NO_TW>(a, nch, "c-no_H_tw");
+    run<NO_GLOBAL | NO_OA>(a, nch, "c-no_oa");
+    run<NO_GLOBAL | NO_BARRIER>(a, nch, "c-no_bar");
+    run<NO_GLOBAL | NO_LDS>(a, nch, "c-no_lds");
+    run<NO_GLOBAL | NO_LDS | NO_H | NO_TW>(a, nch, "c-flops");
     g_extra_lds = 20 * 1024;   // 98 KB per workgroup: only one fits per CU
     printf("-- one workgroup per CU\n");
     run<FULL>(a, nch, "full");
     run<NO_GLOBAL>(a, nch, "no_global");
+    run<NO_GLOBAL | NO_LDS | NO_H | NO_TW>(a, nch, "c-flops");
     run<COPY>(a, nch, "copy_only");
     return 0;
 }

@@ -1,0 +1,76 @@
+"""Turn the rocprofv3 outputs of benchmarks/refresh_profiles.sh into the files
+kept under profiles/: the per-kernel duration summary, the mean FETCH_SIZE /
+WRITE_SIZE per kernel (separate --pmc passes) and traffic.json, the HBM bytes
+per launch that bench.py reports as roofline.traffic.
+
+    python benchmarks/summarise_profiles.py gpurun_out/prof rNN
+
+HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE under-counts
+streaming reads by 1/2 on gfx950 (MI355X_MICROARCH.md, HBM section); the factor
+is checked in the same run on checksum_kernel (known 2 GiB read) and
+synth_normal_kernel (known 2 GiB write).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, pattern):
+    hits = sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+    return hits[0] if hits else None
+
+
+def counter_means(path, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    if not path:
+        return acc
+    with open(path, newline="") as fh:
+        for row in csv.DictReader(fh):
+            if row.get("Counter_Name") != counter:
+                continue
+            a = acc[row["Kernel_Name"]]
+            a[0] += 1
+            a[1] += float(row["Counter_Value"])
+    return acc
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+    stats = find(os.path.join(root, "stats"), "*kernel_stats.csv")
+    if stats:
+        with open(stats) as src, open(os.path.join(out, f"{tag}_kernel_stats_bench.csv"), "w") as dst:
+            dst.write(src.read())
+    fetch = counter_means(find(os.path.join(root, "fetch"), "*counter_collection.csv"), "FETCH_SIZE")
+    write = counter_means(find(os.path.join(root, "write"), "*counter_collection.csv"), "WRITE_SIZE")
+    traffic = {}
+    with open(os.path.join(out, f"{tag}_pmc_hbm_traffic.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "launches_fetch", "FETCH_SIZE_KB_mean", "launches_write",
+                    "WRITE_SIZE_KB_mean", "hbm_bytes_per_launch(2*FETCH+WRITE)*1024"])
+        for name in fetch:
+            nf, sf = fetch[name]
+            nw, sw = write.get(name, [0, 0.0])
+            f, wr = sf / max(nf, 1), sw / max(nw, 1)
+            hbm = (2 * f + wr) * 1024
+            w.writerow([name, nf, round(f, 1), nw, round(wr, 1), int(hbm)])
+            # the big launches only (the same kernels run tiny warm-up launches)
+            if "sos_dual" in name and hbm > 1e9:
+                traffic["sos_dual"] = hbm
+            elif "fir_oa_kernel" in name and hbm > 1e9:
+                traffic["fir_oa"] = hbm
+            elif "sos_kernel" in name and "false, false" in name and hbm > 1e9:
+                traffic["sos_fwd"] = hbm
+    traffic["_note"] = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                        "(separate passes), (2*FETCH_SIZE + WRITE_SIZE)*1024; see "
+                        f"{tag}_pmc_hbm_traffic.csv and profiles/README.md for the calibration.")
+    with open(os.path.join(out, "traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -394,5 +394,230 @@ OSZ_HD void i1(int t, double *re, double *im, const Tables &tb, const double *pr
     inv16(re, im);
 }
 
+// ---- cube layout: interleaved complex, in-place exchanges ------------------
+// One array of 4096 complex slots (64 KB, no padding) viewed as a 16x16x16 cube
+//   slot(k0, m, l) = 256 k0 + 16 m + (l ^ k0)
+// and three ownership views, one per pass:
+//   view A  thread (l = n0, m = n1) owns the 16 slots k0 = 0..15   (pass 1)
+//   view B  thread (k0, l = n0)     owns the 16 slots m = n1 | k1  (pass 2)
+//   view C  thread (k0, m = k1)     owns the 16 slots l = n0 | k2  (pass 3)
+// Every pass reads its 16 slots, transforms, and writes the SAME slots back,
+// so the only hazards are between passes: one barrier per exchange (four per
+// forward + inverse) instead of a load / barrier / store sandwich, and the
+// slots a thread reads last (view A, inverse pass 1) are the ones it writes
+// first for the next transform -- no barrier between transforms at all.
+// re and im travel together as 16-byte accesses (ds_read_b128 / ds_write_b128:
+// full LDS rate already at one or two waves per SIMD, MI355X_MICROARCH.md LDS
+// table).  The XOR with k0 makes all three views conflict free for the b128
+// lane groups (read: 16 lanes x 16 B over 64 banks, write: 8 lanes x 16 B
+// over 32 banks): view A lanes walk l (16 distinct columns), views B and C
+// lanes walk k0 (column (l ^ k0), again 16 distinct); checked by brute force
+// over the guide's lane groups in tests/test_fft_host.py.
+namespace cube {
+
+struct alignas(16) C2 {
+    double re, im;
+};
+
+constexpr int SLOTS = 4096;
+
+OSZ_HD int slot_a(int t, int k0) { return 256 * k0 + (t ^ k0); }            // t = 16 m + l
+OSZ_HD int base_b(int t) { return 256 * (t & 15) + ((t >> 4) ^ (t & 15)); } // + 16 m
+OSZ_HD int slot_c(int t, int l) { return 256 * (t & 15) + (t & ~15) + (l ^ (t & 15)); }
+
+OSZ_HD void cmul(double &re, double &im, double wr, double wi) {
+    const double a = re, b = im;
+    re = a * wr - b * wi;
+    im = a * wi + b * wr;
+}
+
+// F1: registers hold x[256 j + t] at register j.  Pass 1, twiddle W4096^(t k0),
+// store view A.
+OSZ_HD void f1(int t, double *re, double *im, const Tables &tb, C2 *L) {
+    double twr[16], twi[16];
+    t1_powers(t, tb, twr, twi);
+    fwd16(re, im);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k0 = dr(r);
+        if (k0 != 0) cmul(re[r], im[r], twr[k0], twi[k0]);
+        L[slot_a(t, k0)] = C2{re[r], im[r]};
+    }
+}
+
+// F2: view B in place: load n1, pass 2, twiddle W256^(n0 k1), store k1.
+OSZ_HD void f2(int t, double *re, double *im, const Tables &tb, C2 *L) {
+    const int n0 = t >> 4, base = base_b(t);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const C2 v = L[base + 16 * j];
+        re[j] = v.re;
+        im[j] = v.im;
+    }
+    fwd16(re, im);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k1 = dr(r);
+        if (k1 != 0) cmul(re[r], im[r], tb.t2[(n0 * 16 + k1) * 2], tb.t2[(n0 * 16 + k1) * 2 + 1]);
+        L[base + 16 * k1] = C2{re[r], im[r]};
+    }
+}
+
+// F3: view C: load n0, pass 3.  Afterwards register r holds X[t + 256 dr(r)].
+OSZ_HD void f3(int t, double *re, double *im, const C2 *L) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const C2 v = L[slot_c(t, j)];
+        re[j] = v.re;
+        im[j] = v.im;
+    }
+    fwd16(re, im);
+}
+
+// I3: registers hold Y[t + 256 dr(r)] at register r.  Inverse pass 3, store
+// view C (the slots F3 read).
+OSZ_HD void i3(int t, double *re, double *im, C2 *L) {
+    inv16(re, im);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) L[slot_c(t, j)] = C2{re[j], im[j]};
+}
+
+// I2: view B in place: load k1 (at register dr(k1)), conj twiddle, inverse
+// pass 2, store n1.
+OSZ_HD void i2(int t, double *re, double *im, const Tables &tb, C2 *L) {
+    const int n0 = t >> 4, base = base_b(t);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k1 = dr(r);
+        const C2 v = L[base + 16 * k1];
+        re[r] = v.re;
+        im[r] = v.im;
+        if (k1 != 0) cmul(re[r], im[r], tb.t2[(n0 * 16 + k1) * 2], -tb.t2[(n0 * 16 + k1) * 2 + 1]);
+    }
+    inv16(re, im);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) L[base + 16 * j] = C2{re[j], im[j]};
+}
+
+// I1: view A: load k0 (at register dr(k0)), conj twiddle, inverse pass 1.
+// Afterwards register j holds y[256 j + t] (times 4096).
+OSZ_HD void i1(int t, double *re, double *im, const Tables &tb, const C2 *L) {
+    double twr[16], twi[16];
+    t1_powers(t, tb, twr, twi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k0 = dr(r);
+        const C2 v = L[slot_a(t, k0)];
+        re[r] = v.re;
+        im[r] = v.im;
+        if (k0 != 0) cmul(re[r], im[r], twr[k0], -twi[k0]);
+    }
+    inv16(re, im);
+}
+
+// ---- twiddles off the vector-memory path -----------------------------------
+// A wave's global loads return in order, so a twiddle load (an L2 hit) issued
+// after the sample loads of an HBM stream inherits their latency.  Kernels
+// that loop over many transforms keep, per thread, the powers {1, 2, 4, 8} of
+// its two twiddle bases resident (W4096^t for pass 1, W256^n0 for pass 2:
+// 32 registers, exact table values) and apply W^k, k = b + 4a, as the product
+// W^b (W^4)^a with W^3 = W W^2 and W^12 = W^4 W^8 formed on the spot: 26
+// complex multiplies per pass like the table version (15 + 11 to expand the
+// powers), but only 6 twiddles live instead of 15.  After fwd16 (and before
+// inv16) register r holds k = dr(r) = (r >> 2) + 4 (r & 3): b = r >> 2,
+// a = r & 3.
+struct TwPow {
+    double r[4], i[4];   // base^{1,2,4,8}
+};
+
+OSZ_HD void tw_load(int t, const Tables &tb, TwPow &w1, TwPow &w2) {
+    const int n0 = t >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = 1 << q;
+        w1.r[q] = tb.t1[(k * 256 + t) * 2];
+        w1.i[q] = tb.t1[(k * 256 + t) * 2 + 1];
+        w2.r[q] = tb.t2[(n0 * 16 + k) * 2];
+        w2.i[q] = tb.t2[(n0 * 16 + k) * 2 + 1];
+    }
+}
+
+// (a + ib)(wr - i wi): conjugate multiply without negating the twiddle first
+OSZ_HD void cmulc(double &re, double &im, double wr, double wi) {
+    const double a = re, b = im;
+    re = a * wr + b * wi;
+    im = b * wr - a * wi;
+}
+
+template <bool CONJ>
+OSZ_HD void tw_mul(double *re, double *im, const TwPow &w) {
+    double br[4], bi[4], ar[4], ai[4];   // W^b, (W^4)^a
+    br[1] = w.r[0]; bi[1] = w.i[0];
+    br[2] = w.r[1]; bi[2] = w.i[1];
+    ar[1] = w.r[2]; ai[1] = w.i[2];
+    ar[2] = w.r[3]; ai[2] = w.i[3];
+    br[3] = br[1] * br[2] - bi[1] * bi[2]; bi[3] = br[1] * bi[2] + bi[1] * br[2];
+    ar[3] = ar[1] * ar[2] - ai[1] * ai[2]; ai[3] = ar[1] * ai[2] + ai[1] * ar[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int b = r >> 2, a = r & 3;
+        if (CONJ) {
+            if (b != 0) cmulc(re[r], im[r], br[b], bi[b]);
+            if (a != 0) cmulc(re[r], im[r], ar[a], ai[a]);
+        } else {
+            if (b != 0) cmul(re[r], im[r], br[b], bi[b]);
+            if (a != 0) cmul(re[r], im[r], ar[a], ai[a]);
+        }
+    }
+}
+
+OSZ_HD void f1(int t, double *re, double *im, const TwPow &w1, C2 *L) {
+    fwd16(re, im);
+    tw_mul<false>(re, im, w1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L[slot_a(t, dr(r))] = C2{re[r], im[r]};
+}
+
+OSZ_HD void f2(int t, double *re, double *im, const TwPow &w2, C2 *L) {
+    const int base = base_b(t);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const C2 v = L[base + 16 * j];
+        re[j] = v.re;
+        im[j] = v.im;
+    }
+    fwd16(re, im);
+    tw_mul<false>(re, im, w2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L[base + 16 * dr(r)] = C2{re[r], im[r]};
+}
+
+OSZ_HD void i2(int t, double *re, double *im, const TwPow &w2, C2 *L) {
+    const int base = base_b(t);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const C2 v = L[base + 16 * dr(r)];
+        re[r] = v.re;
+        im[r] = v.im;
+    }
+    tw_mul<true>(re, im, w2);
+    inv16(re, im);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) L[base + 16 * j] = C2{re[j], im[j]};
+}
+
+OSZ_HD void i1(int t, double *re, double *im, const TwPow &w1, const C2 *L) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const C2 v = L[slot_a(t, dr(r))];
+        re[r] = v.re;
+        im[r] = v.im;
+    }
+    tw_mul<true>(re, im, w1);
+    inv16(re, im);
+}
+
+}  // namespace cube
+
 }  // namespace fft
 }  // namespace osz

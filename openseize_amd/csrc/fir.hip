@@ -223,6 +223,219 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     for (int i = t; i < wm1; i += 256) tl[i] = carry[i];
 }
 
+// The same run of blocks on the cube layout of fft4096.h (interleaved complex,
+// in-place exchanges, 64 KB): four barriers per pair of blocks, 16-byte LDS
+// accesses, and an overlap that never leaves the registers: with whole blocks
+// of 256 NR samples, sample p = 256 j + t of a's tail (register row j + NR)
+// meets b's head at register row j of the SAME thread, and b's tail meets the
+// next pair's a the same way, so the carried tail is cr[j], 16 - NR doubles
+// per thread.  Ragged pairs (the first one of a push with a left cut, the
+// last one, every pair of a partitioned filter) pass their tails through LDS,
+// over the idle cube; they run in their own loops before and after the
+// stretch of whole pairs so that their predicated code does not weigh on the
+// register allocation of the hot loop.
+//   TW   1: twiddle powers resident in registers, 0: loaded from the tables
+//   HPRE 1: filter spectrum requested before the second barrier
+//   XPRE 1: the NEXT pair's samples requested after the third barrier (the
+//           spectrum registers are dead by then) and arrive behind the
+//           inverse passes, instead of at the top of the loop with nothing to
+//           hide the HBM latency behind
+template <int NR, int TW, int HPRE, int XPRE>
+struct FirPair {
+    using C2 = fft::cube::C2;
+    static constexpr int NT_ = 16 - NR;   // register rows of the tail (wm1 <= 256 NT_)
+
+    const FirArgs &a;
+    const int t, wm1;
+    const double *xr;
+    double *yr;
+    const int64_t blk1;
+    C2 *L;
+    fft::cube::TwPow tw1, tw2;
+    double cr[NT_];
+    double xa[XPRE ? NR : 1], xb[XPRE ? NR : 1];
+
+    __device__ __forceinline__ bool whole(int64_t blk) const {
+        return blk + 1 < blk1 && (blk + 2) * a.step <= a.n && blk * a.step >= a.skip && !a.accum;
+    }
+
+    __device__ __forceinline__ void request(int64_t blk) {
+        const double *pa = xr + blk * a.step + t;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            xa[XPRE ? j : 0] = pa[256 * j];
+            xb[XPRE ? j : 0] = pa[256 * (j + NR)];
+        }
+    }
+
+    // forward transform, filter, inverse transform of the pair in re/im
+    template <bool FAST>
+    __device__ __forceinline__ void transform(double *re, double *im, int64_t blk) {
+        // LDS slot numbers are recomputed per pair from an opaque copy of the
+        // thread index: hoisted out of the loop they would pin 33 registers
+        int t = this->t;
+        asm volatile("" : "+v"(t));
+        if (TW == 1) fft::cube::f1(t, re, im, tw1, L); else fft::cube::f1(t, re, im, a.tb, L);
+        __syncthreads();
+        if (TW == 1) fft::cube::f2(t, re, im, tw2, L); else fft::cube::f2(t, re, im, a.tb, L);
+        double hr[16], hi[16];
+        if (HPRE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = t + 256 * fft::dr(r);
+                hr[r] = a.H[2 * k];
+                hi[r] = a.H[2 * k + 1];
+            }
+        }
+        __syncthreads();
+        fft::cube::f3(t, re, im, L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (HPRE) {
+                fft::cube::cmul(re[r], im[r], hr[r], hi[r]);
+            } else {
+                const int k = t + 256 * fft::dr(r);
+                fft::cube::cmul(re[r], im[r], a.H[2 * k], a.H[2 * k + 1]);
+            }
+        }
+        fft::cube::i3(t, re, im, L);
+        __syncthreads();
+        if (FAST && XPRE && whole(blk + 2)) request(blk + 2);
+        if (TW == 1) fft::cube::i2(t, re, im, tw2, L); else fft::cube::i2(t, re, im, a.tb, L);
+        __syncthreads();
+        if (TW == 1) fft::cube::i1(t, re, im, tw1, L); else fft::cube::i1(t, re, im, a.tb, L);
+    }
+
+    // a pair of whole blocks: no predication anywhere
+    __device__ __forceinline__ void fast_pair(int64_t blk) {
+        const int64_t start_a = blk * a.step;
+        double re[16], im[16];
+        if (XPRE) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = j < NR ? xa[j < NR ? j : 0] : 0.0;
+                im[j] = j < NR ? xb[j < NR ? j : 0] : 0.0;
+            }
+        } else {
+            const double *pa = xr + start_a + t;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = j < NR ? pa[256 * j] : 0.0;
+                im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
+            }
+        }
+        transform<true>(re, im, blk);
+        // re[j] = a[256 j + t], im[j] = b[256 j + t]
+#pragma unroll
+        for (int j = 0; j < NT_; ++j) {
+            const int p = 256 * j + t;
+            if (p < wm1) {
+                re[j] += cr[j];
+                im[j] += re[j + NR];
+                cr[j] = im[j + NR];
+            }
+        }
+        double *qa = yr + (start_a - a.skip) + t;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            qa[256 * j] = re[j];
+            qa[256 * (j + NR)] = im[j];
+        }
+    }
+
+    // any pair: ragged lengths, left cut, accumulate
+    __device__ __forceinline__ void any_pair(int64_t blk) {
+        double *scratch = reinterpret_cast<double *>(L);   // a's tail,
+        double *carry = scratch + 2048;                    // b's tail (<= 2048 doubles each)
+        const int64_t start_a = blk * a.step;
+        const int64_t rem_a = a.n - start_a;
+        const int len_a = rem_a < a.step ? (int)rem_a : a.step;
+        const int64_t start_b = start_a + len_a;
+        int len_b = 0;
+        if (blk + 1 < blk1) {
+            const int64_t rem_b = a.n - start_b;
+            len_b = rem_b < a.step ? (int)rem_b : a.step;
+        }
+        double re[16], im[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int p = 256 * j + t;
+            re[j] = p < len_a ? xr[start_a + p] : 0.0;
+            im[j] = p < len_b ? xr[start_b + p] : 0.0;
+        }
+        transform<false>(re, im, blk);
+        __syncthreads();   // every thread is done reading the cube
+        const int ja0 = len_a >> 8, ja1 = (len_a + wm1 + 255) >> 8;
+        const int jb0 = len_b >> 8, jb1 = (len_b + wm1 + 255) >> 8;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int p = 256 * j + t;
+            if (j < NT_) {
+                if (p < wm1) re[j] += cr[j < NT_ ? j : 0];
+            }
+            if (j >= ja0 && j < ja1) {
+                const int q = p - len_a;
+                if (q >= 0 && q < wm1) scratch[q] = re[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int p = 256 * j + t;
+            if (j < NT_) {
+                if (p < wm1) im[j] += scratch[p];
+            }
+            if (j >= jb0 && j < jb1) {
+                const int q = p - len_b;
+                if (q >= 0 && q < wm1) carry[q] = im[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int p = 256 * j + t;
+            const int64_t oa = start_a + p - a.skip;
+            if (p < len_a && oa >= 0) yr[oa] = a.accum ? yr[oa] + re[j] : re[j];
+            const int64_t ob = start_b + p - a.skip;
+            if (p < len_b && ob >= 0) yr[ob] = a.accum ? yr[ob] + im[j] : im[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT_; ++j) {
+            const int p = 256 * j + t;
+            cr[j] = p < wm1 ? carry[p] : 0.0;
+        }
+        __syncthreads();   // before the next transform overwrites the cube
+    }
+};
+
+template <int NR, int TW = 1, int HPRE = 0, int XPRE = 0>
+__global__ __launch_bounds__(256, 2) void fir_oa_cube_kernel(FirArgs a) {
+    extern __shared__ fft::cube::C2 cube_lds[];
+    const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
+    const int64_t blk0 = fir_run_start(run, a.nblocks, a.nruns);
+    FirPair<NR, TW, HPRE, XPRE> P{a, t, a.wlen - 1, a.x + (int64_t)c * a.ldx,
+                                  a.y + (int64_t)c * a.ldy,
+                                  fir_run_start(run + 1, a.nblocks, a.nruns), cube_lds};
+    if (TW == 1) fft::cube::tw_load(t, a.tb, P.tw1, P.tw2);
+#pragma unroll
+    for (int j = 0; j < 16 - NR; ++j) P.cr[j] = 0.0;
+
+    int64_t blk = blk0;
+    for (; blk < P.blk1 && !P.whole(blk); blk += 2) P.any_pair(blk);
+    if (blk < P.blk1) {
+        if (XPRE) P.request(blk);
+        for (; blk < P.blk1 && P.whole(blk); blk += 2) P.fast_pair(blk);
+    }
+    for (; blk < P.blk1; blk += 2) P.any_pair(blk);
+
+    double *tl = a.tails + ((int64_t)c * a.nruns + run) * P.wm1;
+#pragma unroll
+    for (int j = 0; j < 16 - NR; ++j) {
+        const int p = 256 * j + t;
+        if (p < P.wm1) tl[p] = P.cr[j];
+    }
+}
+
 // Adds every run's published tail into the head of the next run, the carried
 // state of the previous push into the head of this push, and forms the new
 // carried state.  Host guarantees that, when nruns > 1, every run is at least
@@ -413,6 +626,16 @@ static int fir_build_part(FirPart &pt, const double *taps, int ntaps, int nch) {
     return OSZ_OK;
 }
 
+// OSZ_FIR_CUBE=0 selects the older plane-layout kernel (kept for A/B runs)
+static bool fir_use_cube() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("OSZ_FIR_CUBE");
+        v = !(e && atoi(e) == 0);
+    }
+    return v != 0;
+}
+
 // one overlap-add stream: main kernel + seam kernel
 static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx, int64_t n,
                          double *y, int64_t ldy, int64_t skip, int accum, hipStream_t st) {
@@ -437,7 +660,8 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
                 cus = prop.multiProcessorCount;
             if (cus <= 0) cus = 256;
         }
-        const size_t lds_wg = sizeof(double) * (2 * fft::PLANE + (wm1 > 0 ? wm1 : 1));
+        const size_t lds_wg = fir_use_cube() ? sizeof(fft::cube::C2) * fft::cube::SLOTS
+                                             : sizeof(double) * (2 * fft::PLANE + (wm1 > 0 ? wm1 : 1));
         const int64_t slots = (int64_t)cus * (2 * lds_wg <= 160 * 1024 ? 2 : 1);
         int64_t best = nruns;
         double best_waste = 2.0;
@@ -511,8 +735,26 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             attr_set[pow_tw ? 1 : 0][nr - 8] = true;
         }
+        const bool use_cube = fir_use_cube();
         KernelTimer kt("fir_oa", st);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nruns, h->nch), dim3(256), lds_used, st, a);
+        if (use_cube) {
+            static const kern_t ckerns[8] = {
+                fir_oa_cube_kernel<8>, fir_oa_cube_kernel<9>, fir_oa_cube_kernel<10>,
+                fir_oa_cube_kernel<11>, fir_oa_cube_kernel<12>, fir_oa_cube_kernel<13>,
+                fir_oa_cube_kernel<14>, fir_oa_cube_kernel<15>};
+            static bool cattr[8] = {};
+            kern_t ck = ckerns[nr - 8];
+            if (!cattr[nr - 8]) {
+                const size_t lds_max = sizeof(fft::cube::C2) * fft::cube::SLOTS;
+                OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ck),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+                cattr[nr - 8] = true;
+            }
+            const size_t lds_cube = sizeof(fft::cube::C2) * fft::cube::SLOTS;
+            hipLaunchKernelGGL(ck, dim3((unsigned)nruns, h->nch), dim3(256), lds_cube, st, a);
+        } else {
+            hipLaunchKernelGGL(kern, dim3((unsigned)nruns, h->nch), dim3(256), lds_used, st, a);
+        }
     }
     OSZ_HIP(hipGetLastError());
     if (wm1 > 0) {

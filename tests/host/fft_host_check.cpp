@@ -112,6 +112,66 @@ int main() {
         }
     printf("resident-twiddle round trip max abs err %.3e\n", werr);
     bad |= werr > 1e-12;
+    // cube layout (interleaved complex, in-place exchanges): same transform
+    {
+        std::vector<cube::C2> L(cube::SLOTS);
+        std::vector<double> fr(NT * 16), fi(NT * 16);
+        for (int t = 0; t < NT; ++t)
+            for (int j = 0; j < 16; ++j) {
+                re[t * 16 + j] = x[256 * j + t].real();
+                im[t * 16 + j] = x[256 * j + t].imag();
+            }
+        // reference spectrum: the plane-layout forward transform checked above
+        for (int t = 0; t < NT; ++t) f1(t, &re[t * 16], &im[t * 16], tb, pr.data(), pi.data());
+        for (int t = 0; t < NT; ++t) {
+            f2_load(t, &re[t * 16], &im[t * 16], pr.data(), pi.data());
+            f2_compute(t, &re[t * 16], &im[t * 16], tb);
+        }
+        for (int t = 0; t < NT; ++t) f2_store(t, &re[t * 16], &im[t * 16], pr.data(), pi.data());
+        for (int t = 0; t < NT; ++t) f3(t, &re[t * 16], &im[t * 16], pr.data(), pi.data());
+        fr = re;
+        fi = im;
+        for (int t = 0; t < NT; ++t)
+            for (int j = 0; j < 16; ++j) {
+                re[t * 16 + j] = x[256 * j + t].real();
+                im[t * 16 + j] = x[256 * j + t].imag();
+            }
+        // every slot must be owned exactly once in each view
+        std::vector<int> seen(cube::SLOTS);
+        int own_bad = 0;
+        for (int view = 0; view < 3; ++view) {
+            std::fill(seen.begin(), seen.end(), 0);
+            for (int t = 0; t < NT; ++t)
+                for (int j = 0; j < 16; ++j) {
+                    const int s = view == 0 ? cube::slot_a(t, j)
+                                : view == 1 ? cube::base_b(t) + 16 * j : cube::slot_c(t, j);
+                    if (s < 0 || s >= cube::SLOTS) { own_bad = 1; continue; }
+                    seen[s]++;
+                }
+            for (int s = 0; s < cube::SLOTS; ++s) own_bad |= seen[s] != 1;
+        }
+        printf("cube views are bijections: %s\n", own_bad ? "no" : "yes");
+        bad |= own_bad;
+        for (int t = 0; t < NT; ++t) cube::f1(t, &re[t * 16], &im[t * 16], tb, L.data());
+        for (int t = 0; t < NT; ++t) cube::f2(t, &re[t * 16], &im[t * 16], tb, L.data());
+        for (int t = 0; t < NT; ++t) cube::f3(t, &re[t * 16], &im[t * 16], L.data());
+        double cerr = 0;
+        for (size_t i = 0; i < re.size(); ++i)
+            cerr = fmax(cerr, fmax(fabs(re[i] - fr[i]), fabs(im[i] - fi[i])));
+        printf("cube forward vs plane forward max abs diff %.3e\n", cerr);
+        bad |= cerr > 1e-12 * maxmag;
+        for (int t = 0; t < NT; ++t) cube::i3(t, &re[t * 16], &im[t * 16], L.data());
+        for (int t = 0; t < NT; ++t) cube::i2(t, &re[t * 16], &im[t * 16], tb, L.data());
+        for (int t = 0; t < NT; ++t) cube::i1(t, &re[t * 16], &im[t * 16], tb, L.data());
+        double rerr = 0;
+        for (int t = 0; t < NT; ++t)
+            for (int j = 0; j < 16; ++j) {
+                rerr = fmax(rerr, fabs(re[t * 16 + j] / N - x[256 * j + t].real()));
+                rerr = fmax(rerr, fabs(im[t * 16 + j] / N - x[256 * j + t].imag()));
+            }
+        printf("cube round trip max abs err %.3e\n", rerr);
+        bad |= rerr > 1e-12;
+    }
     printf(bad ? "FAIL\n" : "OK\n");
     return bad;
 }
