@@ -1,4 +1,5 @@
-// fir_ablate.hip -- ablation study of the overlap-add FIR kernel (not part of
+// fir_ablate.hip -- ablation study of the FIRST overlap-add FIR kernel (plane LDS
+// layout, benchmarks/fft4096_planes.h); its findings led to the cube layout (not part of
 // the library).  Variants of the pair loop with one cost centre removed each;
 // outputs are wrong by construction, only the timings matter.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 benchmarks/fir_ablate.hip -o /tmp/fir_ablate && /tmp/fir_ablate
@@ -8,7 +9,7 @@
 #include <cstdio>
 #include <vector>
 
-#include "../openseize_amd/csrc/fft4096.h"
+#include "fft4096_planes.h"
 
 using namespace osz;
 

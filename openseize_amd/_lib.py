@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libosz_hip.so")
+# OSZ_HIP_LIB points the binding at another build of the same C ABI
+LIB_PATH = os.environ.get("OSZ_HIP_LIB") or os.path.join(_HERE, "lib", "libosz_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 OSZ_OK = 0

@@ -16,19 +16,12 @@
 // The inverse runs the same passes backwards with conjugated twiddles
 // (1/4096 is folded into the caller's spectrum).
 //
-// LDS: separate re/im planes of doubles.  Exchange 1 is a 16x16 transpose
-// between lanes (n0 fast) and lanes (k0 fast):
-//   slot1 = k0*272 + n1*16 + ((n0 + k0) & 15)
-// the rotation by k0 keeps BOTH sides conflict free under both banking rules
-// the compiler may pick (32-lane/64-bank ds_read_b64, 16-lane/32-bank
-// ds_read2_b64 / ds_write*): writers touch 16 rotated-consecutive doubles,
-// readers hit column (n0 + k0) & 15 of row k0, all distinct, and the two n0
-// rows of a 32-lane half differ in 16*(k0 & 1).  Exchange 2,
-//   slot2 = n0*272 + k1*16 + k0,
-// is lane-contiguous on both sides (rows n0 and n0+1 are 16 mod 32 apart).
+// LDS: one array of 4096 interleaved complex slots (64 KB), the "cube" below:
+// every pass reads its 16 slots, transforms and writes the SAME slots back,
+// so an exchange costs one barrier, and re/im travel as 16-byte accesses.
 //
-// The phase functions are __host__ __device__ so tests/fft_host_check.cpp can
-// replay the 256 threads on the CPU and pin the index math without a GPU.
+// The phase functions are __host__ __device__ so tests/host/fft_host_check.cpp
+// can replay the 256 threads on the CPU and pin the index math without a GPU.
 #pragma once
 
 #if defined(__HIPCC__)
@@ -43,9 +36,6 @@ namespace fft {
 
 constexpr int N = 4096;
 constexpr int NT = 256;          // threads per transform
-constexpr int S1 = 272;          // exchange-1 row stride (doubles); columns rotated by k0
-constexpr int S2 = 272;          // exchange-2 row stride (doubles), = 16 mod 32
-constexpr int PLANE = 16 * S2;   // doubles per plane (>= 16*S1)
 
 // after fwd16 register r holds logical index dr(r); inv16 expects the same
 OSZ_HD constexpr int dr(int r) { return (r >> 2) | ((r & 3) << 2); }
@@ -132,268 +122,6 @@ struct Tables {
     const double *t2;  // [16][16][2]   W256^(n0 k1)
 };
 
-// Pass-1 twiddles W4096^(t k0), k0 = 1..15, for this thread: only the four
-// power-of-two ones are loaded (64 B instead of 240 B of L2 traffic per
-// thread and pass); the others are products of at most three of them.
-OSZ_HD void t1_powers(int t, const Tables &tb, double *wr, double *wi) {
-#define OSZ_LD(K) wr[K] = tb.t1[((K) * 256 + t) * 2]; wi[K] = tb.t1[((K) * 256 + t) * 2 + 1];
-#define OSZ_MUL(C, A, B) wr[C] = wr[A] * wr[B] - wi[A] * wi[B]; wi[C] = wr[A] * wi[B] + wi[A] * wr[B];
-    OSZ_LD(1) OSZ_LD(2) OSZ_LD(4) OSZ_LD(8)
-    OSZ_MUL(3, 1, 2) OSZ_MUL(5, 1, 4) OSZ_MUL(6, 2, 4) OSZ_MUL(7, 3, 4)
-    OSZ_MUL(9, 1, 8) OSZ_MUL(10, 2, 8) OSZ_MUL(11, 3, 8) OSZ_MUL(12, 4, 8)
-    OSZ_MUL(13, 5, 8) OSZ_MUL(14, 6, 8) OSZ_MUL(15, 7, 8)
-#undef OSZ_LD
-#undef OSZ_MUL
-}
-
-// ---- twiddles kept resident in registers ---------------------------------
-// Both twiddle sets a thread ever needs are powers of ONE complex number each:
-// T1[k0][t] = (W4096^t)^k0 and T2[n0][k1] = (W256^n0)^k1.  A kernel that loops
-// over many transforms loads the powers 1, 2, 4, 8 of both once (32 VGPRs,
-// exact table values) and rebuilds the other eleven with <= 3 complex
-// multiplies each time: no table load sits on the per-transform critical path.
-struct TwBase {
-    double r1[4], i1[4];   // W4096^(t * {1,2,4,8})
-    double r2[4], i2[4];   // W256^(n0 * {1,2,4,8}),  n0 = t >> 4
-};
-
-OSZ_HD void tw_load_base(int t, const Tables &tb, TwBase &b) {
-    const int n0 = t >> 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = 1 << q;
-        b.r1[q] = tb.t1[(k * 256 + t) * 2];
-        b.i1[q] = tb.t1[(k * 256 + t) * 2 + 1];
-        b.r2[q] = tb.t2[(n0 * 16 + k) * 2];
-        b.i2[q] = tb.t2[(n0 * 16 + k) * 2 + 1];
-    }
-}
-
-// wr/wi[k] = base^k for k = 1..15 from the powers 1, 2, 4, 8
-OSZ_HD void tw_expand(const double *br, const double *bi, double *wr, double *wi) {
-#define OSZ_MUL(C, A, B) wr[C] = wr[A] * wr[B] - wi[A] * wi[B]; wi[C] = wr[A] * wi[B] + wi[A] * wr[B];
-    wr[1] = br[0]; wi[1] = bi[0]; wr[2] = br[1]; wi[2] = bi[1];
-    wr[4] = br[2]; wi[4] = bi[2]; wr[8] = br[3]; wi[8] = bi[3];
-    OSZ_MUL(3, 1, 2) OSZ_MUL(5, 1, 4) OSZ_MUL(6, 2, 4) OSZ_MUL(7, 3, 4)
-    OSZ_MUL(9, 1, 8) OSZ_MUL(10, 2, 8) OSZ_MUL(11, 3, 8) OSZ_MUL(12, 4, 8)
-    OSZ_MUL(13, 5, 8) OSZ_MUL(14, 6, 8) OSZ_MUL(15, 7, 8)
-#undef OSZ_MUL
-}
-
-// in-register twiddle multiply of the radix-16 outputs: register r holds
-// logical index dr(r); CONJ for the inverse passes
-template <bool CONJ>
-OSZ_HD void tw_apply(double *re, double *im, const double *wr, const double *wi) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k = dr(r);
-        if (k != 0) {
-            const double a = re[r], b = im[r], c = wr[k], d = CONJ ? -wi[k] : wi[k];
-            re[r] = a * c - b * d;
-            im[r] = a * d + b * c;
-        }
-    }
-}
-
-// Resident-twiddle versions of the phases (same data movement as below).
-OSZ_HD void f1_w(int t, double *re, double *im, const TwBase &b, double *pr, double *pi) {
-    double wr[16], wi[16];
-    tw_expand(b.r1, b.i1, wr, wi);
-    fwd16(re, im);
-    tw_apply<false>(re, im, wr, wi);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int slot = dr(r) * S1 + (t & ~15) + ((t + dr(r)) & 15);
-        pr[slot] = re[r];
-        pi[slot] = im[r];
-    }
-}
-
-OSZ_HD void f2_compute_w(double *re, double *im, const TwBase &b) {
-    double wr[16], wi[16];
-    tw_expand(b.r2, b.i2, wr, wi);
-    fwd16(re, im);
-    tw_apply<false>(re, im, wr, wi);
-}
-
-OSZ_HD void i2_load_w(int t, double *re, double *im, const TwBase &b, const double *pr,
-                      const double *pi) {
-    const int k0 = t & 15, n0 = t >> 4;
-    double wr[16], wi[16];
-    tw_expand(b.r2, b.i2, wr, wi);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        re[r] = pr[n0 * S2 + dr(r) * 16 + k0];
-        im[r] = pi[n0 * S2 + dr(r) * 16 + k0];
-    }
-    tw_apply<true>(re, im, wr, wi);
-}
-
-OSZ_HD void i1_w(int t, double *re, double *im, const TwBase &b, const double *pr,
-                 const double *pi) {
-    double wr[16], wi[16];
-    tw_expand(b.r1, b.i1, wr, wi);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int slot = dr(r) * S1 + (t & ~15) + ((t + dr(r)) & 15);
-        re[r] = pr[slot];
-        im[r] = pi[slot];
-    }
-    tw_apply<true>(re, im, wr, wi);
-    inv16(re, im);
-}
-
-// ---- forward phases ----------------------------------------------------
-// F1: registers hold x[256 j + t] at register j (layout A).  Pass 1, twiddle,
-// store to exchange 1.
-template <bool POW = true>
-OSZ_HD void f1(int t, double *re, double *im, const Tables &tb, double *pr, double *pi) {
-    double twr[16], twi[16];
-    if constexpr (POW) {
-        t1_powers(t, tb, twr, twi);
-    } else {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            twr[k] = tb.t1[(k * 256 + t) * 2];
-            twi[k] = tb.t1[(k * 256 + t) * 2 + 1];
-        }
-    }
-    fwd16(re, im);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k0 = dr(r);
-        if (k0 != 0) {
-            const double wr = twr[k0], wi = twi[k0];
-            const double a = re[r], b = im[r];
-            re[r] = a * wr - b * wi;
-            im[r] = a * wi + b * wr;
-        }
-        const int slot = k0 * S1 + (t & ~15) + ((t + k0) & 15);
-        pr[slot] = re[r];
-        pi[slot] = im[r];
-    }
-}
-
-// F2: load layout B (register j = n1), pass 2, twiddle, (caller barriers), store exchange 2.
-OSZ_HD void f2_load(int t, double *re, double *im, const double *pr, const double *pi) {
-    const int k0 = t & 15, n0 = t >> 4;
-    const int base = k0 * S1 + ((n0 + k0) & 15);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        re[j] = pr[base + j * 16];
-        im[j] = pi[base + j * 16];
-    }
-}
-
-OSZ_HD void f2_compute(int t, double *re, double *im, const Tables &tb) {
-    const int n0 = t >> 4;
-    fwd16(re, im);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k1 = dr(r);
-        if (k1 != 0) {
-            const double wr = tb.t2[(n0 * 16 + k1) * 2], wi = tb.t2[(n0 * 16 + k1) * 2 + 1];
-            const double a = re[r], b = im[r];
-            re[r] = a * wr - b * wi;
-            im[r] = a * wi + b * wr;
-        }
-    }
-}
-
-OSZ_HD void f2_store(int t, const double *re, const double *im, double *pr, double *pi) {
-    const int k0 = t & 15, n0 = t >> 4;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k1 = dr(r);
-        pr[n0 * S2 + k1 * 16 + k0] = re[r];
-        pi[n0 * S2 + k1 * 16 + k0] = im[r];
-    }
-}
-
-// F3: load layout C (register j = n0), pass 3.  Afterwards register r holds
-// X[t + 256 dr(r)].
-OSZ_HD void f3(int t, double *re, double *im, const double *pr, const double *pi) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        re[j] = pr[j * S2 + t];
-        im[j] = pi[j * S2 + t];
-    }
-    fwd16(re, im);
-}
-
-// ---- inverse phases ----------------------------------------------------
-// I3: registers hold Y[t + 256 dr(r)] at register r.  Inverse pass 3, store.
-OSZ_HD void i3(int t, double *re, double *im, double *pr, double *pi) {
-    inv16(re, im);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        pr[j * S2 + t] = re[j];
-        pi[j * S2 + t] = im[j];
-    }
-}
-
-// I2: load layout B with logical k1 at register dr(k1), conj twiddle, inverse pass 2.
-OSZ_HD void i2_load(int t, double *re, double *im, const Tables &tb, const double *pr,
-                    const double *pi) {
-    const int k0 = t & 15, n0 = t >> 4;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k1 = dr(r);
-        double a = pr[n0 * S2 + k1 * 16 + k0], b = pi[n0 * S2 + k1 * 16 + k0];
-        if (k1 != 0) {
-            const double wr = tb.t2[(n0 * 16 + k1) * 2], wi = -tb.t2[(n0 * 16 + k1) * 2 + 1];
-            const double a2 = a * wr - b * wi;
-            b = a * wi + b * wr;
-            a = a2;
-        }
-        re[r] = a;
-        im[r] = b;
-    }
-}
-
-OSZ_HD void i2_compute_store(int t, double *re, double *im, double *pr, double *pi) {
-    inv16(re, im);
-    const int k0 = t & 15, n0 = t >> 4;
-    const int base = k0 * S1 + ((n0 + k0) & 15);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {  // register j = n1
-        pr[base + j * 16] = re[j];
-        pi[base + j * 16] = im[j];
-    }
-}
-
-// I1: load layout A with logical k0 at register dr(k0), conj twiddle, inverse
-// pass 1.  Afterwards register j holds y[256 j + t] (times 4096).
-template <bool POW = true>
-OSZ_HD void i1(int t, double *re, double *im, const Tables &tb, const double *pr,
-               const double *pi) {
-    double twr[16], twi[16];
-    if constexpr (POW) {
-        t1_powers(t, tb, twr, twi);
-    } else {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            twr[k] = tb.t1[(k * 256 + t) * 2];
-            twi[k] = tb.t1[(k * 256 + t) * 2 + 1];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k0 = dr(r);
-        const int slot = k0 * S1 + (t & ~15) + ((t + k0) & 15);
-        double a = pr[slot], b = pi[slot];
-        if (k0 != 0) {
-            const double wr = twr[k0], wi = -twi[k0];
-            const double a2 = a * wr - b * wi;
-            b = a * wi + b * wr;
-            a = a2;
-        }
-        re[r] = a;
-        im[r] = b;
-    }
-    inv16(re, im);
-}
-
 // ---- cube layout: interleaved complex, in-place exchanges ------------------
 // One array of 4096 complex slots (64 KB, no padding) viewed as a 16x16x16 cube
 //   slot(k0, m, l) = 256 k0 + 16 m + (l ^ k0)
@@ -413,6 +141,17 @@ OSZ_HD void i1(int t, double *re, double *im, const Tables &tb, const double *pr
 // over 32 banks): view A lanes walk l (16 distinct columns), views B and C
 // lanes walk k0 (column (l ^ k0), again 16 distinct); checked by brute force
 // over the guide's lane groups in tests/test_fft_host.py.
+//
+// Twiddles stay off the vector-memory path: a wave's global loads return in
+// order, so a twiddle load (an L2 hit) issued after the sample loads of an HBM
+// stream inherits their latency.  Each thread keeps the powers {1, 2, 4, 8} of
+// its two twiddle bases resident (W4096^t for pass 1, W256^n0 for pass 2:
+// 32 registers, exact table values) and applies W^k, k = b + 4a, as the
+// product W^b (W^4)^a with W^3 = W W^2 and W^12 = W^4 W^8 formed on the spot:
+// 26 complex multiplies per pass, as many as expanding all 15 powers would
+// take, but only 6 twiddles live instead of 15.  After fwd16 (and before
+// inv16) register r holds k = dr(r) = (r >> 2) + 4 (r & 3): b = r >> 2,
+// a = r & 3.
 namespace cube {
 
 struct alignas(16) C2 {
@@ -431,101 +170,13 @@ OSZ_HD void cmul(double &re, double &im, double wr, double wi) {
     im = a * wi + b * wr;
 }
 
-// F1: registers hold x[256 j + t] at register j.  Pass 1, twiddle W4096^(t k0),
-// store view A.
-OSZ_HD void f1(int t, double *re, double *im, const Tables &tb, C2 *L) {
-    double twr[16], twi[16];
-    t1_powers(t, tb, twr, twi);
-    fwd16(re, im);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k0 = dr(r);
-        if (k0 != 0) cmul(re[r], im[r], twr[k0], twi[k0]);
-        L[slot_a(t, k0)] = C2{re[r], im[r]};
-    }
+// (a + ib)(wr - i wi): conjugate multiply without negating the twiddle first
+OSZ_HD void cmulc(double &re, double &im, double wr, double wi) {
+    const double a = re, b = im;
+    re = a * wr + b * wi;
+    im = b * wr - a * wi;
 }
 
-// F2: view B in place: load n1, pass 2, twiddle W256^(n0 k1), store k1.
-OSZ_HD void f2(int t, double *re, double *im, const Tables &tb, C2 *L) {
-    const int n0 = t >> 4, base = base_b(t);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const C2 v = L[base + 16 * j];
-        re[j] = v.re;
-        im[j] = v.im;
-    }
-    fwd16(re, im);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k1 = dr(r);
-        if (k1 != 0) cmul(re[r], im[r], tb.t2[(n0 * 16 + k1) * 2], tb.t2[(n0 * 16 + k1) * 2 + 1]);
-        L[base + 16 * k1] = C2{re[r], im[r]};
-    }
-}
-
-// F3: view C: load n0, pass 3.  Afterwards register r holds X[t + 256 dr(r)].
-OSZ_HD void f3(int t, double *re, double *im, const C2 *L) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const C2 v = L[slot_c(t, j)];
-        re[j] = v.re;
-        im[j] = v.im;
-    }
-    fwd16(re, im);
-}
-
-// I3: registers hold Y[t + 256 dr(r)] at register r.  Inverse pass 3, store
-// view C (the slots F3 read).
-OSZ_HD void i3(int t, double *re, double *im, C2 *L) {
-    inv16(re, im);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) L[slot_c(t, j)] = C2{re[j], im[j]};
-}
-
-// I2: view B in place: load k1 (at register dr(k1)), conj twiddle, inverse
-// pass 2, store n1.
-OSZ_HD void i2(int t, double *re, double *im, const Tables &tb, C2 *L) {
-    const int n0 = t >> 4, base = base_b(t);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k1 = dr(r);
-        const C2 v = L[base + 16 * k1];
-        re[r] = v.re;
-        im[r] = v.im;
-        if (k1 != 0) cmul(re[r], im[r], tb.t2[(n0 * 16 + k1) * 2], -tb.t2[(n0 * 16 + k1) * 2 + 1]);
-    }
-    inv16(re, im);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) L[base + 16 * j] = C2{re[j], im[j]};
-}
-
-// I1: view A: load k0 (at register dr(k0)), conj twiddle, inverse pass 1.
-// Afterwards register j holds y[256 j + t] (times 4096).
-OSZ_HD void i1(int t, double *re, double *im, const Tables &tb, const C2 *L) {
-    double twr[16], twi[16];
-    t1_powers(t, tb, twr, twi);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k0 = dr(r);
-        const C2 v = L[slot_a(t, k0)];
-        re[r] = v.re;
-        im[r] = v.im;
-        if (k0 != 0) cmul(re[r], im[r], twr[k0], -twi[k0]);
-    }
-    inv16(re, im);
-}
-
-// ---- twiddles off the vector-memory path -----------------------------------
-// A wave's global loads return in order, so a twiddle load (an L2 hit) issued
-// after the sample loads of an HBM stream inherits their latency.  Kernels
-// that loop over many transforms keep, per thread, the powers {1, 2, 4, 8} of
-// its two twiddle bases resident (W4096^t for pass 1, W256^n0 for pass 2:
-// 32 registers, exact table values) and apply W^k, k = b + 4a, as the product
-// W^b (W^4)^a with W^3 = W W^2 and W^12 = W^4 W^8 formed on the spot: 26
-// complex multiplies per pass like the table version (15 + 11 to expand the
-// powers), but only 6 twiddles live instead of 15.  After fwd16 (and before
-// inv16) register r holds k = dr(r) = (r >> 2) + 4 (r & 3): b = r >> 2,
-// a = r & 3.
 struct TwPow {
     double r[4], i[4];   // base^{1,2,4,8}
 };
@@ -540,13 +191,6 @@ OSZ_HD void tw_load(int t, const Tables &tb, TwPow &w1, TwPow &w2) {
         w2.r[q] = tb.t2[(n0 * 16 + k) * 2];
         w2.i[q] = tb.t2[(n0 * 16 + k) * 2 + 1];
     }
-}
-
-// (a + ib)(wr - i wi): conjugate multiply without negating the twiddle first
-OSZ_HD void cmulc(double &re, double &im, double wr, double wi) {
-    const double a = re, b = im;
-    re = a * wr + b * wi;
-    im = b * wr - a * wi;
 }
 
 template <bool CONJ>
@@ -571,6 +215,8 @@ OSZ_HD void tw_mul(double *re, double *im, const TwPow &w) {
     }
 }
 
+// F1: registers hold x[256 j + t] at register j.  Pass 1, twiddle W4096^(t k0),
+// store view A.
 OSZ_HD void f1(int t, double *re, double *im, const TwPow &w1, C2 *L) {
     fwd16(re, im);
     tw_mul<false>(re, im, w1);
@@ -578,6 +224,7 @@ OSZ_HD void f1(int t, double *re, double *im, const TwPow &w1, C2 *L) {
     for (int r = 0; r < 16; ++r) L[slot_a(t, dr(r))] = C2{re[r], im[r]};
 }
 
+// F2: view B in place: load n1, pass 2, twiddle W256^(n0 k1), store k1.
 OSZ_HD void f2(int t, double *re, double *im, const TwPow &w2, C2 *L) {
     const int base = base_b(t);
 #pragma unroll
@@ -592,6 +239,27 @@ OSZ_HD void f2(int t, double *re, double *im, const TwPow &w2, C2 *L) {
     for (int r = 0; r < 16; ++r) L[base + 16 * dr(r)] = C2{re[r], im[r]};
 }
 
+// F3: view C: load n0, pass 3.  Afterwards register r holds X[t + 256 dr(r)].
+OSZ_HD void f3(int t, double *re, double *im, const C2 *L) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const C2 v = L[slot_c(t, j)];
+        re[j] = v.re;
+        im[j] = v.im;
+    }
+    fwd16(re, im);
+}
+
+// I3: registers hold Y[t + 256 dr(r)] at register r.  Inverse pass 3, store
+// view C (the slots F3 read).
+OSZ_HD void i3(int t, double *re, double *im, C2 *L) {
+    inv16(re, im);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) L[slot_c(t, j)] = C2{re[j], im[j]};
+}
+
+// I2: view B in place: load k1 (at register dr(k1)), conj twiddle, inverse
+// pass 2, store n1.
 OSZ_HD void i2(int t, double *re, double *im, const TwPow &w2, C2 *L) {
     const int base = base_b(t);
 #pragma unroll
@@ -606,6 +274,8 @@ OSZ_HD void i2(int t, double *re, double *im, const TwPow &w2, C2 *L) {
     for (int j = 0; j < 16; ++j) L[base + 16 * j] = C2{re[j], im[j]};
 }
 
+// I1: view A: load k0 (at register dr(k0)), conj twiddle, inverse pass 1.
+// Afterwards register j holds y[256 j + t] (times 4096).
 OSZ_HD void i1(int t, double *re, double *im, const TwPow &w1, const C2 *L) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -9,18 +9,18 @@
 //   - one fixed transform length, NFFT = 4096, independent of the reference's
 //     nfft (65 536 / 262 144 for 256 / 1024 taps, far beyond LDS): the linear
 //     convolution is segmentation independent, so the segment is chosen to
-//     keep r2c -> xH -> c2r entirely on chip (fft4096.h: registers + 68 KB LDS);
+//     keep r2c -> xH -> c2r entirely on chip (fft4096.h: registers + 64 KB LDS);
 //   - two consecutive real blocks ride one complex transform (a + i b): since
 //     h is real, Re/Im of the inverse are the two blocks' results -- no
 //     real-FFT split/merge pass and no bit reversal;
 //   - a workgroup owns a RUN of consecutive blocks of one channel and keeps
-//     the (ntaps-1) overlap tail in LDS from pair to pair; runs are
+//     the (ntaps-1) overlap tail in registers from pair to pair; runs are
 //     independent: each starts with a zero tail and publishes its last tail,
 //     and a small seam kernel adds tails across run boundaries and across
 //     pushes (the carried state of the iterator);
 //   - HBM: every sample is read once (8 B, consecutive lanes -> consecutive
-//     samples) and written once (8 B): 16 B per channel-sample; twiddles and
-//     H (64 KB each) stay L2 resident.
+//     samples) and written once (8 B): 16 B per channel-sample; the filter
+//     spectrum H (64 KB) stays L2 resident, the twiddles live in registers.
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -55,192 +55,28 @@ __host__ __device__ __forceinline__ int64_t fir_run_start(int64_t r, int64_t nbl
 }
 
 // NR = rows of 256 samples per block (block length step = 256 NR, chosen by
-// the host as the largest multiple of 256 with step + ntaps - 1 <= 4096).  A
-// pair of two whole blocks past the left cut -- every pair but the ragged last
-// one of a push -- takes the FAST path: which register rows carry samples is a
-// compile-time fact, so loads, stores and the first butterfly stage (whose
-// rows >= NR are literal zeros) need no predication.
-template <bool POW, int NR>
-__global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
-    extern __shared__ double lds[];
-    double *pr = lds;
-    double *pi = lds + fft::PLANE;
-    double *carry = lds + 2 * fft::PLANE;  // wlen - 1 doubles
-
-    const int t = threadIdx.x;
-    const int run = blockIdx.x;
-    const int c = blockIdx.y;
-    const int wm1 = a.wlen - 1;
-    const double *xr = a.x + (int64_t)c * a.ldx;
-    double *yr = a.y + (int64_t)c * a.ldy;
-
-    const int64_t blk0 = fir_run_start(run, a.nblocks, a.nruns);
-    const int64_t blk1 = fir_run_start(run + 1, a.nblocks, a.nruns);
-
-    for (int i = t; i < wm1; i += 256) carry[i] = 0.0;
-    __syncthreads();
-
-    fft::TwBase tw;
-    constexpr bool RES = false;   // resident twiddle bases: measured to spill under the 256-VGPR cap
-    if (RES) fft::tw_load_base(t, a.tb, tw);
-    double re[16], im[16];
-    for (int64_t blk = blk0; blk < blk1; blk += 2) {
-        const int64_t start_a = blk * a.step;
-        const int64_t rem_a = a.n - start_a;
-        const int len_a = rem_a < a.step ? (int)rem_a : a.step;
-        const int64_t start_b = start_a + len_a;
-        int len_b = 0;
-        if (blk + 1 < blk1) {
-            const int64_t rem_b = a.n - start_b;
-            len_b = rem_b < a.step ? (int)rem_b : a.step;
-        }
-        // ---- load two zero-padded real blocks as one complex block
-        const bool fast = len_a == 256 * NR && len_b == 256 * NR && start_a >= a.skip && !a.accum;
-        if (fast) {
-            const double *pa = xr + start_a + t, *pb = xr + start_b + t;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                re[j] = j < NR ? pa[256 * j] : 0.0;
-                im[j] = j < NR ? pb[256 * j] : 0.0;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int p = 256 * j + t;
-                re[j] = p < len_a ? xr[start_a + p] : 0.0;
-                im[j] = p < len_b ? xr[start_b + p] : 0.0;
-            }
-        }
-        // ---- forward transform
-        if (RES) fft::f1_w(t, re, im, tw, pr, pi); else fft::f1<POW>(t, re, im, a.tb, pr, pi);
-        __syncthreads();
-        fft::f2_load(t, re, im, pr, pi);
-        if (RES) fft::f2_compute_w(re, im, tw); else fft::f2_compute(t, re, im, a.tb);
-        __syncthreads();
-        fft::f2_store(t, re, im, pr, pi);
-        // filter spectrum of this thread's bins: issued before the barrier so
-        // the L2 latency overlaps the exchange and pass 3
-        double hr[16], hi[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = t + 256 * fft::dr(r);
-            hr[r] = a.H[2 * k];
-            hi[r] = a.H[2 * k + 1];
-        }
-        __syncthreads();
-        fft::f3(t, re, im, pr, pi);
-        // ---- multiply by the filter spectrum
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double u = re[r], v = im[r];
-            re[r] = u * hr[r] - v * hi[r];
-            im[r] = u * hi[r] + v * hr[r];
-        }
-        // ---- inverse transform (each thread overwrites only the slots it read)
-        fft::i3(t, re, im, pr, pi);
-        __syncthreads();
-        if (RES) fft::i2_load_w(t, re, im, tw, pr, pi); else fft::i2_load(t, re, im, a.tb, pr, pi);
-        __syncthreads();
-        fft::i2_compute_store(t, re, im, pr, pi);
-        __syncthreads();
-        if (RES) fft::i1_w(t, re, im, tw, pr, pi); else fft::i1<POW>(t, re, im, a.tb, pr, pi);
-        __syncthreads();
-        // ---- overlap add.  re[j] = a[256 j + t], im[j] = b[256 j + t].
-        double *xb = pr;  // a's tail handed to b's head
-        if (fast) {
-            // whole blocks: the tail occupies rows NR..15 and lands in rows
-            // 0..15-NR of the next block (wm1 <= 256 (16 - NR) by construction)
-#pragma unroll
-            for (int j = 0; j < 16 - NR; ++j) {
-                const int p = 256 * j + t;
-                if (p < wm1) {
-                    re[j] += carry[p];
-                    xb[p] = re[j + NR];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 16 - NR; ++j) {
-                const int p = 256 * j + t;
-                if (p < wm1) {
-                    im[j] += xb[p];
-                    carry[p] = im[j + NR];
-                }
-            }
-        } else {
-            // Only a few of the 16 register rows take part (j < ceil(wm1/256)
-            // for the heads, the rows covering [len, len + wm1) for the tails):
-            // the row tests are wave-uniform scalar branches, the lane tests
-            // stay inside.
-            const int jhead = (wm1 + 255) >> 8;
-            const int ja0 = len_a >> 8, ja1 = (len_a + wm1 + 255) >> 8;
-            const int jb0 = len_b >> 8, jb1 = (len_b + wm1 + 255) >> 8;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int p = 256 * j + t;
-                if (j < jhead) {
-                    if (p < wm1) re[j] += carry[p];
-                }
-                if (j >= ja0 && j < ja1) {
-                    const int q = p - len_a;
-                    if (q >= 0 && q < wm1) xb[q] = re[j];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int p = 256 * j + t;
-                if (j < jhead) {
-                    if (p < wm1) im[j] += xb[p];
-                }
-                if (j >= jb0 && j < jb1) {
-                    const int q = p - len_b;
-                    if (q >= 0 && q < wm1) carry[q] = im[j];
-                }
-            }
-        }
-        // ---- write the finished samples (full-convolution positions start_a + p)
-        if (fast) {
-            double *qa = yr + (start_a - a.skip) + t, *qb = yr + (start_b - a.skip) + t;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                qa[256 * j] = re[j];
-                qb[256 * j] = im[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int p = 256 * j + t;
-                const int64_t oa = start_a + p - a.skip;
-                if (p < len_a && oa >= 0) yr[oa] = a.accum ? yr[oa] + re[j] : re[j];
-                const int64_t ob = start_b + p - a.skip;
-                if (p < len_b && ob >= 0) yr[ob] = a.accum ? yr[ob] + im[j] : im[j];
-            }
-        }
-        __syncthreads();
-    }
-    double *tl = a.tails + ((int64_t)c * a.nruns + run) * wm1;
-    for (int i = t; i < wm1; i += 256) tl[i] = carry[i];
-}
-
-// The same run of blocks on the cube layout of fft4096.h (interleaved complex,
-// in-place exchanges, 64 KB): four barriers per pair of blocks, 16-byte LDS
-// accesses, and an overlap that never leaves the registers: with whole blocks
-// of 256 NR samples, sample p = 256 j + t of a's tail (register row j + NR)
-// meets b's head at register row j of the SAME thread, and b's tail meets the
-// next pair's a the same way, so the carried tail is cr[j], 16 - NR doubles
-// per thread.  Ragged pairs (the first one of a push with a left cut, the
-// last one, every pair of a partitioned filter) pass their tails through LDS,
-// over the idle cube; they run in their own loops before and after the
-// stretch of whole pairs so that their predicated code does not weigh on the
-// register allocation of the hot loop.
-//   TW   1: twiddle powers resident in registers, 0: loaded from the tables
-//   HPRE 1: filter spectrum requested before the second barrier
-//   XPRE 1: the NEXT pair's samples requested after the third barrier (the
-//           spectrum registers are dead by then) and arrive behind the
-//           inverse passes, instead of at the top of the loop with nothing to
-//           hide the HBM latency behind
-template <int NR, int TW, int HPRE, int XPRE>
+// the host as the largest multiple of 256 with step + ntaps - 1 <= 4096).
+// A workgroup walks its run pair by pair on the cube layout of fft4096.h
+// (interleaved complex, in-place exchanges, 64 KB of LDS): four barriers per
+// pair, 16-byte LDS accesses, twiddle powers resident in registers, and an
+// overlap that never leaves the registers: with whole blocks of 256 NR
+// samples, sample p = 256 j + t of a's tail (register row j + NR) meets b's
+// head at register row j of the SAME thread, and b's tail meets the next
+// pair's a the same way, so the carried tail is cr[j], 16 - NR doubles per
+// thread.  Which register rows carry samples is a compile-time fact there, so
+// loads, stores and the first butterfly stage (whose rows >= NR are literal
+// zeros) need no predication.  Ragged pairs (the first one of a push with a
+// left cut, the last one) pass their
+// tails through LDS, over the idle cube; they run in their own loops before
+// and after the stretch of whole pairs so that their predicated code does not
+// weigh on the register allocation of the hot loop.
+// Measured and rejected on this kernel (profiles/README.md): requesting the
+// whole filter spectrum before the second barrier (the 64 extra live
+// registers spill), requesting the NEXT pair's samples after the third
+// barrier (+6 % time), twiddles loaded from the tables per pass (+13 %),
+// running the FIR of chunk k+1 beside the IIR step of chunk k on a second
+// stream (+5 %, benchmarks/overlap_probe.py).
+template <int NR, int HPRE>
 struct FirPair {
     using C2 = fft::cube::C2;
     static constexpr int NT_ = 16 - NR;   // register rows of the tail (wm1 <= 256 NT_)
@@ -253,78 +89,55 @@ struct FirPair {
     C2 *L;
     fft::cube::TwPow tw1, tw2;
     double cr[NT_];
-    double xa[XPRE ? NR : 1], xb[XPRE ? NR : 1];
 
     __device__ __forceinline__ bool whole(int64_t blk) const {
-        return blk + 1 < blk1 && (blk + 2) * a.step <= a.n && blk * a.step >= a.skip && !a.accum;
-    }
-
-    __device__ __forceinline__ void request(int64_t blk) {
-        const double *pa = xr + blk * a.step + t;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            xa[XPRE ? j : 0] = pa[256 * j];
-            xb[XPRE ? j : 0] = pa[256 * (j + NR)];
-        }
+        return blk + 1 < blk1 && (blk + 2) * a.step <= a.n && blk * a.step >= a.skip;
     }
 
     // forward transform, filter, inverse transform of the pair in re/im
-    template <bool FAST>
-    __device__ __forceinline__ void transform(double *re, double *im, int64_t blk) {
+    __device__ __forceinline__ void transform(double *re, double *im) {
         // LDS slot numbers are recomputed per pair from an opaque copy of the
         // thread index: hoisted out of the loop they would pin 33 registers
         int t = this->t;
         asm volatile("" : "+v"(t));
-        if (TW == 1) fft::cube::f1(t, re, im, tw1, L); else fft::cube::f1(t, re, im, a.tb, L);
+        fft::cube::f1(t, re, im, tw1, L);
         __syncthreads();
-        if (TW == 1) fft::cube::f2(t, re, im, tw2, L); else fft::cube::f2(t, re, im, a.tb, L);
-        double hr[16], hi[16];
-        if (HPRE) {
+        fft::cube::f2(t, re, im, tw2, L);
+        // HPRE of the 16 filter-spectrum bins are requested before the barrier
+        // (all 16 would cost 64 live registers and spill; 4 measured best)
+        double hr[HPRE > 0 ? HPRE : 1], hi[HPRE > 0 ? HPRE : 1];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = t + 256 * fft::dr(r);
-                hr[r] = a.H[2 * k];
-                hi[r] = a.H[2 * k + 1];
-            }
+        for (int r = 0; r < HPRE; ++r) {
+            const int k = t + 256 * fft::dr(r);
+            hr[r] = a.H[2 * k];
+            hi[r] = a.H[2 * k + 1];
         }
         __syncthreads();
         fft::cube::f3(t, re, im, L);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (HPRE) {
-                fft::cube::cmul(re[r], im[r], hr[r], hi[r]);
-            } else {
-                const int k = t + 256 * fft::dr(r);
-                fft::cube::cmul(re[r], im[r], a.H[2 * k], a.H[2 * k + 1]);
-            }
+            const int k = t + 256 * fft::dr(r);
+            if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
+            else fft::cube::cmul(re[r], im[r], a.H[2 * k], a.H[2 * k + 1]);
         }
         fft::cube::i3(t, re, im, L);
         __syncthreads();
-        if (FAST && XPRE && whole(blk + 2)) request(blk + 2);
-        if (TW == 1) fft::cube::i2(t, re, im, tw2, L); else fft::cube::i2(t, re, im, a.tb, L);
+        fft::cube::i2(t, re, im, tw2, L);
         __syncthreads();
-        if (TW == 1) fft::cube::i1(t, re, im, tw1, L); else fft::cube::i1(t, re, im, a.tb, L);
+        fft::cube::i1(t, re, im, tw1, L);
     }
 
     // a pair of whole blocks: no predication anywhere
     __device__ __forceinline__ void fast_pair(int64_t blk) {
         const int64_t start_a = blk * a.step;
         double re[16], im[16];
-        if (XPRE) {
+        const double *pa = xr + start_a + t;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                re[j] = j < NR ? xa[j < NR ? j : 0] : 0.0;
-                im[j] = j < NR ? xb[j < NR ? j : 0] : 0.0;
-            }
-        } else {
-            const double *pa = xr + start_a + t;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                re[j] = j < NR ? pa[256 * j] : 0.0;
-                im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
-            }
+        for (int j = 0; j < 16; ++j) {
+            re[j] = j < NR ? pa[256 * j] : 0.0;
+            im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
         }
-        transform<true>(re, im, blk);
+        transform(re, im);
         // re[j] = a[256 j + t], im[j] = b[256 j + t]
 #pragma unroll
         for (int j = 0; j < NT_; ++j) {
@@ -336,10 +149,18 @@ struct FirPair {
             }
         }
         double *qa = yr + (start_a - a.skip) + t;
+        if (a.accum) {   // a piece of a partitioned filter adds into the work row
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            qa[256 * j] = re[j];
-            qa[256 * (j + NR)] = im[j];
+            for (int j = 0; j < NR; ++j) {
+                qa[256 * j] += re[j];
+                qa[256 * (j + NR)] += im[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                qa[256 * j] = re[j];
+                qa[256 * (j + NR)] = im[j];
+            }
         }
     }
 
@@ -363,7 +184,7 @@ struct FirPair {
             re[j] = p < len_a ? xr[start_a + p] : 0.0;
             im[j] = p < len_b ? xr[start_b + p] : 0.0;
         }
-        transform<false>(re, im, blk);
+        transform(re, im);
         __syncthreads();   // every thread is done reading the cube
         const int ja0 = len_a >> 8, ja1 = (len_a + wm1 + 255) >> 8;
         const int jb0 = len_b >> 8, jb1 = (len_b + wm1 + 255) >> 8;
@@ -408,24 +229,20 @@ struct FirPair {
     }
 };
 
-template <int NR, int TW = 1, int HPRE = 0, int XPRE = 0>
-__global__ __launch_bounds__(256, 2) void fir_oa_cube_kernel(FirArgs a) {
+template <int NR, int HPRE = 4>
+__global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     extern __shared__ fft::cube::C2 cube_lds[];
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
     const int64_t blk0 = fir_run_start(run, a.nblocks, a.nruns);
-    FirPair<NR, TW, HPRE, XPRE> P{a, t, a.wlen - 1, a.x + (int64_t)c * a.ldx,
-                                  a.y + (int64_t)c * a.ldy,
-                                  fir_run_start(run + 1, a.nblocks, a.nruns), cube_lds};
-    if (TW == 1) fft::cube::tw_load(t, a.tb, P.tw1, P.tw2);
+    FirPair<NR, HPRE> P{a, t, a.wlen - 1, a.x + (int64_t)c * a.ldx, a.y + (int64_t)c * a.ldy,
+                  fir_run_start(run + 1, a.nblocks, a.nruns), cube_lds};
+    fft::cube::tw_load(t, a.tb, P.tw1, P.tw2);
 #pragma unroll
     for (int j = 0; j < 16 - NR; ++j) P.cr[j] = 0.0;
 
     int64_t blk = blk0;
     for (; blk < P.blk1 && !P.whole(blk); blk += 2) P.any_pair(blk);
-    if (blk < P.blk1) {
-        if (XPRE) P.request(blk);
-        for (; blk < P.blk1 && P.whole(blk); blk += 2) P.fast_pair(blk);
-    }
+    for (; blk < P.blk1 && P.whole(blk); blk += 2) P.fast_pair(blk);
     for (; blk < P.blk1; blk += 2) P.any_pair(blk);
 
     double *tl = a.tails + ((int64_t)c * a.nruns + run) * P.wm1;
@@ -626,16 +443,6 @@ static int fir_build_part(FirPart &pt, const double *taps, int ntaps, int nch) {
     return OSZ_OK;
 }
 
-// OSZ_FIR_CUBE=0 selects the older plane-layout kernel (kept for A/B runs)
-static bool fir_use_cube() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("OSZ_FIR_CUBE");
-        v = !(e && atoi(e) == 0);
-    }
-    return v != 0;
-}
-
 // one overlap-add stream: main kernel + seam kernel
 static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx, int64_t n,
                          double *y, int64_t ldy, int64_t skip, int accum, hipStream_t st) {
@@ -660,9 +467,7 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
                 cus = prop.multiProcessorCount;
             if (cus <= 0) cus = 256;
         }
-        const size_t lds_wg = fir_use_cube() ? sizeof(fft::cube::C2) * fft::cube::SLOTS
-                                             : sizeof(double) * (2 * fft::PLANE + (wm1 > 0 ? wm1 : 1));
-        const int64_t slots = (int64_t)cus * (2 * lds_wg <= 160 * 1024 ? 2 : 1);
+        const int64_t slots = (int64_t)cus * 2;   // 64 KB of LDS per workgroup
         int64_t best = nruns;
         double best_waste = 2.0;
         for (int64_t cand = nruns; cand < nruns + 8; ++cand) {
@@ -692,13 +497,6 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
             return fail(OSZ_ERR_NOMEM, "osz_fir_push: tails workspace %lld doubles", (long long)need);
         h->tails_cap = need;
     }
-    static bool pow_tw = true;    // pass-1 twiddles as products of 4 loaded powers (OSZ_FIR_T1POW=0: table)
-    static bool env_read = false;
-    if (!env_read) {
-        const char *e = getenv("OSZ_FIR_T1POW");
-        pow_tw = !(e && atoi(e) == 0);   // default on: measured 2.4 % faster
-        env_read = true;
-    }
     FirArgs a{};
     a.x = x;
     a.y = y;
@@ -715,46 +513,22 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
     a.H = pt.dH;
     a.tb = h->tb;
     a.tails = h->dtails;
-    const size_t lds_used = sizeof(double) * (2 * fft::PLANE + (wm1 > 0 ? wm1 : 1));
     {
         using kern_t = void (*)(FirArgs);
         // rows per block: 8 (2049 taps) .. 15 (<= 257 taps)
-        static const kern_t kerns[2][8] = {
-            {fir_oa_kernel<false, 8>, fir_oa_kernel<false, 9>, fir_oa_kernel<false, 10>,
-             fir_oa_kernel<false, 11>, fir_oa_kernel<false, 12>, fir_oa_kernel<false, 13>,
-             fir_oa_kernel<false, 14>, fir_oa_kernel<false, 15>},
-            {fir_oa_kernel<true, 8>, fir_oa_kernel<true, 9>, fir_oa_kernel<true, 10>,
-             fir_oa_kernel<true, 11>, fir_oa_kernel<true, 12>, fir_oa_kernel<true, 13>,
-             fir_oa_kernel<true, 14>, fir_oa_kernel<true, 15>}};
-        static bool attr_set[2][8] = {};
+        static const kern_t kerns[8] = {fir_oa_kernel<8>,  fir_oa_kernel<9>,  fir_oa_kernel<10>,
+                                        fir_oa_kernel<11>, fir_oa_kernel<12>, fir_oa_kernel<13>,
+                                        fir_oa_kernel<14>, fir_oa_kernel<15>};
+        static bool attr_set[8] = {};
         const int nr = pt.step / 256;
-        kern_t kern = kerns[pow_tw ? 1 : 0][nr - 8];
-        if (!attr_set[pow_tw ? 1 : 0][nr - 8]) {
-            const size_t lds_max = sizeof(double) * (2 * fft::PLANE + 2048);
-            OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            attr_set[pow_tw ? 1 : 0][nr - 8] = true;
+        const size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS;
+        if (!attr_set[nr - 8]) {
+            OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[nr - 8]),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[nr - 8] = true;
         }
-        const bool use_cube = fir_use_cube();
         KernelTimer kt("fir_oa", st);
-        if (use_cube) {
-            static const kern_t ckerns[8] = {
-                fir_oa_cube_kernel<8>, fir_oa_cube_kernel<9>, fir_oa_cube_kernel<10>,
-                fir_oa_cube_kernel<11>, fir_oa_cube_kernel<12>, fir_oa_cube_kernel<13>,
-                fir_oa_cube_kernel<14>, fir_oa_cube_kernel<15>};
-            static bool cattr[8] = {};
-            kern_t ck = ckerns[nr - 8];
-            if (!cattr[nr - 8]) {
-                const size_t lds_max = sizeof(fft::cube::C2) * fft::cube::SLOTS;
-                OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ck),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-                cattr[nr - 8] = true;
-            }
-            const size_t lds_cube = sizeof(fft::cube::C2) * fft::cube::SLOTS;
-            hipLaunchKernelGGL(ck, dim3((unsigned)nruns, h->nch), dim3(256), lds_cube, st, a);
-        } else {
-            hipLaunchKernelGGL(kern, dim3((unsigned)nruns, h->nch), dim3(256), lds_used, st, a);
-        }
+        hipLaunchKernelGGL(kerns[nr - 8], dim3((unsigned)nruns, h->nch), dim3(256), lds, st, a);
     }
     OSZ_HIP(hipGetLastError());
     if (wm1 > 0) {

@@ -164,11 +164,23 @@ struct FusedArgs {
 
 constexpr int kNF = 2049;   // nfft / 2 + 1
 
-template <int MODE, bool LINEAR>
-__global__ __launch_bounds__(256, 2) void spec_fused_kernel(FusedArgs a) {
-    extern __shared__ double lds[];
-    double *pr = lds;
-    double *pi = lds + fft::PLANE;
+// The fused pass runs on the cube layout of fft4096.h (interleaved complex,
+// in-place exchanges, resident twiddle powers and window): four barriers per
+// pair of segments.  With HALF (stride == 2048, the 50 % overlap of cfg-4/5)
+// segment b's first half IS segment a's second half in the same registers and
+// b's second half is the next pair's first half, so a thread loads 16 new
+// samples per pair instead of 32: each sample goes through the vector-memory
+// path once.  (Requesting those 16 one pair ahead was measured 14 % SLOWER,
+// as the same idea was in the FIR kernel: the kernel is not latency-starved
+// at two workgroups per CU, and the longer-lived registers cost more.)  The
+// two spectra are separated through the view-C slots a thread already owns
+// (Z[k] parked at slot_c(t, k >> 8), its mirror Z[N-k] read from thread
+// 256 - t's slots).
+template <int MODE, bool LINEAR, bool HALF>
+__global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
+    using fft::cube::C2;
+    extern __shared__ C2 cube_lds[];
+    C2 *L = cube_lds;
     __shared__ double red[4][4];
     const int t = threadIdx.x;
     const int run = blockIdx.x;
@@ -176,14 +188,24 @@ __global__ __launch_bounds__(256, 2) void spec_fused_kernel(FusedArgs a) {
     const double *cr = a.carry + (int64_t)c * a.ncap;
     const double *xr = a.x + (int64_t)c * a.ldx;
     const int64_t npairs = (a.nseg + 1) / 2;
-    const int64_t p0 = (int64_t)run * a.R;
-    const int64_t p1 = (p0 + a.R < npairs) ? p0 + a.R : npairs;
+    const int64_t p0 = ((int64_t)run * npairs) / a.nruns;
+    const int64_t p1 = ((int64_t)(run + 1) * npairs) / a.nruns;
     const double mid = 0.5 * (fft::N - 1);
     const double s2 = a.scale * a.scale;
+
+    fft::cube::TwPow tw1, tw2;
+    fft::cube::tw_load(t, a.tb, tw1, tw2);
+    double win[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) win[j] = a.window[256 * j + t];
 
     double acc[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = 0.0;
+    double keep[HALF ? 8 : 1];
+    bool have_keep = false;
+
+    auto ld = [&](int64_t v) { return v < a.ncarry ? cr[v] : xr[v - a.ncarry]; };
 
     double re[16], im[16];
     for (int64_t p = p0; p < p1; ++p) {
@@ -191,13 +213,51 @@ __global__ __launch_bounds__(256, 2) void spec_fused_kernel(FusedArgs a) {
         const bool has_b = sb < a.nseg;
         const int64_t va = sa * (int64_t)a.stride, vb = va + a.stride;
         // ---- load both segments (virtual stream = carry ++ chunk)
+        if (HALF) {
+            const bool chunk_only = va + (have_keep ? 2048 : 0) >= a.ncarry;
+            const double *q = xr + (va - a.ncarry) + t;
+            if (have_keep) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) re[j] = keep[HALF ? j : 0];
+            } else if (chunk_only) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) re[j] = q[256 * j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) re[j] = ld(va + 256 * j + t);
+            }
+            if (chunk_only) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) re[8 + j] = q[2048 + 256 * j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) re[8 + j] = ld(va + 2048 + 256 * j + t);
+            }
+            if (has_b) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    im[j] = re[8 + j];
+                    im[8 + j] = chunk_only ? q[4096 + 256 * j] : ld(va + 4096 + 256 * j + t);
+                    keep[HALF ? j : 0] = im[8 + j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) im[j] = 0.0;
+            }
+            have_keep = has_b;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = 256 * j + t;
+                re[j] = ld(va + i);
+                im[j] = has_b ? ld(vb + i) : 0.0;
+            }
+        }
+        // ---- trend: block sums
         double sum_a = 0.0, sum_b = 0.0, lin_a = 0.0, lin_b = 0.0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int i = 256 * j + t;
-            const int64_t ia = va + i, ib = vb + i;
-            re[j] = ia < a.ncarry ? cr[ia] : xr[ia - a.ncarry];
-            im[j] = has_b ? (ib < a.ncarry ? cr[ib] : xr[ib - a.ncarry]) : 0.0;
             sum_a += re[j];
             sum_b += im[j];
             if (LINEAR) {
@@ -205,7 +265,6 @@ __global__ __launch_bounds__(256, 2) void spec_fused_kernel(FusedArgs a) {
                 lin_b += (i - mid) * im[j];
             }
         }
-        // ---- trend: block sums
         for (int off = 32; off > 0; off >>= 1) {
             sum_a += __shfl_down(sum_a, off, 64);
             sum_b += __shfl_down(sum_b, off, 64);
@@ -220,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void spec_fused_kernel(FusedArgs a) {
             red[t >> 6][2] = lin_a;
             red[t >> 6][3] = lin_b;
         }
-        __syncthreads();
+        __syncthreads();   // also: every mirror read of the previous pair is done
         const double mean_a = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) / fft::N;
         const double mean_b = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) / fft::N;
         double slope_a = 0.0, slope_b = 0.0;
@@ -232,41 +291,36 @@ __global__ __launch_bounds__(256, 2) void spec_fused_kernel(FusedArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int i = 256 * j + t;
-            const double w = a.window[i];
             if (LINEAR) {
-                re[j] = (re[j] - mean_a - slope_a * (i - mid)) * w;
-                im[j] = has_b ? (im[j] - mean_b - slope_b * (i - mid)) * w : 0.0;
+                re[j] = (re[j] - mean_a - slope_a * (i - mid)) * win[j];
+                im[j] = has_b ? (im[j] - mean_b - slope_b * (i - mid)) * win[j] : 0.0;
             } else {
-                re[j] = (re[j] - mean_a) * w;
-                im[j] = has_b ? (im[j] - mean_b) * w : 0.0;
+                re[j] = (re[j] - mean_a) * win[j];
+                im[j] = has_b ? (im[j] - mean_b) * win[j] : 0.0;
             }
         }
         // ---- forward transform of a + i b
-        fft::f1<true>(t, re, im, a.tb, pr, pi);
+        int tt = t;   // opaque copy: keeps the LDS slot numbers out of loop-invariant registers
+        asm volatile("" : "+v"(tt));
+        fft::cube::f1(tt, re, im, tw1, L);
         __syncthreads();
-        fft::f2_load(t, re, im, pr, pi);
-        fft::f2_compute(t, re, im, a.tb);
+        fft::cube::f2(tt, re, im, tw2, L);
         __syncthreads();
-        fft::f2_store(t, re, im, pr, pi);
-        __syncthreads();
-        fft::f3(t, re, im, pr, pi);
-        __syncthreads();
-        // ---- separate the two spectra: exchange Z in natural order
+        fft::cube::f3(tt, re, im, L);
+        // ---- separate the two spectra: park Z[k] in this thread's own slots
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = t + 256 * fft::dr(r);
-            pr[k] = re[r];
-            pi[k] = im[r];
-        }
+        for (int r = 0; r < 16; ++r) L[fft::cube::slot_c(tt, fft::dr(r))] = C2{re[r], im[r]};
         __syncthreads();
+        const int tp = (256 - tt) & 255;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = fft::dr(r);
             if (j > 8) continue;
             const int k = t + 256 * j;
             if (j == 8 && t != 0) continue;
-            const int kp = (fft::N - k) & (fft::N - 1);
-            const double zr = re[r], zi = im[r], qr = pr[kp], qi = pi[kp];
+            const int jp = t == 0 ? ((16 - j) & 15) : 15 - j;   // N - k = tp + 256 jp
+            const C2 q = L[fft::cube::slot_c(tp, jp)];
+            const double zr = re[r], zi = im[r], qr = q.re, qi = q.im;
             const double ar = 0.5 * (zr + qr), ai = 0.5 * (zi - qi);
             const double br = 0.5 * (zi + qi), bi = -0.5 * (zr - qr);
             const bool dbl = (k != 0) && (k != fft::N / 2);
@@ -293,7 +347,6 @@ __global__ __launch_bounds__(256, 2) void spec_fused_kernel(FusedArgs a) {
                 }
             }
         }
-        __syncthreads();
     }
     if (MODE == OSZ_SPEC_PSD_MEAN) {
         double *o = a.partial + ((int64_t)c * a.nruns + run) * kNF;
@@ -487,26 +540,30 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
             }
             fa.partial = h->dpartial;
         }
-        const size_t lds = sizeof(double) * 2 * fft::PLANE;
-        static bool attr_set = false;
         using kern_t = void (*)(FusedArgs);
-        static const kern_t kerns[3][2] = {
-            {spec_fused_kernel<0, false>, spec_fused_kernel<0, true>},
-            {spec_fused_kernel<1, false>, spec_fused_kernel<1, true>},
-            {spec_fused_kernel<2, false>, spec_fused_kernel<2, true>}};
-        if (!attr_set) {
+        static const kern_t ck[3][2][2] = {
+            {{spec_cube_kernel<0, false, false>, spec_cube_kernel<0, false, true>},
+             {spec_cube_kernel<0, true, false>, spec_cube_kernel<0, true, true>}},
+            {{spec_cube_kernel<1, false, false>, spec_cube_kernel<1, false, true>},
+             {spec_cube_kernel<1, true, false>, spec_cube_kernel<1, true, true>}},
+            {{spec_cube_kernel<2, false, false>, spec_cube_kernel<2, false, true>},
+             {spec_cube_kernel<2, true, false>, spec_cube_kernel<2, true, true>}}};
+        static bool cattr = false;
+        const size_t clds = sizeof(fft::cube::C2) * fft::cube::SLOTS;
+        if (!cattr) {
             for (int m = 0; m < 3; ++m)
                 for (int l = 0; l < 2; ++l)
-                    OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[m][l]),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)lds));
-            attr_set = true;
+                    for (int hf = 0; hf < 2; ++hf)
+                        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ck[m][l][hf]),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)clds));
+            cattr = true;
         }
         {
             KernelTimer kt("spec_fused", st);
             const dim3 grid((unsigned)nruns, h->nch), block(256);
-            hipLaunchKernelGGL(kerns[h->mode][h->detrend == OSZ_DETREND_LINEAR ? 1 : 0], grid, block,
-                               lds, st, fa);
+            hipLaunchKernelGGL(ck[h->mode][h->detrend == OSZ_DETREND_LINEAR ? 1 : 0]
+                                 [h->stride == 2048 ? 1 : 0], grid, block, clds, st, fa);
         }
         OSZ_HIP(hipGetLastError());
         if (h->mode == OSZ_SPEC_PSD_MEAN) {
