@@ -85,6 +85,20 @@ def sqrt(a):
     return torch.sqrt(a) if is_tensor(a) else np.sqrt(a)
 
 
+def absolute(a):
+    return torch.abs(a) if is_tensor(a) else np.abs(a)
+
+
+def angle_0_2pi(a):
+    """Phase of complex values mapped to [0, 2 pi)."""
+    if is_tensor(a):
+        phi = torch.angle(a)
+        return torch.where(phi < 0, phi + 2 * np.pi, phi)
+    phi = np.angle(a)
+    phi[phi < 0] += 2 * np.pi
+    return phi
+
+
 def require_gpu():
     lib = _lib.load()          # raises OszLibraryError when the .so is missing
     if torch is None or not torch.cuda.is_available():

@@ -1,0 +1,61 @@
+"""Complex transforms of real data for amplitude / phase extraction (SURVEY
+section 8f rank 4): consumers of the FIR path.  Same interface as the
+reference's ``experimental/coupling/transforms.py`` (Transform :18-107,
+Analytic :110-192).  The Hilbert FIR runs through the overlap-add kernel; the
+elementwise parts (x + i h(x), |z|, angle) map over produced chunks on whatever
+memory kind they live in.
+"""
+
+import abc
+
+import numpy as np
+
+from openseize_amd import _device as dev
+from openseize_amd.core import protools
+from openseize_amd.core.producer import producer
+from openseize_amd.filtering.special import Hilbert
+
+
+class Transform(abc.ABC):
+    """Holds ``data`` (a producer of the raw arrays) and ``signal`` (a producer
+    of its complex transform); concrete classes supply ``estimate``."""
+
+    def __init__(self, data, fs, chunksize=int(10e6), axis=-1, **kwargs):
+        self.fs = fs
+        self.chunksize = chunksize
+        self.axis = axis
+        self.data = producer(data, chunksize, axis)
+        self.signal = self.estimate(self.data, **kwargs)
+
+    @abc.abstractmethod
+    def estimate(self, data, **kwargs):
+        """Returns a producer of complex values."""
+
+    def _envelope(self):
+        for arr in self.signal:
+            yield dev.absolute(arr)
+
+    @property
+    def amplitudes(self):
+        return producer(self._envelope, self.chunksize, self.axis, shape=self.signal.shape)
+
+    def _phase(self):
+        for arr in self.signal:
+            yield dev.angle_0_2pi(arr)
+
+    @property
+    def phases(self):
+        """Phases in [0, 2 pi)."""
+        return producer(self._phase, self.chunksize, self.axis, shape=self.signal.shape)
+
+
+class Analytic(Transform):
+    """x + i H(x) with H the type-III Kaiser Hilbert FIR of
+    ``filtering.special.Hilbert`` (transition ``width`` around 0 and Nyquist)."""
+
+    def estimate(self, data, *, width, gpass=0.01, gstop=60, **kwargs):
+        hilbert = Hilbert(width, fs=self.fs, gpass=gpass, gstop=gstop)
+        real = producer(data, self.chunksize, self.axis)
+        imag = hilbert(real, self.chunksize, self.axis)
+        imag = protools.multiply(imag, complex(0, 1))
+        return protools.add(real, imag)

@@ -469,6 +469,33 @@ def g13_hilbert():
     save("g13_hilbert.npz", **out)
 
 
+# --------------------------------------------------------------------------
+# G14 band metrics and the analytic transform
+# --------------------------------------------------------------------------
+def g14_metrics_analytic():
+    from openseize.experimental.coupling.transforms import Analytic
+    from openseize.spectra import metrics
+    rng = np.random.default_rng(1414)
+    psd = rng.random((3, 501)) + 0.1
+    freqs = np.linspace(0, 250, 501)
+    out = {"psd": psd, "freqs": freqs}
+    out["power_all"] = metrics.power(psd, freqs)
+    out["power_0_40"] = metrics.power(psd, freqs, start=0, stop=40)
+    out["power_7p3_33p1"] = metrics.power(psd, freqs, start=7.3, stop=33.1)   # even sample count
+    out["power_axis0"] = metrics.power(psd.T, freqs, start=2, stop=100, axis=0)
+    out["power_norm_4_30"] = metrics.power_norm(psd, freqs, start=4, stop=30)
+    ci = metrics.confidence_interval(psd, n_estimates=47, alpha=0.05)
+    out["ci_lower"] = np.stack([c[0] for c in ci])
+    out["ci_upper"] = np.stack([c[1] for c in ci])
+    x = rng.standard_normal((2, 9000))
+    out["x"] = x
+    tr = Analytic(x, fs=500, chunksize=2500, axis=-1, width=12.5)
+    out["signal"] = tr.signal.to_array(dtype=complex)
+    out["amplitudes"] = tr.amplitudes.to_array()
+    out["phases"] = tr.phases.to_array()
+    save("g14_metrics_analytic.npz", **out)
+
+
 if __name__ == "__main__":
     g1_producer()
     g2_fir()
@@ -483,3 +510,4 @@ if __name__ == "__main__":
     g11_edf()
     g12_protools()
     g13_hilbert()
+    g14_metrics_analytic()

@@ -707,3 +707,21 @@ def test_hilbert_analytic_signal(osz, golden):
     env = np.abs(tone + 1j * filt(tone, chunksize=5000, axis=-1, mode="same"))
     core = slice(len(filt.coeffs), -len(filt.coeffs))
     assert np.max(np.abs(env[0, core] - 1.0)) < 2e-3        # gpass 0.01 dB
+
+
+def test_analytic_transform_golden(osz, golden):
+    """experimental.coupling.transforms.Analytic: x + i H(x)
+    through the device FIR, amplitudes and phases in [0, 2 pi) equal the
+    reference's."""
+    from openseize_amd.experimental.coupling.transforms import Analytic
+    g = golden("g14_metrics_analytic.npz")
+    tr = Analytic(g["x"], fs=500, chunksize=2500, axis=-1, width=12.5)
+    sig = tr.signal.to_array(dtype=complex)
+    assert sig.shape == g["signal"].shape
+    assert rel_err(sig.real, g["signal"].real) < RTOL
+    assert rel_err(sig.imag, g["signal"].imag) < RTOL
+    assert rel_err(tr.amplitudes.to_array(), g["amplitudes"]) < RTOL
+    ph = tr.phases.to_array()
+    assert ph.min() >= 0 and ph.max() < 2 * np.pi
+    # compare on the unit circle (a phase next to 0 / 2 pi may wrap either way)
+    assert np.max(np.abs(np.exp(1j * ph) - np.exp(1j * g["phases"]))) < 1e-8

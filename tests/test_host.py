@@ -299,3 +299,25 @@ def test_protools_golden(golden):
     assert eq(protools.mean(pro, 0), g["mean_other"]) and eq(protools.std(pro, 0), g["std_other"])
     assert eq(protools.standardize(pro, -1).to_array(), g["standardize_prod"])
     assert eq(protools.standardize(pro, 0).to_array(), g["standardize_other"])
+
+
+def test_band_metrics_golden(golden):
+    """spectra.metrics against the reference's outputs:
+    Simpson band power (odd and even sample counts, either axis), the
+    normalised estimate and the chi-squared confidence bounds."""
+    from openseize_amd.spectra import metrics
+    g = golden("g14_metrics_analytic.npz")
+    psd, freqs = g["psd"], g["freqs"]
+    np.testing.assert_allclose(metrics.power(psd, freqs), g["power_all"], rtol=1e-13)
+    np.testing.assert_allclose(metrics.power(psd, freqs, start=0, stop=40), g["power_0_40"], rtol=1e-13)
+    np.testing.assert_allclose(metrics.power(psd, freqs, start=7.3, stop=33.1),
+                               g["power_7p3_33p1"], rtol=1e-13)
+    np.testing.assert_allclose(metrics.power(psd.T, freqs, start=2, stop=100, axis=0),
+                               g["power_axis0"], rtol=1e-13)
+    np.testing.assert_allclose(metrics.power_norm(psd, freqs, start=4, stop=30),
+                               g["power_norm_4_30"], rtol=1e-13)
+    ci = metrics.confidence_interval(psd, n_estimates=47, alpha=0.05)
+    assert len(ci) == psd.shape[0]
+    np.testing.assert_allclose(np.stack([c[0] for c in ci]), g["ci_lower"], rtol=1e-13)
+    np.testing.assert_allclose(np.stack([c[1] for c in ci]), g["ci_upper"], rtol=1e-13)
+    assert metrics.nearest1D(freqs, 7.3) == int(np.argmin(np.abs(freqs - 7.3)))
