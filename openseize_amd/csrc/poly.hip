@@ -8,10 +8,12 @@
 // xup = x zero-stuffed by L, zeros outside, ceil(N*L/M) outputs
 // (resampling/resampling.py:91), which is what this kernel evaluates directly:
 // only the taps k = (j*M + half) mod L, +L, +2L, ... hit non-zero samples.
-// One thread per output sample; consecutive lanes read input windows that
-// overlap by all but M/L samples, so the reads are L1/L2 hits and HBM sees
-// each input once (8 B) and each output once (8*L/M B).
-// The handle carries the last `hist` input samples across pushes.
+// HBM sees each input once (8 B) and each output once (8*L/M B).  The handle
+// carries the last `hist` input samples across pushes.  Two kernels:
+// poly_block_kernel (LDS window, register-blocked, all practical L/M) and
+// poly_kernel (one thread per output through L1/L2; only for M so large that
+// the window of a 64-thread tile does not fit in LDS).
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -50,71 +52,129 @@ __global__ __launch_bounds__(256) void poly_kernel(PolyArgs a) {
     }
 }
 
-// LDS-tiled polyphase kernel.  Output j only meets the taps k = phi + L k',
-// phi = (j M + half) mod L, and phi depends on j mod L alone, so the outputs
-// of one residue class r = j mod L form a plain decimating FIR
-//     out[jf + L q] = sum_k' hL[phi + L k'] * x[itop + M q - k'],
-//     itop = (jf M + half - phi) / L,
-// with its own sub-filter.  Grid (tiles, nch, L): a 256-thread workgroup
-// produces 256*R consecutive outputs of ONE residue class of one channel: the
-// input window (256 R M + ceil(m/L) - M samples) is staged once in LDS with
-// coalesced loads; thread t accumulates R outputs reading its taps from LDS
-// (lane stride M doubles: conflict free for odd M) while the coefficient of
-// each tap is wave-uniform (scalar load).  For decimation (L = 1, the EEG case)
-// HBM sees every input once and every output once; for L > 1 the L residue
-// classes re-read the same window through L2.
-template <int R>
-__global__ __launch_bounds__(256) void poly_phase_kernel(PolyArgs a,
-                                                         const double *__restrict__ hL) {
+// Output j only meets the taps k = phi + L k', phi = (j M + half) mod L, and
+// phi depends on j mod L alone, so the outputs of one residue class r = j mod L
+// form a plain decimating FIR with its own sub-filter hsub[k'] = hL[phi + L k']:
+//     out[jf + L q] = sum_k' hsub[k'] * x[itop + M q - k'],
+//     itop = (jf M + half - phi) / L.
+//
+// Register-blocked polyphase kernel.  Within one residue class
+//     out[o] = sum_k' hsub[k'] x[itop + M o - k'],
+// and with u = msub - 1 - k' = M a + e the sum splits into M ordinary
+// (non-decimating) FIRs over the phase streams x_e[i] = win[i M + e]:
+//     out[o] = sum_e sum_a G[e][a] x_e[o + a],   G[e][a] = hsub[msub - 1 - (M a + e)].
+// A thread owns R = 4 CONSECUTIVE outputs, so a block of 8 taps of one phase
+// needs only 4 + 7 stream values for its 32 multiply-adds (2.9 per LDS read
+// instead of 1), and the 8 coefficients are one wave-uniform scalar load.
+// The window is staged deinterleaved by phase and padded one double per four
+// (position i -> i + i/4), which makes the lane stride 5 doubles: conflict
+// free, and every read of the blocked loop sits at a compile-time offset from
+// one per-block base address.  Results leave through LDS so that consecutive
+// lanes store consecutive outputs.
+constexpr int kPolyR = 4;                 // consecutive outputs per thread
+constexpr int kPolyBlk = 8;               // taps per coefficient block
+constexpr int kPolyBatch = 24;            // staging loads in flight per thread
+
+__device__ __forceinline__ int poly_pad(int i) { return i + (i >> 2); }
+
+struct PolyBlockArgs {
+    PolyArgs p;
+    const double *G;   // [L][M][apad] blocked sub-filters, zero padded
+    int apad;          // taps per phase stream, multiple of kPolyBlk
+    int se;            // LDS doubles per phase stream
+};
+
+// ONE: L == 1 (decimation), a single class per tile.  NT threads produce
+// NT * kPolyR outputs per class: large M shrinks the tile so that the window
+// (M phase streams) still fits three workgroups' worth of LDS.
+template <bool ONE, int NT>
+__global__ __launch_bounds__(NT, 3) void poly_block_kernel(PolyBlockArgs b) {
+    constexpr int NJ = NT * kPolyR;
     extern __shared__ double win[];
+    const PolyArgs &a = b.p;
     const int c = blockIdx.y;
     const int t = threadIdx.x;
-    const int r = blockIdx.z;                           // residue class j mod L
     const double *xr = a.x + (int64_t)c * a.ldx;
     const double *hr = a.hist + (int64_t)c * a.H;
     double *yr = a.y + (int64_t)c * a.ldy;
-    // first output of this class at or after j0, and the class' sub-filter
-    int64_t jf = a.j0 + (((int64_t)r - a.j0) % a.L + a.L) % a.L;
-    const int phi = (int)(((int64_t)r * a.M + a.half) % a.L);
-    const int msub = phi < a.m ? (a.m - phi + a.L - 1) / a.L : 0;
-    const int64_t nq_all = jf < a.j1 ? (a.j1 - jf + a.L - 1) / a.L : 0;
-    const int64_t qt = (int64_t)blockIdx.x * (256 * R);
-    if (qt >= nq_all) return;
-    const int nj = (int)((nq_all - qt) < (256 * R) ? (nq_all - qt) : (256 * R));
-    jf += qt * a.L;                                     // first output of this tile
-    const int64_t itop = (jf * a.M + a.half - phi) / a.L;
-    // window: inputs [i0, i0 + wlen)
-    const int64_t i0 = itop - (msub - 1);
-    const int wlen = (nj - 1) * a.M + msub;
-    for (int q = t; q < wlen; q += 256) {
-        const int64_t i = i0 + q;
-        double v = 0.0;
-        if (i >= 0 && i < a.navail)
-            v = i >= a.nin ? xr[i - a.nin] : (i >= a.nin - a.H ? hr[i - (a.nin - a.H)] : 0.0);
-        win[q] = v;
+    const int L = ONE ? 1 : a.L;
+    // this workgroup produces the L * NJ consecutive outputs [J0, J0 + L NJ):
+    // all L residue classes, one after the other, gathered in LDS so that the
+    // stores are contiguous (a class on its own would write every L-th double)
+    const int64_t J0 = a.j0 + (int64_t)blockIdx.x * NJ * L;
+    if (J0 >= a.j1) return;
+    double *outbuf = ONE ? win : win + a.M * b.se;      // L = 1: reuses the window
+    const int nstream = NJ + b.apad;               // entries per phase stream
+    const int wtot = nstream * a.M;
+    const int dq = NT / a.M, dr = NT - dq * a.M;
+    for (int cls = 0; cls < L; ++cls) {
+        const int64_t jf = J0 + cls;                    // first output of this class in the tile
+        const int r = ONE ? 0 : (int)(jf % L);                  // its residue j mod L
+        const int phi = ONE ? 0 : (int)(((int64_t)r * a.M + a.half) % L);
+        const int msub = phi < a.m ? (a.m - phi + L - 1) / L : 0;
+        const int64_t itop = (jf * a.M + a.half - phi) / L;
+        const int64_t i0 = itop - (msub - 1);           // window: inputs [i0, i0 + wtot)
+        // staging walks w = t, t + NT, ...: (i, e) = (w div M, w mod M) advance by
+        // (NT div M, NT mod M) with a carry, no division in the loop
+        int i = t / a.M, e = t - i * a.M;
+        if (i0 >= a.nin && i0 + wtot <= a.navail) {
+            // the whole window lies in the current chunk: plain coalesced loads,
+            // kPolyBatch in flight per thread, issued back to back, then placed
+            const double *src = xr + (i0 - a.nin);
+            for (int w = t; w < wtot; w += kPolyBatch * NT) {
+                double v[kPolyBatch];
+#pragma unroll
+                for (int u = 0; u < kPolyBatch; ++u)
+                    v[u] = (w + NT * u < wtot) ? src[w + NT * u] : 0.0;
+#pragma unroll
+                for (int u = 0; u < kPolyBatch; ++u) {
+                    if (w + NT * u < wtot) win[e * b.se + poly_pad(i)] = v[u];
+                    i += dq;
+                    e += dr;
+                    if (e >= a.M) { e -= a.M; ++i; }
+                }
+            }
+        } else {
+            for (int w = t; w < wtot; w += NT) {
+                const int64_t g = i0 + w;
+                double v = 0.0;
+                if (g >= 0 && g < a.navail)
+                    v = g >= a.nin ? xr[g - a.nin] : (g >= a.nin - a.H ? hr[g - (a.nin - a.H)] : 0.0);
+                win[e * b.se + poly_pad(i)] = v;
+                i += dq;
+                e += dr;
+                if (e >= a.M) { e -= a.M; ++i; }
+            }
+        }
+        __syncthreads();
+        double acc[kPolyR];
+#pragma unroll
+        for (int s = 0; s < kPolyR; ++s) acc[s] = 0.0;
+        const double *Gr = b.G + (int64_t)r * a.M * b.apad;
+        for (int ph = 0; ph < a.M; ++ph) {
+            const double *ge = Gr + (int64_t)ph * b.apad;
+            const double *xe = win + ph * b.se + 5 * t;     // poly_pad(4 t) = 5 t
+            for (int a0 = 0; a0 < b.apad; a0 += kPolyBlk) {
+                double g[kPolyBlk], xv[kPolyBlk + kPolyR - 1];
+#pragma unroll
+                for (int q = 0; q < kPolyBlk; ++q) g[q] = ge[a0 + q];      // wave-uniform
+                const double *xb = xe + (a0 + (a0 >> 2));                  // a0 multiple of 8
+#pragma unroll
+                for (int d = 0; d < kPolyBlk + kPolyR - 1; ++d) xv[d] = xb[d + (d >> 2)];
+#pragma unroll
+                for (int q = 0; q < kPolyBlk; ++q)
+#pragma unroll
+                    for (int s = 0; s < kPolyR; ++s) acc[s] = fma(g[q], xv[s + q], acc[s]);
+            }
+        }
+        __syncthreads();                                // everyone is done with the window
+#pragma unroll
+        for (int s = 0; s < kPolyR; ++s) outbuf[cls + L * (kPolyR * t + s)] = acc[s];
     }
     __syncthreads();
-    // output q = t + 256 s reads win[q M + (msub - 1) - k']
-    double acc[R];
-    const double *base[R];
-#pragma unroll
-    for (int s = 0; s < R; ++s) {
-        acc[s] = 0.0;
-        const int o = t + 256 * s;
-        base[s] = win + (o < nj ? o : 0) * a.M + (msub - 1);
-    }
-    const double *hs = hL + phi;
-#pragma unroll 4
-    for (int k = 0; k < msub; ++k) {
-        const double ck = hs[(int64_t)k * a.L];
-#pragma unroll
-        for (int s = 0; s < R; ++s) acc[s] = fma(ck, base[s][-k], acc[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < R; ++s) {
-        const int o = t + 256 * s;
-        if (o < nj) yr[(jf - a.j0) + (int64_t)o * a.L] = acc[s];
-    }
+    const int64_t left = a.j1 - J0;
+    const int ntile = (int)(left < (int64_t)NJ * L ? left : (int64_t)NJ * L);
+    for (int o = t; o < ntile; o += NT) yr[(J0 - a.j0) + o] = outbuf[o];
 }
 
 // newhist = last H samples of (hist ++ x[0:n])
@@ -139,6 +199,8 @@ using namespace osz;
 struct osz_poly_s {
     int m, L, M, nch, H, half;
     double *dhL;
+    double *dG;         // blocked sub-filters for poly_block_kernel, or null
+    int apad, se, nt;   // nt: threads per workgroup (256, 128 or 64), 0 = kernel not usable
     double *dhist[2];
     int cur;
     int64_t nin, nout;
@@ -177,6 +239,38 @@ int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M, 
     OSZ_HIP(hipMemcpy(p->dhL, hL.data(), sizeof(double) * ntaps, hipMemcpyHostToDevice));
     OSZ_HIP(hipMemset(p->dhist[0], 0, hb));
     OSZ_HIP(hipMemset(p->dhist[1], 0, hb));
+    // blocked sub-filters G[r][e][a] = hsub_r[msub_r - 1 - (M a + e)]
+    p->dG = nullptr;
+    {
+        const int msub_max = (ntaps + L - 1) / L;
+        int apad = (msub_max + M - 1) / M;                       // taps per phase stream
+        apad = (apad + kPolyBlk - 1) / kPolyBlk * kPolyBlk;
+        p->apad = apad;
+        p->nt = 0;
+        p->se = 0;
+        for (int nt = 256; nt >= 64 && !p->nt; nt >>= 1) {
+            const int nstream = nt * kPolyR + apad;
+            const int se = (nstream + (nstream >> 2) + 2) | 1;   // odd: spreads the staging writes
+            const size_t bytes = ((size_t)M * se + (L == 1 ? 0 : (size_t)nt * kPolyR * L)) * sizeof(double);
+            if (bytes <= (nt == 64 ? 64 : 53) * 1024) {
+                p->nt = nt;
+                p->se = se;
+            }
+        }
+        if (p->nt) {
+            std::vector<double> G((size_t)L * M * apad, 0.0);
+            for (int r = 0; r < L; ++r) {
+                const int phi = (int)(((int64_t)r * M + p->half) % L);
+                const int msub = phi < ntaps ? (ntaps - phi + L - 1) / L : 0;
+                for (int kk = 0; kk < msub; ++kk) {
+                    const int u = msub - 1 - kk, aa = u / M, e = u % M;
+                    G[((size_t)r * M + e) * apad + aa] = hL[phi + (size_t)L * kk];
+                }
+            }
+            OSZ_HIP(hipMalloc(&p->dG, G.size() * sizeof(double)));
+            OSZ_HIP(hipMemcpy(p->dG, G.data(), G.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
     *h = p;
     return OSZ_OK;
 }
@@ -184,6 +278,7 @@ int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M, 
 int osz_poly_destroy(osz_poly_t h) {
     if (!h) return OSZ_OK;
     (void)hipFree(h->dhL);
+    (void)hipFree(h->dG);
     (void)hipFree(h->dhist[0]);
     (void)hipFree(h->dhist[1]);
     delete h;
@@ -230,17 +325,29 @@ int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n, int fin
         a.M = h->M;
         a.H = h->H;
         a.half = h->half;
-        constexpr int R = 4;
-        const int msub = (h->m + h->L - 1) / h->L;
-        const size_t lds = sizeof(double) * ((size_t)(256 * R - 1) * h->M + msub);
-        if (lds <= 64 * 1024 && h->L <= 64) {
-            // LDS-tiled path: 256*R outputs of one residue class per workgroup
-            const int64_t nq = (cnt + h->L - 1) / h->L + 1;
-            const int64_t bx = (nq + 256 * R - 1) / (256 * R);
-            KernelTimer kt("poly_phase", st);
-            hipLaunchKernelGGL(poly_phase_kernel<R>, dim3((unsigned)bx, h->nch, h->L), dim3(256),
-                               lds, st, a, h->dhL);
-        } else {
+        if (h->dG) {
+            PolyBlockArgs b{a, h->dG, h->apad, h->se};
+            const size_t blds = sizeof(double) * ((size_t)h->M * h->se +
+                                                  (h->L == 1 ? 0 : (size_t)h->nt * kPolyR * h->L));
+            using kern_t = void (*)(PolyBlockArgs);
+            static const kern_t kerns[2][3] = {
+                {poly_block_kernel<false, 256>, poly_block_kernel<false, 128>, poly_block_kernel<false, 64>},
+                {poly_block_kernel<true, 256>, poly_block_kernel<true, 128>, poly_block_kernel<true, 64>}};
+            static bool attr = false;
+            if (!attr) {
+                for (int o = 0; o < 2; ++o)
+                    for (int q = 0; q < 3; ++q)
+                        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[o][q]),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    64 * 1024));
+                attr = true;
+            }
+            const int64_t per = (int64_t)h->nt * kPolyR * h->L;
+            const int64_t bx = (cnt + per - 1) / per;
+            KernelTimer kt("poly_block", st);
+            hipLaunchKernelGGL(kerns[h->L == 1 ? 1 : 0][h->nt == 256 ? 0 : h->nt == 128 ? 1 : 2],
+                               dim3((unsigned)bx, h->nch), dim3(h->nt), blds, st, b);
+        } else {   // very large M: the window of even a 64-thread tile exceeds LDS
             int64_t bx = (cnt + 255) / 256;
             if (bx > 4096) bx = 4096;
             KernelTimer kt("poly", st);
