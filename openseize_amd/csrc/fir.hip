@@ -31,6 +31,23 @@
 
 namespace osz {
 
+// In-kernel phase stamps for the diagnostic build only
+// (benchmarks/fir_stamps.hip defines OSZ_FIR_STAMPS); the library build has none.
+#ifdef OSZ_FIR_STAMPS
+__device__ unsigned long long *g_fir_stamps = nullptr;   // [waves][12] cycle sums
+#define OSZ_FSTAMP(slot)                                                             \
+    do {                                                                             \
+        unsigned long long now_;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        stamp_acc[slot] += now_ - stamp_last;                                        \
+        stamp_last = now_;                                                           \
+    } while (0)
+#else
+#define OSZ_FSTAMP(slot) do { } while (0)
+#endif
+
 constexpr int kFirMaxTaps = 2049;  // NFFT - ntaps + 1 >= ntaps - 1
 
 struct FirArgs {
@@ -89,6 +106,9 @@ struct FirPair {
     C2 *L;
     fft::cube::TwPow tw1, tw2;
     double cr[NT_];
+#ifdef OSZ_FIR_STAMPS
+    unsigned long long stamp_acc[12], stamp_last;
+#endif
 
     __device__ __forceinline__ bool whole(int64_t blk) const {
         return blk + 1 < blk1 && (blk + 2) * a.step <= a.n && blk * a.step >= a.skip;
@@ -101,10 +121,12 @@ struct FirPair {
         int t = this->t;
         asm volatile("" : "+v"(t));
         fft::cube::f1(t, re, im, tw1, L);
+        OSZ_FSTAMP(1);   // sample loads landed + pass 1 + stores
         __syncthreads();
+        OSZ_FSTAMP(2);   // barrier 1
         fft::cube::f2(t, re, im, tw2, L);
         // HPRE of the 16 filter-spectrum bins are requested before the barrier
-        // (all 16 would cost 64 live registers and spill; 4 measured best)
+        // (all 16 spill a few registers; 14 measured best, 3 % over 4)
         double hr[HPRE > 0 ? HPRE : 1], hi[HPRE > 0 ? HPRE : 1];
 #pragma unroll
         for (int r = 0; r < HPRE; ++r) {
@@ -112,18 +134,26 @@ struct FirPair {
             hr[r] = a.H[2 * k];
             hi[r] = a.H[2 * k + 1];
         }
+        OSZ_FSTAMP(3);   // pass 2
         __syncthreads();
+        OSZ_FSTAMP(4);   // barrier 2
         fft::cube::f3(t, re, im, L);
+        OSZ_FSTAMP(5);   // pass 3
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = t + 256 * fft::dr(r);
             if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
             else fft::cube::cmul(re[r], im[r], a.H[2 * k], a.H[2 * k + 1]);
         }
+        OSZ_FSTAMP(6);   // filter spectrum: loads + multiply
         fft::cube::i3(t, re, im, L);
+        OSZ_FSTAMP(7);   // inverse pass 3
         __syncthreads();
+        OSZ_FSTAMP(8);   // barrier 3
         fft::cube::i2(t, re, im, tw2, L);
+        OSZ_FSTAMP(9);   // inverse pass 2
         __syncthreads();
+        OSZ_FSTAMP(10);  // barrier 4
         fft::cube::i1(t, re, im, tw1, L);
     }
 
@@ -137,6 +167,7 @@ struct FirPair {
             re[j] = j < NR ? pa[256 * j] : 0.0;
             im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
         }
+        OSZ_FSTAMP(0);   // sample loads issued (and the previous pair's stores)
         transform(re, im);
         // re[j] = a[256 j + t], im[j] = b[256 j + t]
 #pragma unroll
@@ -162,6 +193,7 @@ struct FirPair {
                 qa[256 * (j + NR)] = im[j];
             }
         }
+        OSZ_FSTAMP(11);  // inverse pass 1 + overlap add + stores issued
     }
 
     // any pair: ragged lengths, left cut, accumulate
@@ -229,7 +261,9 @@ struct FirPair {
     }
 };
 
-template <int NR, int HPRE = 4>
+// bins of the filter spectrum requested before the second barrier: as many
+// as fit without spilling (the carried tail takes 2 (16 - NR) registers)
+template <int NR, int HPRE = (NR + 2 < 14 ? NR + 2 : 14)>
 __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     extern __shared__ fft::cube::C2 cube_lds[];
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
@@ -242,7 +276,17 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
 
     int64_t blk = blk0;
     for (; blk < P.blk1 && !P.whole(blk); blk += 2) P.any_pair(blk);
+#ifdef OSZ_FIR_STAMPS
+    for (int q = 0; q < 12; ++q) P.stamp_acc[q] = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.stamp_last)::"memory");
+#endif
     for (; blk < P.blk1 && P.whole(blk); blk += 2) P.fast_pair(blk);
+#ifdef OSZ_FIR_STAMPS
+    if (g_fir_stamps && (t & 63) == 0) {
+        unsigned long long *o = g_fir_stamps + (((int64_t)c * a.nruns + run) * 4 + (t >> 6)) * 12;
+        for (int q = 0; q < 12; ++q) o[q] = P.stamp_acc[q];
+    }
+#endif
     for (; blk < P.blk1; blk += 2) P.any_pair(blk);
 
     double *tl = a.tails + ((int64_t)c * a.nruns + run) * P.wm1;
