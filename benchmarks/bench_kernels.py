@@ -102,6 +102,45 @@ def main():
     out.append({"workload": "d2d copy 256 ch x 2^20 (practical HBM ceiling)",
                 "ms_per_chunk": dt * 1e3, "algorithmic_GBps": 16 * CH * N / dt / 1e9})
 
+    # EDF record decode on the device: 64 channels x 1000
+    # samples per 1 s record, 4000 records of little-endian int16 already in
+    # HBM -> (64, 4e6) float64: 2 B read + 8 B written per sample
+    nch_e, spr_e, nrec_e = 64, 1000, 4000
+    raw = torch.randint(-2000, 2000, (nrec_e * nch_e * spr_e,), dtype=torch.int16, device="cuda")
+    as_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    choff = as_dev((np.arange(nch_e) * spr_e).astype(np.int32))
+    spr = as_dev(np.full(nch_e, spr_e, np.int32))
+    lens = as_dev(np.full(nch_e, spr_e * nrec_e, np.int64))
+    slope, offs = as_dev(np.full(nch_e, 0.25)), as_dev(np.full(nch_e, -3.0))
+    width = spr_e * nrec_e
+    dec = torch.empty((nch_e, width), dtype=torch.float64, device="cuda")
+    lib = _lib.load()
+
+    def edf():
+        _lib.check(lib.osz_edf_decode(dev.ptr(raw), nch_e * spr_e, nch_e, dev.ptr(choff), dev.ptr(spr),
+                                      dev.ptr(slope), dev.ptr(offs), dev.ptr(lens), 0, 0, width,
+                                      ctypes.c_double(float("nan")), dev.ptr(dec), dec.stride(0),
+                                      dev.stream_ptr()))
+    dt = timed(edf, 5)
+    out.append({"workload": "EDF decode 64 ch x 4e6 samples (int16 records in HBM -> f64)",
+                "ms_per_chunk": dt * 1e3, "Msamples_s": nch_e * width / dt / 1e6,
+                "algorithmic_GBps": 10 * nch_e * width / dt / 1e9})
+
+    # transfer-function filter through the public API, device-resident:
+    # Notch (order 2, one section) zero-phase on 64 ch x 2^20
+    from openseize_amd import producer as make_producer
+    from openseize_amd.filtering.iir import Notch
+    xs = x[:64]
+    notch = Notch(fstop=60, width=4, fs=5000)
+
+    def ba():
+        for _ in notch(make_producer(xs, 1 << 18, -1), 1 << 18, -1, dephase=True):
+            pass
+    dt = timed(ba, 3)
+    out.append({"workload": "Notch filtfilt (ba, order 2) 64 ch x 2^20 via the producer API, chunksize 2^18",
+                "ms_per_chunk": dt * 1e3, "Msamples_s": 64 * N / dt / 1e6,
+                "algorithmic_GBps": 32 * 64 * N / dt / 1e9})
+
     # cfg-1, HOST-FED through the public API (ndarray in -> ndarray out):
     # 16 ch x 1e6, 256-tap FIR, chunksize 30000, mode same.  PCIe + per-chunk
     # launch overhead included; the reference needs 0.309 s for this.
