@@ -205,6 +205,30 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 double tmp[T / 2];
+                const double *src = xrow + mem_base + hh * HALF;
+                if (full && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+                    // 16 bytes per lane: half as many vector-memory instructions.
+                    // Lane l, step i holds elements m = 128 i + 2 l + {0, 1} of the
+                    // half window: LDS row m / T, column m % T (T = 32: row 4 i + l / 16)
+                    const double2 *p2 = reinterpret_cast<const double2 *>(src) + l;
+                    double2 t2[T / 4];
+#pragma unroll
+                    for (int i = 0; i < T / 4; ++i) t2[i] = p2[i * 64];
+                    double *st2 = wl + ((2 * l) / T) * ROW + (2 * l) % T;
+#pragma unroll
+                    for (int i = 0; i < T / 4; ++i) {
+                        st2[i * (128 / T) * ROW] = t2[i].x;
+                        st2[i * (128 / T) * ROW + 1] = t2[i].y;
+                    }
+                    wave_lds_fence();
+                    if ((myrow >> 5) == hh) {
+                        const double *blk = wl + (myrow & 31) * ROW;
+#pragma unroll
+                        for (int j = 0; j < T; ++j) v[j] = blk[REV ? (T - 1 - j) : j];
+                    }
+                    wave_lds_fence();
+                    continue;
+                }
                 if (full) {
                     const double *p = xrow + mem_base + hh * HALF + l;
 #pragma unroll
@@ -380,7 +404,18 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
                         for (int j = 0; j < T; ++j) blk[REV ? (T - 1 - j) : j] = v[j];
                     }
                     wave_lds_fence();
-                    if (full) {
+                    double *dst = yrow + mem_base + hh * HALF;
+                    if (full && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                        double2 *q2 = reinterpret_cast<double2 *>(dst) + l;
+                        const double *st2 = wl + ((2 * l) / T) * ROW + (2 * l) % T;
+#pragma unroll
+                        for (int i = 0; i < T / 4; ++i) {
+                            double2 o;
+                            o.x = st2[i * (128 / T) * ROW];
+                            o.y = st2[i * (128 / T) * ROW + 1];
+                            q2[i * 64] = o;
+                        }
+                    } else if (full) {
                         double *q = yrow + mem_base + hh * HALF + l;
 #pragma unroll
                         for (int i = 0; i < T / 2; ++i) q[i * 64] = stage[i * STEP];
