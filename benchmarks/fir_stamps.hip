@@ -51,9 +51,13 @@ int main() {
         ++waves;
         for (int i = 0; i < 12; ++i) { tot[i] += hs[wv * 12 + i]; all += hs[wv * 12 + i]; }
     }
+    unsigned long long clk[2] = {0, 0};
+    hipMemcpyFromSymbol(clk, HIP_SYMBOL(osz::g_fir_clock), sizeof(clk));
+    printf("one run: %llu s_memtime ticks over %llu s_memrealtime ticks (100 MHz) => s_memtime at %.0f MHz\n",
+           clk[0], clk[1], clk[1] ? 100.0 * clk[0] / clk[1] : 0.0);
     const double pairs_per_wave = (double)((n / (3072 * 2)) * nch) * 4 / waves;
     printf("FIR 256 ch x 2^20, 1024 taps (stamped build): %.3f ms; %zu waves, %.1f pairs per wave\n", ms, waves, pairs_per_wave);
-    printf("mean s_memtime ticks per pair per wave: %.0f (100 MHz ticks => %.2f us)\n", all / waves / pairs_per_wave, all / waves / pairs_per_wave / 100.0);
+    printf("mean s_memtime ticks per pair per wave: %.0f\n", all / waves / pairs_per_wave);
     for (int i = 0; i < 12; ++i) printf("  %-30s %5.1f %%  (%.0f ticks per pair)\n", names[i], 100.0 * tot[i] / all, tot[i] / waves / pairs_per_wave);
     return 0;
 }

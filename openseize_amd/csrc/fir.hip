@@ -35,6 +35,7 @@ namespace osz {
 // (benchmarks/fir_stamps.hip defines OSZ_FIR_STAMPS); the library build has none.
 #ifdef OSZ_FIR_STAMPS
 __device__ unsigned long long *g_fir_stamps = nullptr;   // [waves][12] cycle sums
+__device__ unsigned long long g_fir_clock[2];            // {s_memtime, s_memrealtime} ticks of one run
 #define OSZ_FSTAMP(slot)                                                             \
     do {                                                                             \
         unsigned long long now_;                                                     \
@@ -277,6 +278,8 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     int64_t blk = blk0;
     for (; blk < P.blk1 && !P.whole(blk); blk += 2) P.any_pair(blk);
 #ifdef OSZ_FIR_STAMPS
+    unsigned long long rt_begin, mt_begin;
+    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_begin), "=s"(mt_begin)::"memory");
     for (int q = 0; q < 12; ++q) P.stamp_acc[q] = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.stamp_last)::"memory");
 #endif
@@ -285,6 +288,14 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     if (g_fir_stamps && (t & 63) == 0) {
         unsigned long long *o = g_fir_stamps + (((int64_t)c * a.nruns + run) * 4 + (t >> 6)) * 12;
         for (int q = 0; q < 12; ++q) o[q] = P.stamp_acc[q];
+        // clock check: the same interval in shader-clock ticks (s_memtime) and in
+        // constant 100 MHz ticks (s_memrealtime), first workgroup only
+        if (c == 0 && run == 0 && t == 0) {
+            unsigned long long rt1, mt1;
+            asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1), "=s"(mt1)::"memory");
+            g_fir_clock[0] = mt1 - mt_begin;
+            g_fir_clock[1] = rt1 - rt_begin;
+        }
     }
 #endif
     for (; blk < P.blk1; blk += 2) P.any_pair(blk);

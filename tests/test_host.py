@@ -321,3 +321,39 @@ def test_band_metrics_golden(golden):
     np.testing.assert_allclose(np.stack([c[0] for c in ci]), g["ci_lower"], rtol=1e-13)
     np.testing.assert_allclose(np.stack([c[1] for c in ci]), g["ci_upper"], rtol=1e-13)
     assert metrics.nearest1D(freqs, 7.3) == int(np.argmin(np.abs(freqs - 7.3)))
+
+
+def _scale(arr, factor):
+    return arr * factor
+
+
+def _shift(arr, offset):
+    return arr + offset
+
+
+def _two_free(arr, other):
+    return arr + other
+
+
+def test_pipeline_composition_and_validation():
+    """tools.pipeline.Pipeline: stages run in order on a copy of the input,
+    membership by function, TypeError for a stage with two free arguments,
+    and the pipeline pickles (multiprocessing use, reference
+    tests/test_pipelines.py)."""
+    from openseize_amd.tools.pipeline import Pipeline
+
+    pipe = Pipeline()
+    pipe.append(_scale, factor=3.0)
+    pipe.append(_shift, offset=1.0)
+    x = np.arange(5.0)
+    assert np.array_equal(pipe(x), 3.0 * x + 1.0)
+    assert _scale in pipe and _two_free not in pipe
+    with pytest.raises(TypeError):
+        pipe.append(_two_free)                   # two unbound arguments
+    clone = pickle.loads(pickle.dumps(pipe))
+    assert np.array_equal(clone(x), pipe(x))
+    # a producer stage: chunking survives the copy made by __call__
+    pipe2 = Pipeline()
+    pipe2.append(producer, chunksize=4, axis=-1)
+    pro = pipe2(np.arange(10.0)[None, :])
+    assert [a.shape[-1] for a in pro] == [4, 4, 2]
