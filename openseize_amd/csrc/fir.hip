@@ -576,7 +576,8 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
                                         fir_oa_kernel<14>, fir_oa_kernel<15>};
         static bool attr_set[8] = {};
         const int nr = pt.step / 256;
-        const size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS;
+        size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS;
+        if (const char *e = getenv("OSZ_FIR_LDS_PAD")) lds += (size_t)atoi(e) * 1024;   // occupancy experiments
         if (!attr_set[nr - 8]) {
             OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[nr - 8]),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
