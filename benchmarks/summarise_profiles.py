@@ -19,8 +19,9 @@ from collections import defaultdict
 
 
 def find(root, pattern):
-    hits = sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
-    return hits[0] if hits else None
+    """Newest match: gpurun merges into gpurun_out/ without deleting earlier runs."""
+    hits = glob.glob(os.path.join(root, "**", pattern), recursive=True)
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def counter_means(path, counter):
