@@ -748,3 +748,77 @@ def test_sos_alignment_paths(osz):
     ref = sps.sosfilt(sos, aligned.cpu().numpy(), axis=-1)
     y = torch.cat(list(osz.sosfilt(producer(view, n // 2, -1), sos, -1)), -1).cpu().numpy()
     assert rel_err(y, ref) < RTOL
+
+
+def test_long_stream_cfg3_direct(osz):
+    """cfg-3 chain at the BASELINE chunksize (2^20) over a long stream, checked
+    DIRECTLY against the CPU oracle on a 256-channel device-resident signal for
+    three of its channels: 1024-tap FIR ('same') -> 6-section band-pass
+    sosfiltfilt, 12 chunks (1.26e7 samples per channel), through the public
+    producer API with CUDA tensors.  The oracle side uses SciPy's FFT
+    convolution for the FIR (the direct form would take minutes) and the
+    chunk-local zero-phase definition of the reference for the IIR."""
+    import scipy.signal as sps
+    import torch
+    from functools import partial
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    C, cs, nchunks = 256, 1 << 20, 12
+    n = cs * nchunks
+    h = sps.firwin(1024, 0.2)
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    x = torch.cat([dev.synth_normal(C, cs, seed=11, n0=k * cs) for k in range(nchunks)], 1)
+    fir = producer(partial(osz.oaconvolve, producer(x, cs, -1), h, -1, "same"), cs, -1,
+                   shape=tuple(x.shape))
+    pick = [0, 101, 255]
+    got = []
+    for out in osz.sosfiltfilt(fir, sos, -1):
+        assert out.is_cuda
+        got.append(out[pick].cpu().numpy())
+    got = np.concatenate(got, -1)
+    assert got.shape == (3, n)
+    xh = x[pick].cpu().numpy()
+    del x
+    fir_ref = np.stack([sps.fftconvolve(row, h, mode="same") for row in xh])
+    ref = orc.sosfiltfilt(fir_ref, sos, cs)
+    assert rel_err(got, ref) < RTOL
+
+
+def test_long_stream_cfg4_cfg5_direct(osz):
+    """cfg-4 and cfg-5 at their BASELINE parameters over a long device-resident
+    stream, checked DIRECTLY against the CPU oracle for three of 256 channels.
+    cfg-4: psd(x, fs=4096, resolution=1.0, hann, 50 %, constant, density).
+    cfg-5: downsample(x, M=5, fs=20480, chunksize=2^20) -> stft(y, fs=4096,
+    resolution=1.0, boundary, padded) as a producer of segments."""
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    from openseize_amd.resampling.resampling import downsample
+    from openseize_amd.spectra.estimators import psd, stft
+    C, cs, nchunks = 256, 1 << 20, 4
+    n = cs * nchunks
+    x = torch.cat([dev.synth_normal(C, cs, seed=12, n0=k * cs) for k in range(nchunks)], 1)
+    pick = [0, 77, 255]
+    xh = x[pick].cpu().numpy()
+    # ---- cfg-4
+    cnt, freqs, p = psd(x, fs=4096, axis=-1, resolution=1.0, window="hann", overlap=0.5,
+                        detrend="constant", scaling="density")
+    p = p.cpu().numpy() if hasattr(p, "cpu") else np.asarray(p)
+    rc, rf, rp = orc.psd(xh, 4096, resolution=1.0)
+    assert cnt == rc == (n - 4096) // 2048 + 1
+    assert np.array_equal(freqs, rf)
+    assert rel_err(p[pick], rp) < RTOL
+    # ---- cfg-5
+    y = downsample(producer(x, cs, -1), M=5, fs=20480, chunksize=cs, axis=-1)
+    f, t, pro = stft(y, fs=4096, axis=-1, resolution=1.0, window="hann", overlap=0.5,
+                     detrend="constant", scaling="density", boundary=True, padded=True,
+                     asarray=False)
+    yh = orc.polyphase_resample(xh, 1, 5, orc.resample_filter(1, 5, 20480))
+    rf2, rt2, rX = orc.stft(yh, 4096, resolution=1.0)
+    assert np.array_equal(f, rf2) and np.allclose(t, rt2, rtol=0, atol=1e-12)
+    nseg = 0
+    for k, seg in enumerate(pro):
+        seg = seg[pick].cpu().numpy() if hasattr(seg, "cpu") else np.asarray(seg)[pick]
+        assert np.max(np.abs(seg - rX[..., k])) < RTOL * np.max(np.abs(rX))
+        nseg += 1
+    assert nseg == rX.shape[-1]
