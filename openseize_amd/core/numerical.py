@@ -24,7 +24,7 @@ from openseize_amd import _device as dev
 from openseize_amd import _lib
 from openseize_amd.core import protools
 from openseize_amd.core.arraytools import normalize_axis, slice_along_axis
-from openseize_amd.core.producer import producer
+from openseize_amd.core.producer import ArrayProducer, producer
 
 
 # ---------------------------------------------------------------------------
@@ -386,6 +386,30 @@ def periodogram(arr, fs, nfft=None, window="hann", axis=-1,
                      _lib.SPEC_PSD_SEGMENTS)
 
 
+def _batched(pro, axis, nch):
+    """Joins consecutive produced arrays into pieces of up to ~2^25 elements
+    before they go to the device.  The estimators force chunksize = int(fs)
+    (spectra/estimators.py:141), i.e. a launch per second of signal; the
+    segment sequence -- and so every estimate -- does not depend on where the
+    stream is cut, so the cuts are moved, not the result."""
+    target = max(1, min(1 << 20, (1 << 25) // max(int(nch), 1)))
+    if isinstance(pro, ArrayProducer):
+        # an in-memory array: larger views of it, no copies
+        n = pro.data.shape[axis]
+        for start in range(0, n, target):
+            yield slice_along_axis(pro.data, start, min(start + target, n), axis=axis)
+        return
+    buf, count = [], 0
+    for arr in pro:
+        buf.append(arr)
+        count += arr.shape[axis]
+        if count >= target:
+            yield buf[0] if len(buf) == 1 else dev.concatenate(buf, axis)
+            buf, count = [], 0
+    if buf:
+        yield buf[0] if len(buf) == 1 else dev.concatenate(buf, axis)
+
+
 def _spectra_estimatives(pro, fs, nfft, window, overlap, axis, detrend,
                          scaling, func, **kwargs):
     """One estimate per nfft-sample segment, ``stride = nfft - int(nfft *
@@ -402,7 +426,7 @@ def _spectra_estimatives(pro, fs, nfft, window, overlap, axis, detrend,
     spec = dev.SpecStream(nfft, nfft, stride, coeffs, scale, detrend, mode,
                           layout.nch)
     try:
-        for arr in pro:
+        for arr in _batched(pro, layout.axis, layout.nch):
             x2d, host = layout.to2d(arr)
             if x2d.shape[1] == 0:
                 continue

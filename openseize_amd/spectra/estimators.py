@@ -32,7 +32,7 @@ def psd(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
                           _lib.SPEC_PSD_MEAN, layout.nch)
     host = True
     try:
-        for arr in pro:
+        for arr in nm._batched(pro, axis_n, layout.nch):
             x2d, host = layout.to2d(arr)
             if x2d.shape[1]:
                 spec.push(x2d)
