@@ -148,7 +148,12 @@ class Layout:
             t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
         t = torch.movedim(t, self.axis, -1)
         n = t.shape[-1]
-        return t.reshape(self.nch, n).contiguous(), host
+        t = t.reshape(self.nch, n)
+        # the C ABI takes a row pitch: a chunk that is a column range of a larger
+        # resident array (what ArrayProducer yields) goes in as the view it is
+        if n > 0 and (t.stride(1) != 1 or t.stride(0) < n):
+            t = t.contiguous()
+        return t, host
 
     def from2d(self, t, host):
         """(nch, m) tensor -> array of the original kind with the sample axis
@@ -275,10 +280,10 @@ class FirStream(_Handle):
             skip, stream_ptr()))
         return y
 
-    def flush(self, device, skip=0, drop=0):
+    def flush(self, device, skip=0, drop=0, out=None):
         cnt = self.ntaps - 1 - skip - drop
-        y = torch.empty((self.nch, max(cnt, 0)), dtype=torch.float64,
-                        device=device)
+        y = out if out is not None else torch.empty(
+            (self.nch, max(cnt, 0)), dtype=torch.float64, device=device)
         if cnt > 0:
             _lib.check(self.lib.osz_fir_flush(self.h, ptr(y), y.stride(0), skip,
                                               drop, stream_ptr()))

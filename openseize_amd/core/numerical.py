@@ -111,7 +111,19 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
             f"along axis {axis}, fewer than the {wlen} window taps")
     layout = dev.Layout(pro.shape, axis)
     fir = dev.FirStream(window, layout.nch)
+    # Output pieces are written straight into buffers as long as the incoming
+    # chunks: the left cut shifts the output against the input by `lcut`
+    # samples, so every incoming chunk is pushed in two parts -- its head
+    # completes the open buffer, its body starts the next one.  Downstream
+    # re-chunking (GenProducer) then finds chunk-aligned arrays and copies
+    # nothing; for a resident stream no sample is moved twice.
     pos, host, device = 0, True, "cuda"
+    cur, fill = None, 0                      # open output buffer and its filled columns
+    import torch
+
+    def emit(buf, cols):
+        return layout.from2d(buf if cols == buf.shape[1] else buf[:, :cols], host)
+
     try:
         for arr in pro:
             x2d, host = layout.to2d(arr)
@@ -120,14 +132,43 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
             if n == 0:
                 continue
             skip = min(max(lcut - pos, 0), n)
-            y = fir.push(x2d, skip)
             pos += n
-            if y.shape[1] > 0:
-                yield layout.from2d(y, host)
+            done = 0                          # input columns of this chunk already pushed
+            if cur is not None:
+                part = min(n - skip, cur.shape[1] - fill)
+                if part > 0 or skip > 0:
+                    fir.push(x2d[:, :skip + part], skip, out=cur[:, fill:fill + part])
+                    fill += part
+                    done = skip + part
+                    skip = 0
+                if fill == cur.shape[1]:
+                    yield emit(cur, fill)
+                    cur, fill = None, 0
+            if done < n:
+                if cur is None:
+                    cur = torch.empty((layout.nch, n), dtype=torch.float64, device=device)
+                    fill = 0
+                cnt = n - done - skip
+                fir.push(x2d[:, done:], skip, out=cur[:, fill:fill + cnt])
+                fill += cnt
+                if fill == cur.shape[1]:
+                    yield emit(cur, fill)
+                    cur, fill = None, 0
         if pos > 0:
-            tail = fir.flush(device, skip=min(max(lcut - pos, 0), wlen - 1),
-                             drop=rcut)
-            if tail.shape[1] > 0:
+            skip = min(max(lcut - pos, 0), wlen - 1)
+            cnt = max(wlen - 1 - skip - rcut, 0)
+            if cur is not None and cnt > 0:
+                part = min(cnt, cur.shape[1] - fill)
+                if part > 0:
+                    fir.flush(device, skip=skip, drop=rcut + cnt - part,
+                              out=cur[:, fill:fill + part])
+                    fill += part
+                    skip += part
+                    cnt -= part
+            if cur is not None and fill > 0:
+                yield emit(cur, fill)
+            if cnt > 0:
+                tail = fir.flush(device, skip=skip, drop=rcut)
                 yield layout.from2d(tail, host)
     finally:
         fir.close()
