@@ -116,7 +116,8 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
     # samples, so every incoming chunk is pushed in two parts -- its head
     # completes the open buffer, its body starts the next one.  Downstream
     # re-chunking (GenProducer) then finds chunk-aligned arrays and copies
-    # nothing; for a resident stream no sample is moved twice.
+    # nothing; for a resident stream no sample is moved twice.  (Host-fed
+    # streams keep one push per chunk: their pieces cross PCIe anyway.)
     pos, host, device = 0, True, "cuda"
     cur, fill = None, 0                      # open output buffer and its filled columns
     import torch
@@ -133,6 +134,12 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
                 continue
             skip = min(max(lcut - pos, 0), n)
             pos += n
+            if host:
+                # host-fed: every piece goes back over PCIe as it is; one push per chunk
+                y = fir.push(x2d, skip)
+                if y.shape[1] > 0:
+                    yield layout.from2d(y, host)
+                continue
             done = 0                          # input columns of this chunk already pushed
             if cur is not None:
                 part = min(n - skip, cur.shape[1] - fill)
