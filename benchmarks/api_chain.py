@@ -32,10 +32,16 @@ def main():
 
     chain()
     torch.cuda.synchronize()
+    st0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     n = chain()
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    st1 = torch.cuda.memory_stats()
+    print("host-side issue time %.1f ms of %.1f ms; device allocations during the run: %d, frees: %d"
+          % (t_host * 1e3, dt * 1e3, st1["num_device_alloc"] - st0["num_device_alloc"],
+             st1["num_device_free"] - st0["num_device_free"]))
     print("API chain: %.2f ms per 256 x 2^20 chunk (%.1f Gsamples/s) over %d samples per channel"
           % (dt / nchunks * 1e3, C * n / dt / 1e9, n))
 
