@@ -21,6 +21,7 @@ def psd(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
     """Welch power spectrum (density) estimate.  chunksize is forced to
     ``int(fs)`` (estimators.py:141) and nfft = int(fs / resolution) (:144)."""
     pro = producer(data, chunksize=int(fs), axis=axis)
+    pro = nm._coarse(pro, int(np.prod(pro.shape)) // max(pro.shape[axis], 1))
     nfft = int(fs / resolution)
     freqs = np.fft.rfftfreq(nfft, 1 / fs)
     noverlap = int(nfft * overlap)
@@ -58,6 +59,7 @@ def stft(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
     ``asarray`` the per-segment estimates are stacked on a new last axis when
     they fit in memory (:279-282), else a producer is returned."""
     pro = producer(data, chunksize=int(fs), axis=axis)
+    pro = nm._coarse(pro, int(np.prod(pro.shape)) // max(pro.shape[axis], 1))
     nfft = int(fs / resolution)
     freqs, time, result = nm.stft(pro, fs, nfft, window, overlap, axis,
                                   detrend, scaling, boundary, padded)
