@@ -822,3 +822,27 @@ def test_long_stream_cfg4_cfg5_direct(osz):
         assert np.max(np.abs(seg - rX[..., k])) < RTOL * np.max(np.abs(rX))
         nseg += 1
     assert nseg == rX.shape[-1]
+
+
+def test_estimators_keep_producer_semantics(osz):
+    """psd / stft set chunksize = int(fs) on the caller's producer (reference
+    spectra/estimators.py:141) although the device work runs on a coarser copy;
+    a masked producer goes through the same path and equals the estimate of
+    the masked array."""
+    from openseize_amd.spectra.estimators import psd, stft
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((3, 40000))
+    pro = producer(x, 1000, -1)
+    cnt, f, p = psd(pro, fs=256, axis=-1, resolution=1.0)
+    assert pro.chunksize == 256
+    cnt2, f2, p2 = psd(x, fs=256, axis=-1, resolution=1.0)
+    assert cnt == cnt2 and rel_err(p, p2) < 1e-12
+    mask = rng.random(40000) > 0.3
+    mpro = producer(x, 1000, -1, mask=mask)
+    cm, fm, pm = psd(mpro, fs=256, axis=-1, resolution=1.0)
+    ca, fa, pa = psd(x[:, mask], fs=256, axis=-1, resolution=1.0)
+    assert mpro.chunksize == 256 and cm == ca and rel_err(pm, pa) < 1e-12
+    pro = producer(x, 1000, -1)
+    f, t, X = stft(pro, fs=256, axis=-1, resolution=1.0)
+    f2, t2, X2 = stft(x, fs=256, axis=-1, resolution=1.0)
+    assert pro.chunksize == 256 and np.array_equal(t, t2) and rel_err(X, X2) < 1e-12
