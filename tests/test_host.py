@@ -239,6 +239,28 @@ def test_library_exports_every_declared_symbol():
     assert lib.osz_version() >= 100
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/osz_hip.h is the C ABI: it must compile as strict C99 (no C++,
+    no torch types) and a C program must link against the library and call
+    through it without a GPU (osz_version / osz_last_error touch no device)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "osz_hip.h"\n'
+                   'int main(void) { printf("%d %s\\n", osz_version(), osz_last_error());'
+                   ' return osz_version() >= 100 ? 0 : 1; }\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic",
+                           "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-losz_hip", f"-Wl,-rpath,{libdir}",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 # ------------------------------------------------------------ EDF header / plan
 def test_edf_header_and_plan(golden):
     """Header parsing and record location of the EDF reader are pure host
