@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Randomised stress run of the public API against whole-array SciPy / NumPy
+(not part of the test suite: minutes, not seconds).  Hunts for geometry bugs:
+lengths around block / tile / chunk boundaries, odd chunk sizes, long filters,
+ragged last chunks, every mode and axis position.
+
+    python benchmarks/fuzz_gpu.py [iterations] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.signal as sps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+TOL = 1e-9
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return float("inf")
+    return float(np.max(np.abs(a - b))) / max(float(np.max(np.abs(b))), 1e-300) if a.size else 0.0
+
+
+def interesting_length(rng, lo, hi):
+    """Lengths clustered around multiples of the kernel geometries."""
+    if rng.random() < 0.6:
+        base = int(rng.choice([256, 512, 2048, 3072, 3073, 4096, 6144, 8192, 16384, 30000, 32768, 65536]))
+        n = base * int(rng.integers(1, 5)) + int(rng.integers(-3, 4))
+    else:
+        n = int(rng.integers(lo, hi))
+    return int(min(max(n, lo), hi))
+
+
+def case_array(rng, n):
+    ndim = int(rng.integers(1, 4))
+    axis = int(rng.integers(0, ndim))
+    shape = [int(rng.integers(1, 4)) for _ in range(ndim)]
+    shape[axis] = n
+    return rng.standard_normal(shape), axis
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    import torch
+    from openseize_amd import producer
+    from openseize_amd.core import numerical as nm
+    from openseize_amd.resampling import resampling as rs
+    from openseize_amd.spectra.estimators import psd
+    from openseize_amd.filtering.fir import Kaiser
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    rng = np.random.default_rng(seed)
+    designs = [sps.butter(2, 0.3, output="sos"), sps.butter(6, [0.05, 0.3], "bandpass", output="sos"),
+               sps.cheby1(5, 1, 0.3, output="sos"), sps.ellip(4, 0.5, 40, [0.1, 0.4], "bandpass", output="sos"),
+               sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
+    bad, t0 = 0, time.time()
+    for it in range(iters):
+        kind = it % 5
+        try:
+            if kind == 0:      # FIR
+                taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
+                n = interesting_length(rng, taps + 1, 70000)
+                x, axis = case_array(rng, n)
+                h = rng.standard_normal(taps) / np.sqrt(taps)
+                mode = ("full", "same", "valid")[int(rng.integers(0, 3))]
+                cs = int(rng.integers(max(taps // 8, 1), n + 100))
+                dev_in = rng.random() < 0.5
+                src = torch.from_numpy(x).cuda() if dev_in else x
+                out = list(nm.oaconvolve(producer(src, cs, axis), h, axis, mode))
+                y = np.concatenate([o.cpu().numpy() if dev_in else o for o in out], axis)
+                ref = np.apply_along_axis(lambda r: sps.fftconvolve(r, h, mode=mode), axis, x)
+                e, what = rel(y, ref), f"fir taps={taps} n={n} shape={x.shape} axis={axis} mode={mode} cs={cs} dev={dev_in}"
+            elif kind == 1:    # sosfilt
+                n = interesting_length(rng, 50, 80000)
+                x, axis = case_array(rng, n)
+                sos = designs[int(rng.integers(0, len(designs)))]
+                cs = int(rng.integers(10, n + 100))
+                y = np.concatenate(list(nm.sosfilt(producer(x, cs, axis), sos, axis)), axis)
+                e, what = rel(y, sps.sosfilt(sos, x, axis=axis)), f"sosfilt n={n} shape={x.shape} axis={axis} cs={cs}"
+            elif kind == 2:    # sosfiltfilt (chunk-local oracle)
+                n = interesting_length(rng, 200, 80000)
+                x, axis = case_array(rng, n)
+                sos = designs[int(rng.integers(0, len(designs)))]
+                cs = int(rng.integers(100, n + 100))
+                y = np.concatenate(list(nm.sosfiltfilt(producer(x, cs, axis), sos, axis)), axis)
+                x2 = np.moveaxis(x, axis, -1)
+                ref = orc.sosfiltfilt(x2.reshape(-1, n), sos, cs).reshape(x2.shape)
+                e, what = rel(np.moveaxis(y, axis, -1), ref), f"sosfiltfilt n={n} shape={x.shape} axis={axis} cs={cs}"
+            elif kind == 3:    # resample
+                L, M = [(1, 2), (1, 5), (1, 10), (1, 20), (2, 1), (3, 1), (3, 2), (2, 7), (5, 3), (4, 25), (7, 5)][int(rng.integers(0, 11))]
+                n = interesting_length(rng, 12000, 90000)
+                x, axis = case_array(rng, n)
+                cs = int(rng.integers(3000, 40000))
+                y = rs.resample(x, L, M, 5000, cs, axis)
+                fc = 5000 / (2 * max(L, M))
+                h = Kaiser(fc - fc / 10, fc + fc / 10, 5000, gpass=0.1, gstop=40).coeffs
+                e, what = rel(y, sps.resample_poly(x, L, M, axis=axis, window=h)), f"resample {L}/{M} n={n} shape={x.shape} axis={axis} cs={cs}"
+            else:              # psd
+                fs = float(rng.choice([250, 500, 1000, 4096]))
+                res = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
+                nfft = int(fs / res)
+                n = interesting_length(rng, 3 * nfft, 120000)
+                x, axis = case_array(rng, n)
+                ov = float(rng.choice([0.0, 0.25, 0.5, 0.75]))
+                det = ("constant", "linear")[int(rng.integers(0, 2))]
+                sc = ("density", "spectrum")[int(rng.integers(0, 2))]
+                win = ("hann", "hamming", "boxcar")[int(rng.integers(0, 3))]
+                cnt, f, p = psd(x, fs, axis=axis, resolution=res, window=win, overlap=ov, detrend=det, scaling=sc)
+                _, pr = sps.welch(x, fs, window=win, nperseg=nfft, noverlap=int(nfft * ov), detrend=det,
+                                  scaling=sc, axis=axis)
+                e, what = rel(p, pr), f"psd fs={fs} res={res} n={n} shape={x.shape} axis={axis} ov={ov} {det} {sc} {win}"
+        except Exception as exc:   # noqa: BLE001 - report and continue
+            e, what = float("inf"), f"kind {kind} raised {type(exc).__name__}: {exc}"
+        if not e < (1e-8 if kind == 4 else TOL):
+            bad += 1
+            print(f"FAIL it={it} err={e:.3e} {what}", flush=True)
+        if (it + 1) % 50 == 0:
+            print(f"{it + 1} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
+    print(f"done: {iters} cases, {bad} failures")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
