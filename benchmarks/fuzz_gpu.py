@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 5
+        kind = it % 9
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -101,7 +101,54 @@ def main():
                 fc = 5000 / (2 * max(L, M))
                 h = Kaiser(fc - fc / 10, fc + fc / 10, 5000, gpass=0.1, gstop=40).coeffs
                 e, what = rel(y, sps.resample_poly(x, L, M, axis=axis, window=h)), f"resample {L}/{M} n={n} shape={x.shape} axis={axis} cs={cs}"
-            else:              # psd
+            elif kind == 5:    # stft against the oracle's restatement
+                from openseize_amd.spectra.estimators import stft
+                fs = float(rng.choice([250, 500, 1000]))
+                res = float(rng.choice([0.5, 1.0, 2.0]))
+                nfft = int(fs / res)
+                n = interesting_length(rng, 3 * nfft, 40000)
+                x = rng.standard_normal((int(rng.integers(1, 4)), n))
+                ov = float(rng.choice([0.25, 0.5, 0.75]))
+                b, pd_ = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+                det = ("constant", "linear")[int(rng.integers(0, 2))]
+                f, t, X = stft(x, fs, axis=-1, resolution=res, overlap=ov, detrend=det, boundary=b, padded=pd_)
+                rf, rt, rX = orc.stft(x, fs, resolution=res, overlap=ov, detrend=det, boundary=b, padded=pd_)
+                e = max(rel(X, rX), 0.0 if np.allclose(t, rt, rtol=0, atol=1e-12) else float("inf"))
+                what = f"stft fs={fs} res={res} n={n} ov={ov} boundary={b} padded={pd_} {det}"
+            elif kind == 6:    # masked producer -> sosfilt, device tensors
+                n = interesting_length(rng, 500, 60000)
+                x = rng.standard_normal((int(rng.integers(1, 5)), n))
+                mask = rng.random(n) > rng.random() * 0.8
+                if mask.sum() < 50:
+                    mask[:50] = True
+                sos = designs[int(rng.integers(0, len(designs)))]
+                cs = int(rng.integers(100, n + 10))
+                dev_in = rng.random() < 0.5
+                src = torch.from_numpy(x).cuda() if dev_in else x
+                out = list(nm.sosfilt(producer(src, cs, -1, mask=mask), sos, -1))
+                y = np.concatenate([o.cpu().numpy() if dev_in else o for o in out], -1)
+                e, what = rel(y, sps.sosfilt(sos, x[:, mask], axis=-1)), f"masked sosfilt n={n} kept={int(mask.sum())} cs={cs} dev={dev_in}"
+            elif kind == 7:    # transfer-function (ba) filters: lfilter and filtfilt
+                n = interesting_length(rng, 500, 60000)
+                x = rng.standard_normal((int(rng.integers(1, 4)), n))
+                order = int(rng.choice([1, 2, 3, 4, 6]))
+                b_, a_ = sps.butter(order, float(rng.uniform(0.05, 0.6)))
+                cs = int(rng.integers(200, n + 10))
+                y = np.concatenate(list(nm.lfilter(producer(x, cs, -1), (b_, a_), -1)), -1)
+                e1 = rel(y, sps.lfilter(b_, a_, x, axis=-1))
+                z = np.concatenate(list(nm.filtfilt(producer(x, cs, -1), (b_, a_), -1)), -1)
+                e2 = rel(z, orc.filtfilt(x, (b_, a_), cs))
+                e, what = max(e1 / 10, e2 / 100), f"ba order={order} n={n} cs={cs} (lfilter {e1:.1e}, filtfilt {e2:.1e})"
+            elif kind == 8:    # sosfilt with a user zi, chunked == whole
+                n = interesting_length(rng, 300, 50000)
+                x = rng.standard_normal((int(rng.integers(1, 4)), n))
+                sos = designs[int(rng.integers(0, len(designs)))]
+                zi = rng.standard_normal((sos.shape[0], x.shape[0], 2))
+                cs = int(rng.integers(50, n + 10))
+                y = np.concatenate(list(nm.sosfilt(producer(x, cs, -1), sos, -1, zi=zi)), -1)
+                ref, _ = sps.sosfilt(sos, x, axis=-1, zi=zi)
+                e, what = rel(y, ref), f"sosfilt zi n={n} cs={cs}"
+            elif kind == 4:    # psd
                 fs = float(rng.choice([250, 500, 1000, 4096]))
                 res = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
                 nfft = int(fs / res)
@@ -117,7 +164,7 @@ def main():
                 e, what = rel(p, pr), f"psd fs={fs} res={res} n={n} shape={x.shape} axis={axis} ov={ov} {det} {sc} {win}"
         except Exception as exc:   # noqa: BLE001 - report and continue
             e, what = float("inf"), f"kind {kind} raised {type(exc).__name__}: {exc}"
-        if not e < (1e-8 if kind == 4 else TOL):
+        if not e < (1e-8 if kind in (4, 5) else TOL):
             bad += 1
             print(f"FAIL it={it} err={e:.3e} {what}", flush=True)
         if (it + 1) % 50 == 0:
