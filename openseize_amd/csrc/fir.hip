@@ -518,8 +518,11 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
                          double *y, int64_t ldy, int64_t skip, int accum, hipStream_t st) {
     const int wm1 = pt.ntaps - 1;
     const int64_t nblocks = (n + pt.step - 1) / pt.step;
-    // run length: enough workgroups to fill 256 CUs x 2, runs of an even number of blocks
-    int64_t R = (nblocks * h->nch) / 2048;
+    // run length: long runs (every workgroup pays for its twiddle loads, its tail
+    // and its seam) as long as about 3/4 of the 512 workgroup slots stay busy --
+    // measured at 16..256 channels, runs of an even number of blocks
+    int64_t R = (nblocks * h->nch) / 384;
+    if (const char *e = getenv("OSZ_FIR_R")) R = atoi(e);   // tuning knob: blocks per run
     if (R > 32) R = 32;
     if (R < 2) R = 2;
     R &= ~1LL;

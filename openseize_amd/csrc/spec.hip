@@ -507,8 +507,10 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
     OSZ_REQUIRE(nseg == 0 || h->mode == OSZ_SPEC_PSD_MEAN || out, "osz_spec_push: null output");
     if (nseg > 0 && h->fused) {
         const int64_t npairs = (nseg + 1) / 2;
-        // run length: enough workgroups to fill the chip, long runs for L2 reuse
-        int64_t R = (npairs * h->nch) / 2048;
+        // run length: long runs (a workgroup reloads its twiddles and window and
+        // publishes partial sums once per run) while ~512 workgroups remain
+        int64_t R = (npairs * h->nch) / 512;
+        if (const char *e = getenv("OSZ_SPEC_R")) R = atoi(e);   // tuning knob: pairs per run
         if (R > 32) R = 32;
         if (R < 1) R = 1;
         const int64_t nruns = (npairs + R - 1) / R;
