@@ -973,7 +973,13 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
     bw.n = na;
     if (sos_lean() && h->warm_len == tile && (nx / tile) >= 8 && (na / tile) >= 8) {
         // lean bodies: both passes cut into time segments, 3 workgroups per CU
+        // at least four segments per pass: several rounds of the 768 resident
+        // workgroups even out the tail (measured 96..512 channels; with one
+        // segment per pass, >= 384 channels, the launch fell back to the
+        // two-workgroups-per-CU body and lost 7 %)
         int nseg = (768 + 2 * h->nch - 1) / (2 * h->nch);
+        if (nseg < 4) nseg = 4;
+        if (const char *e = getenv("OSZ_SOS_DUAL_SEGS")) nseg = atoi(e);   // tuning knob
         const int64_t tmin = (nx < na ? nx : na) / tile;
         if (nseg > tmin / 4) nseg = (int)(tmin / 4);
         if (nseg >= 2) {
