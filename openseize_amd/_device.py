@@ -85,6 +85,15 @@ def sqrt(a):
     return torch.sqrt(a) if is_tensor(a) else np.sqrt(a)
 
 
+def to_complex(re, im):
+    """re + 1j * im as a complex128 array of the operands' kind."""
+    if is_tensor(re) or is_tensor(im):
+        re = re if is_tensor(re) else torch.from_numpy(np.ascontiguousarray(re)).to(im.device)
+        im = im if is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im)).to(re.device)
+        return torch.complex(re.to(torch.float64), im.to(torch.float64))
+    return np.asarray(re, dtype=np.float64) + 1j * np.asarray(im, dtype=np.float64)
+
+
 def absolute(a):
     return torch.abs(a) if is_tensor(a) else np.abs(a)
 

@@ -7,11 +7,9 @@ memory kind they live in.
 """
 
 import abc
-
-import numpy as np
+from functools import partial
 
 from openseize_amd import _device as dev
-from openseize_amd.core import protools
 from openseize_amd.core.producer import producer
 from openseize_amd.filtering.special import Hilbert
 
@@ -50,12 +48,21 @@ class Transform(abc.ABC):
 
 
 class Analytic(Transform):
-    """x + i H(x) with H the type-III Kaiser Hilbert FIR of
-    ``filtering.special.Hilbert`` (transition ``width`` around 0 and Nyquist)."""
+    """The analytic signal x + i H(x), H being the type-III Kaiser Hilbert FIR
+    of ``filtering.special.Hilbert`` with transition ``width`` around 0 and
+    Nyquist.  Real and imaginary parts are produced chunk by chunk from the
+    same source and joined into one complex chunk on the memory kind they
+    live in."""
 
     def estimate(self, data, *, width, gpass=0.01, gstop=60, **kwargs):
-        hilbert = Hilbert(width, fs=self.fs, gpass=gpass, gstop=gstop)
-        real = producer(data, self.chunksize, self.axis)
-        imag = hilbert(real, self.chunksize, self.axis)
-        imag = protools.multiply(imag, complex(0, 1))
-        return protools.add(real, imag)
+        source = producer(data, self.chunksize, self.axis)
+        quadrature = Hilbert(width, fs=self.fs, gpass=gpass, gstop=gstop)(
+            source, self.chunksize, self.axis)
+        return producer(partial(_join_complex, source, quadrature), self.chunksize,
+                        self.axis, shape=source.shape)
+
+
+def _join_complex(real_pro, imag_pro):
+    """Generator of re + 1j * im over two equally chunked producers."""
+    for re, im in zip(real_pro, imag_pro):
+        yield dev.to_complex(re, im)
