@@ -20,7 +20,7 @@
 //     pushes (the carried state of the iterator);
 //   - HBM: every sample is read once (8 B, consecutive lanes -> consecutive
 //     samples) and written once (8 B): 16 B per channel-sample; the filter
-//     spectrum H (64 KB) stays L2 resident, the twiddles live in registers.
+//     spectrum H (64 KB) and the twiddles live in registers for a whole run.
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -89,8 +89,8 @@ __host__ __device__ __forceinline__ int64_t fir_run_start(int64_t r, int64_t nbl
 // and after the stretch of whole pairs so that their predicated code does not
 // weigh on the register allocation of the hot loop.
 // Measured and rejected on this kernel (profiles/README.md): requesting the
-// whole filter spectrum before the second barrier (the 64 extra live
-// registers spill), requesting the NEXT pair's samples after the third
+// filter spectrum per pair (before the second barrier or at its use) instead
+// of keeping it resident, requesting the NEXT pair's samples after the third
 // barrier (+6 % time), twiddles loaded from the tables per pass (+13 %),
 // running the FIR of chunk k+1 beside the IIR step of chunk k on a second
 // stream (+5 %, benchmarks/overlap_probe.py).
@@ -107,6 +107,7 @@ struct FirPair {
     C2 *L;
     fft::cube::TwPow tw1, tw2;
     double cr[NT_];
+    double Hr[HPRE < 0 ? 16 : 1], Hi[HPRE < 0 ? 16 : 1];   // HPRE < 0: spectrum resident
 #ifdef OSZ_FIR_STAMPS
     unsigned long long stamp_acc[12], stamp_last;
 #endif
@@ -126,11 +127,10 @@ struct FirPair {
         __syncthreads();
         OSZ_FSTAMP(2);   // barrier 1
         fft::cube::f2(t, re, im, tw2, L);
-        // HPRE of the 16 filter-spectrum bins are requested before the barrier
-        // (all 16 spill a few registers; 14 measured best, 3 % over 4)
+        // HPRE > 0: that many filter-spectrum bins are requested before the barrier
         double hr[HPRE > 0 ? HPRE : 1], hi[HPRE > 0 ? HPRE : 1];
 #pragma unroll
-        for (int r = 0; r < HPRE; ++r) {
+        for (int r = 0; r < (HPRE > 0 ? HPRE : 0); ++r) {
             const int k = t + 256 * fft::dr(r);
             hr[r] = a.H[2 * k];
             hi[r] = a.H[2 * k + 1];
@@ -143,7 +143,8 @@ struct FirPair {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = t + 256 * fft::dr(r);
-            if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
+            if (HPRE < 0) fft::cube::cmul(re[r], im[r], Hr[HPRE < 0 ? r : 0], Hi[HPRE < 0 ? r : 0]);
+            else if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
             else fft::cube::cmul(re[r], im[r], a.H[2 * k], a.H[2 * k + 1]);
         }
         OSZ_FSTAMP(6);   // filter spectrum: loads + multiply
@@ -262,9 +263,12 @@ struct FirPair {
     }
 };
 
-// bins of the filter spectrum requested before the second barrier: as many
-// as fit without spilling (the carried tail takes 2 (16 - NR) registers)
-template <int NR, int HPRE = (NR + 2 < 14 ? NR + 2 : 14)>
+// HPRE < 0 (shipped): the 16 filter-spectrum bins of this thread stay in
+// registers for the whole run -- the passes other than pass 3 have the room,
+// and the hot loop then issues no table load at all (-3.5 % time against
+// loading 14 of them per pair before the second barrier, HPRE = 14; HPRE = 0
+// loads them where they are used).
+template <int NR, int HPRE = -1>
 __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     extern __shared__ fft::cube::C2 cube_lds[];
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
@@ -274,6 +278,14 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     fft::cube::tw_load(t, a.tb, P.tw1, P.tw2);
 #pragma unroll
     for (int j = 0; j < 16 - NR; ++j) P.cr[j] = 0.0;
+    if (HPRE < 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = t + 256 * fft::dr(r);
+            P.Hr[HPRE < 0 ? r : 0] = a.H[2 * k];
+            P.Hi[HPRE < 0 ? r : 0] = a.H[2 * k + 1];
+        }
+    }
 
     int64_t blk = blk0;
     for (; blk < P.blk1 && !P.whole(blk); blk += 2) P.any_pair(blk);
