@@ -90,8 +90,9 @@ __host__ __device__ __forceinline__ int64_t fir_run_start(int64_t r, int64_t nbl
 // weigh on the register allocation of the hot loop.
 // Measured and rejected on this kernel (profiles/README.md): requesting the
 // filter spectrum per pair (before the second barrier or at its use) instead
-// of keeping it resident, requesting the NEXT pair's samples after the third
-// barrier (+6 % time), twiddles loaded from the tables per pass (+13 %),
+// of keeping it resident, requesting the NEXT pair's samples ahead (after the
+// third barrier: +6 % time; before inverse pass 1 with the spectrum resident:
+// 162 spilled registers), twiddles loaded from the tables per pass (+13 %),
 // running the FIR of chunk k+1 beside the IIR step of chunk k on a second
 // stream (+5 %, benchmarks/overlap_probe.py).
 template <int NR, int HPRE>
