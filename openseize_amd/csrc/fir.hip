@@ -666,11 +666,19 @@ int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch) {
         const int off = nparts == 1 ? 0 : q * kFirPart;
         const int len = nparts == 1 ? ntaps : (ntaps - off < kFirPart ? ntaps - off : kFirPart);
         rc = fir_build_part(p->parts[q], taps + off, len, nch);
-        if (rc) return rc;
+        if (rc) {
+            p->parts.resize(q + 1);   // the parts built so far (null pointers are fine to free)
+            (void)osz_fir_destroy(p);
+            return rc;
+        }
     }
     if (nparts > 1) {
         p->dlen = (int64_t)(nparts - 1) * kFirPart;
-        OSZ_HIP(hipMalloc(&p->dD, sizeof(double) * (size_t)nch * p->dlen));
+        if (hipMalloc(&p->dD, sizeof(double) * (size_t)nch * p->dlen) != hipSuccess) {
+            (void)osz_fir_destroy(p);
+            return fail(OSZ_ERR_NOMEM, "osz_fir_create: deferred sums (%lld doubles)",
+                        (long long)nch * p->dlen);
+        }
         OSZ_HIP(hipMemset(p->dD, 0, sizeof(double) * (size_t)nch * p->dlen));
     }
     *h = p;
