@@ -96,6 +96,27 @@ def main():
     out.append({"workload": "K7 take 256 ch x 2^20, every 2nd sample",
                 "ms_per_chunk": dt * 1e3, "Msamples_s": CH * N / dt / 1e6,
                 "algorithmic_GBps": 12 * CH * N / dt / 1e9})
+    # FIR feeding the forward SOS pass: one fused kernel (16 B / sample) against
+    # the two separate kernels (32 B / sample), cfg-3 filters
+    hfir = sps.firwin(1024, 0.2)
+    sosb = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    fir, iir = dev.FirStream(hfir, CH), dev.SosStream(sosb, CH)
+    fo, so = torch.empty_like(x), torch.empty_like(x)
+    dt = timed(lambda: dev.chain_forward(fir, iir, x, out=so), 10)
+    out.append({"workload": "fused FIR(1024) -> forward SOS(6), 256 ch x 2^20 (osz_chain_forward)",
+                "ms_per_chunk": dt * 1e3, "Msamples_s": CH * N / dt / 1e6,
+                "algorithmic_GBps": 16 * CH * N / dt / 1e9})
+
+    def separate():
+        fir.push(x, 0, out=fo)
+        iir.forward(fo, out=so)
+    dt = timed(separate, 10)
+    out.append({"workload": "separate FIR(1024), forward SOS(6), 256 ch x 2^20",
+                "ms_per_chunk": dt * 1e3, "Msamples_s": CH * N / dt / 1e6,
+                "algorithmic_GBps": 32 * CH * N / dt / 1e9})
+    fir.close()
+    iir.close()
+
     # practical ceiling: device-to-device copy of one chunk (read 8 + write 8 B)
     y = torch.empty_like(x)
     dt = timed(lambda: y.copy_(x), 10)

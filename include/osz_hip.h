@@ -155,6 +155,22 @@ int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n,
 int osz_fir_flush(osz_fir_t h, double *y, int64_t ldy, int64_t skip,
                   int64_t drop, void *stream);
 
+/* ---- K1 + K2 fused: FIR feeding the forward pass of a cascade --------- */
+/*
+ * The forward half of the chain the reference builds from two generators --
+ * oaconvolve (core/numerical.py:158-298, 'full' stream, no left cut) into
+ * sosfilt / the forward pass of sosfiltfilt (:301-335, :374-386) -- in one
+ * kernel: f = sosfilt(fir(x)) for the next n samples of every channel, both
+ * handles' carried states advanced exactly as osz_fir_push(skip = 0) followed
+ * by osz_sos_forward would.  The FIR output never reaches HBM (16 instead of
+ * 32 B per channel-sample).  Whole pairs of FIR blocks go through the fused
+ * kernel, the ragged end of the chunk through the separate kernels.  Filters
+ * the fused kernel does not take (partitioned FIRs; fewer than 4 block pairs)
+ * return OSZ_ERR_UNSUPPORTED unless n is less than one SOS tile.
+ */
+int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,
+                      int64_t n, double *f, int64_t ldf, void *stream);
+
 /* ---- K4: polyphase rational resampler --------------------------------- */
 /*
  * Replaces scipy.signal.resample_poly(padded, L, M, window=h) as called at

@@ -299,6 +299,17 @@ class FirStream(_Handle):
         return y
 
 
+def chain_forward(fir, sos, x2d, out=None):
+    """f = sosfilt(fir(x)) for the next chunk in one fused launch (C ABI:
+    osz_chain_forward); both iterators' carried states advance."""
+    n = x2d.shape[1]
+    f = out if out is not None else torch.empty((fir.nch, n), dtype=torch.float64,
+                                                 device=x2d.device)
+    _lib.check(fir.lib.osz_chain_forward(fir.h, sos.h, ptr(x2d), x2d.stride(0), n, ptr(f),
+                                         max(f.stride(0), 1), stream_ptr()))
+    return f
+
+
 class PolyStream(_Handle):
     """One iterator's polyphase resampler state (C ABI: osz_poly_*)."""
     _destroy = "osz_poly_destroy"

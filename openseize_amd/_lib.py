@@ -71,6 +71,7 @@ SIGNATURES = {
     "osz_sosfiltfilt_step": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64,
                                             c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                                             c_vp, c_i64, c_vp]),
+    "osz_chain_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "osz_fir_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_dp, ctypes.c_int,
                                       ctypes.c_int]),
     "osz_fir_destroy": (ctypes.c_int, [c_vp]),

@@ -28,241 +28,10 @@
 
 #include "common.h"
 #include "fft4096.h"
+#include "fir_pair.h"
+#include "handles.h"
 
 namespace osz {
-
-// In-kernel phase stamps for the diagnostic build only
-// (benchmarks/fir_stamps.hip defines OSZ_FIR_STAMPS); the library build has none.
-#ifdef OSZ_FIR_STAMPS
-__device__ unsigned long long *g_fir_stamps = nullptr;   // [waves][12] cycle sums
-__device__ unsigned long long g_fir_clock[2];            // {s_memtime, s_memrealtime} ticks of one run
-#define OSZ_FSTAMP(slot)                                                             \
-    do {                                                                             \
-        unsigned long long now_;                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                           \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
-        __builtin_amdgcn_sched_barrier(0);                                           \
-        stamp_acc[slot] += now_ - stamp_last;                                        \
-        stamp_last = now_;                                                           \
-    } while (0)
-#else
-#define OSZ_FSTAMP(slot) do { } while (0)
-#endif
-
-constexpr int kFirMaxTaps = 2049;  // NFFT - ntaps + 1 >= ntaps - 1
-
-struct FirArgs {
-    const double *x;
-    double *y;
-    int64_t ldx, ldy, n, skip;
-    int wlen, step, R, nruns, accum;   // accum: y += (partitioned filters), else y =
-    int64_t nblocks;
-    const double *H;  // [4096][2], already divided by 4096
-    fft::Tables tb;
-    double *tails;    // [nch][nruns][wlen-1]
-};
-
-// Runs are balanced: run r owns the block PAIRS [r*npairs/nruns, (r+1)*npairs/nruns),
-// i.e. it starts at block 2*floor(r*npairs/nruns).  (A remainder lumped into the
-// last run makes that workgroup up to twice as long as the others and the
-// whole launch waits for it.)
-__host__ __device__ __forceinline__ int64_t fir_run_start(int64_t r, int64_t nblocks, int nruns) {
-    const int64_t npairs = (nblocks + 1) / 2;
-    const int64_t b = 2 * ((r * npairs) / nruns);
-    return b < nblocks ? b : nblocks;
-}
-
-// NR = rows of 256 samples per block (block length step = 256 NR, chosen by
-// the host as the largest multiple of 256 with step + ntaps - 1 <= 4096).
-// A workgroup walks its run pair by pair on the cube layout of fft4096.h
-// (interleaved complex, in-place exchanges, 64 KB of LDS): four barriers per
-// pair, 16-byte LDS accesses, twiddle powers resident in registers, and an
-// overlap that never leaves the registers: with whole blocks of 256 NR
-// samples, sample p = 256 j + t of a's tail (register row j + NR) meets b's
-// head at register row j of the SAME thread, and b's tail meets the next
-// pair's a the same way, so the carried tail is cr[j], 16 - NR doubles per
-// thread.  Which register rows carry samples is a compile-time fact there, so
-// loads, stores and the first butterfly stage (whose rows >= NR are literal
-// zeros) need no predication.  Ragged pairs (the first one of a push with a
-// left cut, the last one) pass their
-// tails through LDS, over the idle cube; they run in their own loops before
-// and after the stretch of whole pairs so that their predicated code does not
-// weigh on the register allocation of the hot loop.
-// Measured and rejected on this kernel (profiles/README.md): requesting the
-// filter spectrum per pair (before the second barrier or at its use) instead
-// of keeping it resident, requesting the NEXT pair's samples ahead (after the
-// third barrier: +6 % time; before inverse pass 1 with the spectrum resident:
-// 162 spilled registers), twiddles loaded from the tables per pass (+13 %),
-// running the FIR of chunk k+1 beside the IIR step of chunk k on a second
-// stream (+5 %, benchmarks/overlap_probe.py).
-template <int NR, int HPRE>
-struct FirPair {
-    using C2 = fft::cube::C2;
-    static constexpr int NT_ = 16 - NR;   // register rows of the tail (wm1 <= 256 NT_)
-
-    const FirArgs &a;
-    const int t, wm1;
-    const double *xr;
-    double *yr;
-    const int64_t blk1;
-    C2 *L;
-    fft::cube::TwPow tw1, tw2;
-    double cr[NT_];
-    double Hr[HPRE < 0 ? 16 : 1], Hi[HPRE < 0 ? 16 : 1];   // HPRE < 0: spectrum resident
-#ifdef OSZ_FIR_STAMPS
-    unsigned long long stamp_acc[12], stamp_last;
-#endif
-
-    __device__ __forceinline__ bool whole(int64_t blk) const {
-        return blk + 1 < blk1 && (blk + 2) * a.step <= a.n && blk * a.step >= a.skip;
-    }
-
-    // forward transform, filter, inverse transform of the pair in re/im
-    __device__ __forceinline__ void transform(double *re, double *im) {
-        // LDS slot numbers are recomputed per pair from an opaque copy of the
-        // thread index: hoisted out of the loop they would pin 33 registers
-        int t = this->t;
-        asm volatile("" : "+v"(t));
-        fft::cube::f1(t, re, im, tw1, L);
-        OSZ_FSTAMP(1);   // sample loads landed + pass 1 + stores
-        __syncthreads();
-        OSZ_FSTAMP(2);   // barrier 1
-        fft::cube::f2(t, re, im, tw2, L);
-        // HPRE > 0: that many filter-spectrum bins are requested before the barrier
-        double hr[HPRE > 0 ? HPRE : 1], hi[HPRE > 0 ? HPRE : 1];
-#pragma unroll
-        for (int r = 0; r < (HPRE > 0 ? HPRE : 0); ++r) {
-            const int k = t + 256 * fft::dr(r);
-            hr[r] = a.H[2 * k];
-            hi[r] = a.H[2 * k + 1];
-        }
-        OSZ_FSTAMP(3);   // pass 2
-        __syncthreads();
-        OSZ_FSTAMP(4);   // barrier 2
-        fft::cube::f3(t, re, im, L);
-        OSZ_FSTAMP(5);   // pass 3
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = t + 256 * fft::dr(r);
-            if (HPRE < 0) fft::cube::cmul(re[r], im[r], Hr[HPRE < 0 ? r : 0], Hi[HPRE < 0 ? r : 0]);
-            else if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
-            else fft::cube::cmul(re[r], im[r], a.H[2 * k], a.H[2 * k + 1]);
-        }
-        OSZ_FSTAMP(6);   // filter spectrum: loads + multiply
-        fft::cube::i3(t, re, im, L);
-        OSZ_FSTAMP(7);   // inverse pass 3
-        __syncthreads();
-        OSZ_FSTAMP(8);   // barrier 3
-        fft::cube::i2(t, re, im, tw2, L);
-        OSZ_FSTAMP(9);   // inverse pass 2
-        __syncthreads();
-        OSZ_FSTAMP(10);  // barrier 4
-        fft::cube::i1(t, re, im, tw1, L);
-    }
-
-    // a pair of whole blocks: no predication anywhere
-    __device__ __forceinline__ void fast_pair(int64_t blk) {
-        const int64_t start_a = blk * a.step;
-        double re[16], im[16];
-        const double *pa = xr + start_a + t;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            re[j] = j < NR ? pa[256 * j] : 0.0;
-            im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
-        }
-        OSZ_FSTAMP(0);   // sample loads issued (and the previous pair's stores)
-        transform(re, im);
-        // re[j] = a[256 j + t], im[j] = b[256 j + t]
-#pragma unroll
-        for (int j = 0; j < NT_; ++j) {
-            const int p = 256 * j + t;
-            if (p < wm1) {
-                re[j] += cr[j];
-                im[j] += re[j + NR];
-                cr[j] = im[j + NR];
-            }
-        }
-        double *qa = yr + (start_a - a.skip) + t;
-        if (a.accum) {   // a piece of a partitioned filter adds into the work row
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                qa[256 * j] += re[j];
-                qa[256 * (j + NR)] += im[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                qa[256 * j] = re[j];
-                qa[256 * (j + NR)] = im[j];
-            }
-        }
-        OSZ_FSTAMP(11);  // inverse pass 1 + overlap add + stores issued
-    }
-
-    // any pair: ragged lengths, left cut, accumulate
-    __device__ __forceinline__ void any_pair(int64_t blk) {
-        double *scratch = reinterpret_cast<double *>(L);   // a's tail,
-        double *carry = scratch + 2048;                    // b's tail (<= 2048 doubles each)
-        const int64_t start_a = blk * a.step;
-        const int64_t rem_a = a.n - start_a;
-        const int len_a = rem_a < a.step ? (int)rem_a : a.step;
-        const int64_t start_b = start_a + len_a;
-        int len_b = 0;
-        if (blk + 1 < blk1) {
-            const int64_t rem_b = a.n - start_b;
-            len_b = rem_b < a.step ? (int)rem_b : a.step;
-        }
-        double re[16], im[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = 256 * j + t;
-            re[j] = p < len_a ? xr[start_a + p] : 0.0;
-            im[j] = p < len_b ? xr[start_b + p] : 0.0;
-        }
-        transform(re, im);
-        __syncthreads();   // every thread is done reading the cube
-        const int ja0 = len_a >> 8, ja1 = (len_a + wm1 + 255) >> 8;
-        const int jb0 = len_b >> 8, jb1 = (len_b + wm1 + 255) >> 8;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = 256 * j + t;
-            if (j < NT_) {
-                if (p < wm1) re[j] += cr[j < NT_ ? j : 0];
-            }
-            if (j >= ja0 && j < ja1) {
-                const int q = p - len_a;
-                if (q >= 0 && q < wm1) scratch[q] = re[j];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = 256 * j + t;
-            if (j < NT_) {
-                if (p < wm1) im[j] += scratch[p];
-            }
-            if (j >= jb0 && j < jb1) {
-                const int q = p - len_b;
-                if (q >= 0 && q < wm1) carry[q] = im[j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = 256 * j + t;
-            const int64_t oa = start_a + p - a.skip;
-            if (p < len_a && oa >= 0) yr[oa] = a.accum ? yr[oa] + re[j] : re[j];
-            const int64_t ob = start_b + p - a.skip;
-            if (p < len_b && ob >= 0) yr[ob] = a.accum ? yr[ob] + im[j] : im[j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NT_; ++j) {
-            const int p = 256 * j + t;
-            cr[j] = p < wm1 ? carry[p] : 0.0;
-        }
-        __syncthreads();   // before the next transform overwrites the cube
-    }
-};
 
 // HPRE < 0 (shipped): the 16 filter-spectrum bins of this thread stay in
 // registers for the whole run -- the passes other than pass 3 have the room,
@@ -456,25 +225,6 @@ using namespace osz;
 
 constexpr int kFirPart = 2048;   // taps per piece of a partitioned filter
 constexpr int kFirMaxParts = 16; // => up to 32768 taps
-
-struct FirPart {
-    int ntaps, step;
-    double *dH;         // [4096][2]
-    double *dstate[2];  // ping-pong carried tails [nch][ntaps-1]
-    int cur;
-};
-
-struct osz_fir_s {
-    int ntaps, nch;
-    std::vector<FirPart> parts;
-    double *dtails;     // run-tail workspace [nch][nruns_cap][<= 2048]
-    int64_t tails_cap;  // doubles
-    double *dD;         // partitioned: deferred sums [nch][(P-1)*kFirPart]
-    int64_t dlen;
-    double *dW;         // partitioned: work rows
-    int64_t w_cap;      // doubles
-    fft::Tables tb;
-};
 
 static int fir_build_part(FirPart &pt, const double *taps, int ntaps, int nch) {
     pt.ntaps = ntaps;

@@ -1,0 +1,51 @@
+// handles.h -- the opaque handles of the C ABI as the library's translation
+// units see them (fir.hip, sos.hip own them; chain.hip drives both).
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <vector>
+
+#include "fft4096.h"
+#include "sos_tile.h"
+
+struct FirPart {
+    int ntaps, step;
+    double *dH;         // [4096][2]
+    double *dstate[2];  // ping-pong carried tails [nch][ntaps-1]
+    int cur;
+};
+
+struct osz_fir_s {
+    int ntaps, nch;
+    std::vector<FirPart> parts;
+    double *dtails;     // run-tail workspace [nch][nruns_cap][<= 2048]
+    int64_t tails_cap;  // doubles
+    double *dD;         // partitioned: deferred sums [nch][(P-1)*kFirPart]
+    int64_t dlen;
+    double *dW;         // partitioned: work rows
+    int64_t w_cap;      // doubles
+    osz::fft::Tables tb;
+};
+
+
+struct osz_sos_s {
+    int T, NW;          // kernel geometry: samples per lane, waves per workgroup
+    int64_t warm_len;   // samples of the sosfiltfilt warm-up that matter (see sos_warmup_len)
+    int nsec, nch;
+    osz::SosSection *dsec;   // device, built for T samples per lane
+    osz::SosSection *dsec_t[33];   // tables for other tile geometries (index = T), lazily built
+    double coef[osz::kSosMaxSec * 6];   // host copy of the sections (b0 b1 b2 1 a1 a2)
+    double *dstate;     // device (nsec, nch, 2): carried forward state
+    double *dtmp;       // device (nsec, nch, 2): warm-up state of sosfiltfilt
+    double *dcarry;     // device (nsec, nch, 2): state between the main and remainder launches
+    double *dzi;        // device (nsec, 2): sosfilt_zi of this cascade
+};
+
+namespace osz {
+// process-wide twiddle tables on the device (fir.hip)
+int get_fft_tables(fft::Tables &out);
+// per-section tables of a cascade for a tile of T samples per lane, built on
+// first use and owned by the handle (sos.hip)
+int sos_tables_for(osz_sos_s *h, int T, const SosSection **dsec);
+}  // namespace osz

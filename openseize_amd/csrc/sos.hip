@@ -27,26 +27,10 @@
 #include <vector>
 
 #include "common.h"
+#include "sos_tile.h"
+#include "handles.h"
 
 namespace osz {
-
-constexpr int kSosT = 32;       // samples per lane per tile
-constexpr int kSosNW = 4;       // waves per workgroup (one channel), one per SIMD
-constexpr int kSosPad = 1;      // LDS row padding (doubles): odd row stride, conflict-free b64
-constexpr int kSosMaxSec = 32;  // sections supported per handle
-
-// Per-section constants, built on the host in osz_sos_create.
-struct SosSection {
-    double b0, b1, b2, a1, a2;
-    double pad_[3];
-    double G8[8][2];          // row 0 of A^r, r = 0..7: homogeneous y response inside an octet
-    double A8[4];             // A^8: octet-to-octet step of the homogeneous response
-    double P[4][4];           // A^(T*2^k), k = 0..3: scan steps inside a 16-lane row (DPP)
-    double B[4];              // A^(16*T): row-to-row step
-    double Q[4];              // A^(64*T): wave-to-wave step
-    double PL16[16][4];       // A^(T*j), j = 0..15: row start state -> lane start state
-    double AJ[kSosT + 1][4];  // A^j (per-lane lookup for the final state of a chunk)
-};
 
 struct SosArgs {
     const double *x;
@@ -58,27 +42,6 @@ struct SosArgs {
     double *state_out;       // (nsec, nch, 2) or null
     int nsec, nch;
 };
-
-__device__ __forceinline__ void mat2_apply(const double *M, double u0, double u1,
-                                           double &r0, double &r1) {
-    r0 = fma(M[0], u0, M[1] * u1);
-    r1 = fma(M[2], u0, M[3] * u1);
-}
-
-// lane i <- lane i-D inside its 16-lane row, 0 for the first D lanes (DPP row_shr)
-template <int D>
-__device__ __forceinline__ double row_shr(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + D, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + D, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double lane_bcast(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
 
 // In-kernel phase stamps for the diagnostic build only
 // (benchmarks/sos_stamps.hip defines OSZ_SOS_STAMPS); the library build has none.
@@ -648,20 +611,26 @@ static int64_t sos_warmup_len(const std::vector<SosSection> &secs, int64_t quant
     return cap;
 }
 
+int sos_tables_for(osz_sos_s *h, int T, const SosSection **dsec) {
+    if (T == h->T) {
+        *dsec = h->dsec;
+        return OSZ_OK;
+    }
+    if (T < 2 || T > 32) return fail(OSZ_ERR_INVALID, "sos_tables_for: T=%d not in [2, 32]", T);
+    if (!h->dsec_t[T]) {
+        std::vector<SosSection> secs(h->nsec);
+        for (int s = 0; s < h->nsec; ++s) build_section(h->coef + 6 * s, secs[s], T);
+        OSZ_HIP(hipMalloc(&h->dsec_t[T], sizeof(SosSection) * h->nsec));
+        OSZ_HIP(hipMemcpy(h->dsec_t[T], secs.data(), sizeof(SosSection) * h->nsec,
+                          hipMemcpyHostToDevice));
+    }
+    *dsec = h->dsec_t[T];
+    return OSZ_OK;
+}
+
 }  // namespace osz
 
 using namespace osz;
-
-struct osz_sos_s {
-    int T, NW;          // kernel geometry: samples per lane, waves per workgroup
-    int64_t warm_len;   // samples of the sosfiltfilt warm-up that matter (see sos_warmup_len)
-    int nsec, nch;
-    SosSection *dsec;   // device
-    double *dstate;     // device (nsec, nch, 2): carried forward state
-    double *dtmp;       // device (nsec, nch, 2): warm-up state of sosfiltfilt
-    double *dcarry;     // device (nsec, nch, 2): state between the main and remainder launches
-    double *dzi;        // device (nsec, 2): sosfilt_zi of this cascade
-};
 
 template <int T, int NW, bool REV, bool GUARD>
 static int sos_launch_one(const SosArgs &a, hipStream_t st) {
@@ -813,6 +782,8 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     p->NW = NW;
     p->nsec = nsec;
     p->nch = nch;
+    for (int i = 0; i < 33; ++i) p->dsec_t[i] = nullptr;
+    for (int i = 0; i < 6 * nsec; ++i) p->coef[i] = sos[i];
     const size_t sb = sizeof(double) * (size_t)nsec * nch * 2;
     OSZ_HIP(hipMalloc(&p->dsec, sizeof(SosSection) * nsec));
     OSZ_HIP(hipMalloc(&p->dstate, sb));
@@ -856,6 +827,7 @@ int osz_sos_set_zi_unit(osz_sos_t h, const double *zi_unit) {
 int osz_sos_destroy(osz_sos_t h) {
     if (!h) return OSZ_OK;
     (void)hipFree(h->dsec);
+    for (int i = 0; i < 33; ++i) (void)hipFree(h->dsec_t[i]);
     (void)hipFree(h->dstate);
     (void)hipFree(h->dtmp);
     (void)hipFree(h->dcarry);

@@ -882,3 +882,32 @@ def test_handle_lifecycle_no_leak(osz):
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free0 - free1) < 64 << 20, (free0, free1)
+
+
+def test_chain_forward_fused(osz):
+    """osz_chain_forward (FIR feeding the forward SOS pass in one kernel, the
+    FIR output never reaching HBM) equals osz_fir_push + osz_sos_forward, chunk
+    after chunk with both carried states, for block lengths NR = 8, 12, 14,
+    few and many channels (one and several runs per channel, i.e. with the
+    zero-state pre-roll) and a ragged chunk end."""
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    for taps, C, n in ((1024, 256, 3 * 6144 * 30 + 777), (1024, 7, 1 << 20), (2049, 5, 400000),
+                       (300, 3, 500000)):
+        h = sps.firwin(taps, 0.2)
+        xs = [dev.synth_normal(C, n, seed=9, n0=k * n) for k in range(3)]
+        fir, iir = dev.FirStream(h, C), dev.SosStream(sos, C)
+        iir.set_state_scaled(xs[0], 0)
+        ref = [iir.forward(fir.push(x, 0)) for x in xs]
+        zref = iir.get_state()
+        fir.close(); iir.close()
+        fir, iir = dev.FirStream(h, C), dev.SosStream(sos, C)
+        iir.set_state_scaled(xs[0], 0)
+        for k, x in enumerate(xs):
+            f = dev.chain_forward(fir, iir, x)
+            err = float((f - ref[k]).abs().max()) / float(ref[k].abs().max())
+            assert err < 1e-12, (taps, C, n, k, err)
+        assert np.allclose(iir.get_state(), zref, rtol=1e-10, atol=1e-12)
+        fir.close(); iir.close()
