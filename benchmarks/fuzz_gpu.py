@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 9
+        kind = it % 10
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -148,6 +148,23 @@ def main():
                 y = np.concatenate(list(nm.sosfilt(producer(x, cs, -1), sos, -1, zi=zi)), -1)
                 ref, _ = sps.sosfilt(sos, x, axis=-1, zi=zi)
                 e, what = rel(y, ref), f"sosfilt zi n={n} cs={cs}"
+            elif kind == 9:    # fused FIR -> forward SOS against the separate kernels
+                from openseize_amd import _device as dev
+                taps = int(rng.choice([300, 513, 777, 1024, 1300, 1793, 2049]))
+                C = int(rng.integers(1, 10))
+                step = min((4097 - taps) // 256, 15) * 256
+                n = int(rng.integers(8, 40)) * 2 * step + int(rng.integers(0, 2 * step))
+                h = rng.standard_normal(taps) / np.sqrt(taps)
+                sos = designs[int(rng.integers(0, len(designs)))]
+                xs = [torch.from_numpy(rng.standard_normal((C, n))).cuda() for _ in range(2)]
+                fir, iir = dev.FirStream(h, C), dev.SosStream(sos, C)
+                ref = [iir.forward(fir.push(x, 0)) for x in xs]
+                fir.close(); iir.close()
+                fir, iir = dev.FirStream(h, C), dev.SosStream(sos, C)
+                got = [dev.chain_forward(fir, iir, x) for x in xs]
+                fir.close(); iir.close()
+                e = max(rel(g_.cpu().numpy(), r_.cpu().numpy()) for g_, r_ in zip(got, ref))
+                what = f"chain taps={taps} C={C} n={n}"
             elif kind == 4:    # psd
                 fs = float(rng.choice([250, 500, 1000, 4096]))
                 res = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
