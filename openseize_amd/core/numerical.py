@@ -234,7 +234,8 @@ def sosfiltfilt(pro, sos, axis):
     layout = dev.Layout(pro.shape, axis)
     stream = dev.SosStream(sos, layout.nch)
     try:
-        chunks = iter(pro)
+        # zero-length arrays carry no samples (sosfilt skips them too)
+        chunks = (c for c in pro if c.shape[layout.axis] > 0)
         first = next(chunks, None)
         if first is None:
             return

@@ -18,6 +18,7 @@
 // (the same 1e-18 bound as the time segments of sos.hip).  The last run
 // leaves both carried states.  Pairs are whole by construction; the host
 // sends the ragged end of a chunk through the separate kernels.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -164,6 +165,8 @@ int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
     OSZ_REQUIRE(n >= 0 && ldx >= n && ldf >= n, "osz_chain_forward: n=%lld ldx=%lld ldf=%lld",
                 (long long)n, (long long)ldx, (long long)ldf);
     if (n == 0) return OSZ_OK;
+    OSZ_SAME_DEVICE(fir, "osz_chain_forward");
+    OSZ_SAME_DEVICE(sos, "osz_chain_forward");
     hipStream_t st = as_stream(stream);
     int64_t whole = 0;   // samples that go through the fused kernel
     if (fir->parts.size() == 1 && fir->ntaps >= 2) {
@@ -196,7 +199,7 @@ int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
             g.fir_state_in = pt.dstate[pt.cur];
             g.fir_state_out = pt.dstate[pt.cur ^ 1];
             g.sos_state_in = sos->dstate;
-            g.sos_state_out = sos->dcarry;
+            g.sos_state_out = sos->dstate_alt;
             g.npairs = npairs;
             g.nruns = (int)nruns;
             g.pre_pairs = (int)pre;
@@ -204,14 +207,9 @@ int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
             static const kern_t kerns[8] = {chain_kernel<8>,  chain_kernel<9>,  chain_kernel<10>,
                                             chain_kernel<11>, chain_kernel<12>, chain_kernel<13>,
                                             chain_kernel<14>, chain_kernel<15>};
-            static bool attr_set[8] = {};
             const size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS +
                                sizeof(double) * (2 * 4 * 2 + 2 * kSosMaxSec * 2);
-            if (!attr_set[nr - 8]) {
-                OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[nr - 8]),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set[nr - 8] = true;
-            }
+            OSZ_DYN_LDS(kerns[nr - 8], lds);
             {
                 KernelTimer kt("chain_fwd", st);
                 hipLaunchKernelGGL(kerns[nr - 8], dim3((unsigned)nruns, fir->nch), dim3(256), lds,
@@ -219,26 +217,19 @@ int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
             }
             OSZ_HIP(hipGetLastError());
             pt.cur ^= 1;
-            OSZ_HIP(hipMemcpyAsync(sos->dstate, sos->dcarry,
-                                   sizeof(double) * (size_t)sos->nsec * sos->nch * 2,
-                                   hipMemcpyDeviceToDevice, st));
+            std::swap(sos->dstate, sos->dstate_alt);
             whole = npairs * pair;
         }
     }
     if (whole < n) {
         // the ragged end (or everything, for shapes the fused kernel does not take):
-        // FIR into the output rows, then the cascade in place (a single partial tile
-        // per channel is read completely before it is written)
+        // FIR into the output rows, then the cascade in place (osz_sos_forward runs
+        // one workgroup per channel when y aliases x: every tile is read before it
+        // is written)
         int rc = osz_fir_push(fir, x + whole, ldx, n - whole, f + whole, ldf, 0, stream);
         if (rc) return rc;
-        if (n - whole < (int64_t)sos->NW * 64 * sos->T) {
-            rc = osz_sos_forward(sos, f + whole, ldf, f + whole, ldf, n - whole, stream);
-            if (rc) return rc;
-        } else {
-            return fail(OSZ_ERR_UNSUPPORTED,
-                        "osz_chain_forward: %lld samples outside the fused kernel need a separate "
-                        "osz_fir_push + osz_sos_forward", (long long)(n - whole));
-        }
+        rc = osz_sos_forward(sos, f + whole, ldf, f + whole, ldf, n - whole, stream);
+        if (rc) return rc;
     }
     return OSZ_OK;
 }

@@ -30,6 +30,28 @@ int fail(int code, const char *fmt, ...);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: this
+// sets it once per (kernel, device) pair (mutex-guarded map in lib.hip).
+int ensure_dyn_lds(const void *kern, size_t bytes);
+#define OSZ_DYN_LDS(kern, bytes)                                             \
+    do {                                                                     \
+        int rc_ = osz::ensure_dyn_lds(reinterpret_cast<const void *>(kern), (bytes)); \
+        if (rc_) return rc_;                                                 \
+    } while (0)
+
+// Handles own device buffers: every entry point checks that the calling
+// thread's current device is the one the handle was created on.
+int current_device(int *dev);
+#define OSZ_SAME_DEVICE(h, fn)                                               \
+    do {                                                                     \
+        int dev_ = -1;                                                       \
+        int rc_ = osz::current_device(&dev_);                                \
+        if (rc_) return rc_;                                                 \
+        if (dev_ != (h)->device)                                             \
+            return osz::fail(OSZ_ERR_STATE, "%s: handle belongs to device %d, current device is %d", \
+                             fn, (h)->device, dev_);                         \
+    } while (0)
+
 constexpr int kWave = 64;  // CDNA wavefront width
 
 // Optional per-kernel timing with HIP events on the launch stream

@@ -23,6 +23,7 @@
 //     spectrum H (64 KB) and the twiddles live in registers for a whole run.
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -181,19 +182,20 @@ __global__ void fir_flush_kernel(FlushArgs a) {
     a.y[(int64_t)c * a.ldy + o] = v;
 }
 
-// Process-wide twiddle tables on the device (one per process per device).
+// Twiddle tables on the device: one set per device, built on first use and
+// kept for the life of the process.
 struct FftTablesDev {
     double *t1 = nullptr, *t2 = nullptr;
-    int device = -1;
 };
 
 int get_fft_tables(fft::Tables &out) {
     static std::mutex mu;
-    static FftTablesDev tabs;
+    static std::map<int, FftTablesDev> per_device;
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     OSZ_HIP(hipGetDevice(&dev));
-    if (tabs.t1 == nullptr || tabs.device != dev) {
+    FftTablesDev &tabs = per_device[dev];
+    if (tabs.t1 == nullptr) {
         const long double PI = acosl(-1.0L);
         std::vector<double> t1(16 * 256 * 2), t2(16 * 16 * 2);
         for (int k0 = 0; k0 < 16; ++k0)
@@ -212,7 +214,6 @@ int get_fft_tables(fft::Tables &out) {
         OSZ_HIP(hipMalloc(&tabs.t2, t2.size() * sizeof(double)));
         OSZ_HIP(hipMemcpy(tabs.t1, t1.data(), t1.size() * sizeof(double), hipMemcpyHostToDevice));
         OSZ_HIP(hipMemcpy(tabs.t2, t2.data(), t2.size() * sizeof(double), hipMemcpyHostToDevice));
-        tabs.device = dev;
     }
     out.t1 = tabs.t1;
     out.t2 = tabs.t2;
@@ -355,15 +356,10 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
         static const kern_t kerns[8] = {fir_oa_kernel<8>,  fir_oa_kernel<9>,  fir_oa_kernel<10>,
                                         fir_oa_kernel<11>, fir_oa_kernel<12>, fir_oa_kernel<13>,
                                         fir_oa_kernel<14>, fir_oa_kernel<15>};
-        static bool attr_set[8] = {};
         const int nr = pt.step / 256;
         size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS;
         if (const char *e = getenv("OSZ_FIR_LDS_PAD")) lds += (size_t)atoi(e) * 1024;   // occupancy experiments
-        if (!attr_set[nr - 8]) {
-            OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[nr - 8]),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set[nr - 8] = true;
-        }
+        OSZ_DYN_LDS(kerns[nr - 8], lds);
         KernelTimer kt("fir_oa", st);
         hipLaunchKernelGGL(kerns[nr - 8], dim3((unsigned)nruns, h->nch), dim3(256), lds, st, a);
     }
@@ -406,6 +402,8 @@ int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch) {
     osz_fir_s *p = new osz_fir_s();
     p->ntaps = ntaps;
     p->nch = nch;
+    p->device = 0;
+    (void)hipGetDevice(&p->device);
     p->dtails = p->dD = p->dW = nullptr;
     p->tails_cap = p->w_cap = 0;
     p->dlen = 0;
@@ -467,6 +465,7 @@ int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y
     OSZ_REQUIRE(skip >= 0 && skip <= n, "osz_fir_push: skip=%lld not in [0, n]", (long long)skip);
     OSZ_REQUIRE(skip == n || (y && ldy >= n - skip), "osz_fir_push: bad output");
     if (n == 0) return OSZ_OK;
+    OSZ_SAME_DEVICE(h, "osz_fir_push");
     hipStream_t st = as_stream(stream);
     if (h->parts.size() == 1)
         return fir_part_push(h, h->parts[0], x, ldx, n, y, ldy, skip, 0, st);

@@ -17,6 +17,7 @@ struct FirPart {
 };
 
 struct osz_fir_s {
+    int device;         // HIP device the handle's buffers live on
     int ntaps, nch;
     std::vector<FirPart> parts;
     double *dtails;     // run-tail workspace [nch][nruns_cap][<= 2048]
@@ -30,13 +31,17 @@ struct osz_fir_s {
 
 
 struct osz_sos_s {
+    int device;         // HIP device the handle's buffers live on
     int T, NW;          // kernel geometry: samples per lane, waves per workgroup
     int64_t warm_len;   // samples of the sosfiltfilt warm-up that matter (see sos_warmup_len)
     int nsec, nch;
     osz::SosSection *dsec;   // device, built for T samples per lane
     osz::SosSection *dsec_t[33];   // tables for other tile geometries (index = T), lazily built
     double coef[osz::kSosMaxSec * 6];   // host copy of the sections (b0 b1 b2 1 a1 a2)
-    double *dstate;     // device (nsec, nch, 2): carried forward state
+    double *dstate;     // device (nsec, nch, 2): carried forward state (current)
+    double *dstate_alt; // the other half of the ping-pong: a forward pass reads dstate and
+                        // writes dstate_alt (its time segments are separate workgroups with
+                        // no ordering between them), then the two swap
     double *dtmp;       // device (nsec, nch, 2): warm-up state of sosfiltfilt
     double *dcarry;     // device (nsec, nch, 2): state between the main and remainder launches
     double *dzi;        // device (nsec, 2): sosfilt_zi of this cascade

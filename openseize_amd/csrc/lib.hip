@@ -1,6 +1,7 @@
 // lib.hip -- library-level entry points: errors, device info, memory/stream
 // helpers, HIP-event timing.
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -63,6 +64,25 @@ void profile_begin(const char *name, hipStream_t st) {
 
 void profile_end(hipStream_t st) {
     if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, st);
+}
+
+int current_device(int *dev) {
+    OSZ_HIP(hipGetDevice(dev));
+    return OSZ_OK;
+}
+
+int ensure_dyn_lds(const void *kern, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> done;
+    int dev = 0;
+    OSZ_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(kern, dev);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return OSZ_OK;
+    OSZ_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done[key] = bytes;
+    return OSZ_OK;
 }
 
 char *err_buf() {

@@ -197,6 +197,7 @@ __global__ void poly_hist_kernel(const double *x, int64_t ldx, int64_t n, const 
 using namespace osz;
 
 struct osz_poly_s {
+    int device;         // HIP device the handle's buffers live on
     int m, L, M, nch, H, half;
     double *dhL;
     double *dG;         // blocked sub-filters for poly_block_kernel, or null
@@ -222,6 +223,8 @@ int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M, 
     OSZ_REQUIRE(ntaps >= 1 && L >= 1 && M >= 1 && nch >= 1 && nch <= 65535,
                 "osz_poly_create: bad sizes (ntaps=%d L=%d M=%d nch=%d; nch <= 65535)", ntaps, L, M, nch);
     osz_poly_s *p = new osz_poly_s();
+    p->device = 0;
+    (void)hipGetDevice(&p->device);
     p->m = ntaps;
     p->L = L;
     p->M = M;
@@ -302,6 +305,7 @@ int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n, int fin
                   int64_t ldy, int64_t *n_out, void *stream) {
     OSZ_REQUIRE(h, "osz_poly_push: null handle");
     OSZ_REQUIRE(n >= 0 && (n == 0 || (x && ldx >= n)), "osz_poly_push: bad input");
+    OSZ_SAME_DEVICE(h, "osz_poly_push");
     hipStream_t st = as_stream(stream);
     const int64_t navail = h->nin + n;
     const int64_t j1 = poly_end(h, navail, final_);
@@ -333,19 +337,12 @@ int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n, int fin
             static const kern_t kerns[2][3] = {
                 {poly_block_kernel<false, 256>, poly_block_kernel<false, 128>, poly_block_kernel<false, 64>},
                 {poly_block_kernel<true, 256>, poly_block_kernel<true, 128>, poly_block_kernel<true, 64>}};
-            static bool attr = false;
-            if (!attr) {
-                for (int o = 0; o < 2; ++o)
-                    for (int q = 0; q < 3; ++q)
-                        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[o][q]),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    64 * 1024));
-                attr = true;
-            }
+            const kern_t kern = kerns[h->L == 1 ? 1 : 0][h->nt == 256 ? 0 : h->nt == 128 ? 1 : 2];
+            OSZ_DYN_LDS(kern, 64 * 1024);
             const int64_t per = (int64_t)h->nt * kPolyR * h->L;
             const int64_t bx = (cnt + per - 1) / per;
             KernelTimer kt("poly_block", st);
-            hipLaunchKernelGGL(kerns[h->L == 1 ? 1 : 0][h->nt == 256 ? 0 : h->nt == 128 ? 1 : 2],
+            hipLaunchKernelGGL(kern,
                                dim3((unsigned)bx, h->nch), dim3(h->nt), blds, st, b);
         } else {   // very large M: the window of even a 64-thread tile exceeds LDS
             int64_t bx = (cnt + 255) / 256;

@@ -22,6 +22,7 @@
 //   Global<->lane-block transposition is staged through a padded LDS tile so
 //   both the HBM side (consecutive lanes -> consecutive samples) and the LDS
 //   side (row stride T+2 doubles) are conflict free.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -635,14 +636,9 @@ using namespace osz;
 template <int T, int NW, bool REV, bool GUARD>
 static int sos_launch_one(const SosArgs &a, hipStream_t st) {
     auto kern = sos_kernel<T, NW, REV, GUARD>;
-    static bool attr_set = false;
     const size_t lds = sizeof(double) * ((size_t)NW * 64 * (T + kSosPad) + 2 * NW * 2 +
                                          2 * kSosMaxSec * 2);
-    if (!attr_set) {
-        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    OSZ_DYN_LDS(kern, lds);
     {
         KernelTimer kt(REV ? (a.y ? (GUARD ? "sos_bwd_tail" : "sos_bwd") : "sos_warmup")
                            : (GUARD ? "sos_fwd_tail" : "sos_fwd"), st);
@@ -679,7 +675,11 @@ static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
         const char *e = getenv("OSZ_SOS_WGS");
         target_wgs = (e && atoi(e) > 0) ? atoi(e) : (sos_lean() ? 768 : 512);
     }
-    if (a.nch < target_wgs && pre_tiles >= 1 && pre_tiles * tile == warm_len) {
+    // in place (y aliases x) the pre-roll of segment s would read what segment
+    // s - 1 is writing: one workgroup per channel then (it reads a tile before
+    // it writes it)
+    const bool in_place = a.y != nullptr && a.y == a.x;
+    if (!in_place && a.nch < target_wgs && pre_tiles >= 1 && pre_tiles * tile == warm_len) {
         nseg = (target_wgs + a.nch - 1) / a.nch;
         const int64_t max_seg = ntiles / (4 * pre_tiles);    // pre-roll <= 25 % extra work
         if (nseg > max_seg) nseg = max_seg;
@@ -689,14 +689,9 @@ static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
     nseg = (ntiles + seg_tiles - 1) / seg_tiles;
     const bool lean = sos_lean();
     auto kern = lean ? sos_split_lean_kernel<T, NW, REV> : sos_split_kernel<T, NW, REV>;
-    static bool attr_set = false;
     const size_t lds = sizeof(double) * ((size_t)NW * (lean ? 32 : 64) * (T + kSosPad) +
                                          2 * NW * 2 + 2 * kSosMaxSec * 2);
-    if (!attr_set) {
-        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;   // `lean` is fixed for the life of the process
-    }
+    OSZ_DYN_LDS(kern, lds);
     {
         KernelTimer kt(REV ? (a.y ? "sos_bwd_split" : "sos_warmup") : "sos_fwd_split", st);
         hipLaunchKernelGGL(kern, dim3(a.nch, (unsigned)nseg), dim3(NW * 64), lds, st, a, a.sec,
@@ -744,14 +739,9 @@ static int sos_launch(const SosArgs &a, double *carry, int T, int NW, int64_t wa
 template <int T, int NW>
 static int sos_launch_dual(const SosArgs &f, const SosArgs &b, hipStream_t st) {
     auto kern = sos_dual_kernel<T, NW>;
-    static bool attr_set = false;
     const size_t lds = sizeof(double) * ((size_t)NW * 64 * (T + kSosPad) + 2 * NW * 2 +
                                          2 * kSosMaxSec * 2);
-    if (!attr_set) {
-        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    OSZ_DYN_LDS(kern, lds);
     {
         KernelTimer kt("sos_dual", st);
         hipLaunchKernelGGL(kern, dim3(f.nch, 2), dim3(NW * 64), lds, st, f, b, f.sec);
@@ -786,7 +776,9 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     for (int i = 0; i < 6 * nsec; ++i) p->coef[i] = sos[i];
     const size_t sb = sizeof(double) * (size_t)nsec * nch * 2;
     OSZ_HIP(hipMalloc(&p->dsec, sizeof(SosSection) * nsec));
+    OSZ_HIP(hipGetDevice(&p->device));
     OSZ_HIP(hipMalloc(&p->dstate, sb));
+    OSZ_HIP(hipMalloc(&p->dstate_alt, sb));
     OSZ_HIP(hipMalloc(&p->dtmp, sb));
     OSZ_HIP(hipMalloc(&p->dcarry, sb));
     OSZ_HIP(hipMalloc(&p->dzi, sizeof(double) * nsec * 2));
@@ -805,7 +797,13 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
         scale *= g;
     }
     OSZ_HIP(hipMemcpy(p->dzi, zi.data(), sizeof(double) * 2 * nsec, hipMemcpyHostToDevice));
-    p->warm_len = sos_warmup_len(secs, (int64_t)NW * 64 * T, (int64_t)1 << 24);
+    {
+        // not converged within the cap (slowly decaying or unstable cascade):
+        // no truncated warm-up and no zero-start time segments for this filter
+        const int64_t cap = (int64_t)1 << 24;
+        const int64_t wl = sos_warmup_len(secs, (int64_t)NW * 64 * T, cap);
+        p->warm_len = wl >= cap ? ((int64_t)1 << 62) : wl;
+    }
     *h = p;
     return OSZ_OK;
 }
@@ -829,6 +827,7 @@ int osz_sos_destroy(osz_sos_t h) {
     (void)hipFree(h->dsec);
     for (int i = 0; i < 33; ++i) (void)hipFree(h->dsec_t[i]);
     (void)hipFree(h->dstate);
+    (void)hipFree(h->dstate_alt);
     (void)hipFree(h->dtmp);
     (void)hipFree(h->dcarry);
     (void)hipFree(h->dzi);
@@ -885,6 +884,7 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y, int64_
     OSZ_REQUIRE(n >= 0 && ldx >= n && ldy >= n, "osz_sos_forward: n=%lld ldx=%lld ldy=%lld",
                 (long long)n, (long long)ldx, (long long)ldy);
     if (n == 0) return OSZ_OK;
+    OSZ_SAME_DEVICE(h, "osz_sos_forward");
     SosArgs a{};
     a.x = x;
     a.y = y;
@@ -894,10 +894,13 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y, int64_
     a.sec = h->dsec;
     a.state_in = h->dstate;
     a.zi_unit = nullptr;
-    a.state_out = h->dstate;
+    a.state_out = h->dstate_alt;
     a.nsec = h->nsec;
     a.nch = h->nch;
-    return sos_launch<false>(a, h->dcarry, h->T, h->NW, h->warm_len, as_stream(stream));
+    int rc = sos_launch<false>(a, h->dcarry, h->T, h->NW, h->warm_len, as_stream(stream));
+    if (rc) return rc;
+    std::swap(h->dstate, h->dstate_alt);
+    return OSZ_OK;
 }
 
 int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, double *f,
@@ -908,6 +911,7 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
     OSZ_REQUIRE(nx >= 1 && ldx >= nx && ldf >= nx, "osz_sosfiltfilt_step: bad forward chunk");
     OSZ_REQUIRE(na >= 1 && ldfa >= na && ldy >= na, "osz_sosfiltfilt_step: bad chunk a");
     OSZ_REQUIRE(!fb || (nb >= 1 && ldfb >= nb), "osz_sosfiltfilt_step: bad chunk b");
+    OSZ_SAME_DEVICE(h, "osz_sosfiltfilt_step");
     const int64_t tile = (int64_t)h->NW * 64 * h->T;
     const bool fusable = h->T == 32 && h->NW == 4 && nx % tile == 0 && na % tile == 0 &&
                          h->nch >= 96;   // fewer channels: time-split launches fill the chip better
@@ -937,7 +941,7 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
     fw.ldy = ldf;
     fw.n = nx;
     fw.state_in = h->dstate;
-    fw.state_out = h->dstate;
+    fw.state_out = h->dstate_alt;
     bw.x = fa;
     bw.y = y;
     bw.ldx = ldfa;
@@ -958,24 +962,23 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
             const int64_t sf = ((nx / tile + nseg - 1) / nseg) * tile;
             const int64_t sb = ((na / tile + nseg - 1) / nseg) * tile;
             auto kern = sos_dual_lean_kernel<32, 4>;
-            static bool attr_set = false;
             const size_t lds = sizeof(double) * ((size_t)4 * 32 * (32 + kSosPad) + 2 * 4 * 2 +
                                                  2 * kSosMaxSec * 2);
-            if (!attr_set) {
-                OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
-            }
+            OSZ_DYN_LDS(kern, lds);
             {
                 KernelTimer kt("sos_dual", st);
                 hipLaunchKernelGGL(kern, dim3(h->nch, 2 * nseg), dim3(256), lds, st, fw, bw,
                                    h->dsec, nseg, sf, sb, h->warm_len);
             }
             OSZ_HIP(hipGetLastError());
+            std::swap(h->dstate, h->dstate_alt);
             return OSZ_OK;
         }
     }
-    return sos_launch_dual<32, 4>(fw, bw, st);
+    int rc = sos_launch_dual<32, 4>(fw, bw, st);
+    if (rc) return rc;
+    std::swap(h->dstate, h->dstate_alt);
+    return OSZ_OK;
 }
 
 int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t na,
@@ -984,6 +987,7 @@ int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t n
     OSZ_REQUIRE(h && fa && y, "osz_sosfiltfilt_chunk: null argument");
     OSZ_REQUIRE(na >= 1 && ldfa >= na && ldy >= na, "osz_sosfiltfilt_chunk: bad chunk a");
     OSZ_REQUIRE(!fb || (nb >= 1 && ldfb >= nb), "osz_sosfiltfilt_chunk: bad chunk b");
+    OSZ_SAME_DEVICE(h, "osz_sosfiltfilt_chunk");
     hipStream_t st = as_stream(stream);
     SosArgs a{};
     a.sec = h->dsec;

@@ -371,6 +371,7 @@ __global__ void spec_partial_reduce_kernel(const double *partial, double *dsum, 
 using namespace osz;
 
 struct osz_spec_s {
+    int device;         // HIP device the handle's buffers live on
     int nwin, nfft, stride, nfreq, detrend, mode, nch;
     double scale;
     double *dwindow;
@@ -427,6 +428,8 @@ int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride, const double 
     OSZ_REQUIRE(mode >= OSZ_SPEC_PSD_MEAN && mode <= OSZ_SPEC_DFT_SEGMENTS,
                 "osz_spec_create: unknown mode %d", mode);
     osz_spec_s *p = new osz_spec_s();
+    p->device = 0;
+    (void)hipGetDevice(&p->device);
     p->nwin = nwin;
     p->nfft = nfft;
     p->stride = stride;
@@ -501,6 +504,7 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
                   void *stream) {
     OSZ_REQUIRE(h, "osz_spec_push: null handle");
     OSZ_REQUIRE(n >= 0 && (n == 0 || (x && ldx >= n)), "osz_spec_push: bad input");
+    OSZ_SAME_DEVICE(h, "osz_spec_push");
     hipStream_t st = as_stream(stream);
     const int64_t total = h->ncarry + n;
     const int64_t nseg = osz_spec_seg_count(h, n);
@@ -550,22 +554,14 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
              {spec_cube_kernel<1, true, false>, spec_cube_kernel<1, true, true>}},
             {{spec_cube_kernel<2, false, false>, spec_cube_kernel<2, false, true>},
              {spec_cube_kernel<2, true, false>, spec_cube_kernel<2, true, true>}}};
-        static bool cattr = false;
         const size_t clds = sizeof(fft::cube::C2) * fft::cube::SLOTS;
-        if (!cattr) {
-            for (int m = 0; m < 3; ++m)
-                for (int l = 0; l < 2; ++l)
-                    for (int hf = 0; hf < 2; ++hf)
-                        OSZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ck[m][l][hf]),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    (int)clds));
-            cattr = true;
-        }
+        const kern_t ckern = ck[h->mode][h->detrend == OSZ_DETREND_LINEAR ? 1 : 0]
+                               [h->stride == 2048 ? 1 : 0];
+        OSZ_DYN_LDS(ckern, clds);
         {
             KernelTimer kt("spec_fused", st);
             const dim3 grid((unsigned)nruns, h->nch), block(256);
-            hipLaunchKernelGGL(ck[h->mode][h->detrend == OSZ_DETREND_LINEAR ? 1 : 0]
-                                 [h->stride == 2048 ? 1 : 0], grid, block, clds, st, fa);
+            hipLaunchKernelGGL(ckern, grid, block, clds, st, fa);
         }
         OSZ_HIP(hipGetLastError());
         if (h->mode == OSZ_SPEC_PSD_MEAN) {
