@@ -18,7 +18,6 @@ producer; handles are created inside ``__iter__``/generators).
 import abc
 import inspect
 from collections import abc as cabc
-from itertools import zip_longest
 
 import numpy as np
 
@@ -35,43 +34,68 @@ def _is_reader(obj):
     return all(hasattr(obj, name) for name in ("read", "shape", "open", "close"))
 
 
+def _is_genfunc(obj):
+    """A generating function, bare or wrapped in functools.partial."""
+    return inspect.isgeneratorfunction(getattr(obj, "func", obj))
+
+
+def _is_sequence(obj):
+    return isinstance(obj, cabc.Sequence) and not isinstance(obj, (str, bytes))
+
+
+def _adopt(existing, chunksize, axis, shape, kwargs):
+    # an existing producer is re-chunked IN PLACE and handed back
+    # (reference core/producer.py:114-117, quirk Q5)
+    existing.chunksize = int(chunksize)
+    existing.axis = normalize_axis(axis, len(existing.shape))
+    return existing
+
+
+def _from_genfunc(func, chunksize, axis, shape, kwargs):
+    if shape is None:
+        raise ValueError("A Producer from a generating function requires a shape.")
+    return GenProducer(func, chunksize, normalize_axis(axis, len(shape)), shape, **kwargs)
+
+
+def _from_array(arr, chunksize, axis, shape, kwargs):
+    return ArrayProducer(arr, chunksize, normalize_axis(axis, len(arr.shape)), **kwargs)
+
+
+def _from_sequence(seq, chunksize, axis, shape, kwargs):
+    return _from_array(dev.concatenate(list(seq), axis), chunksize, axis, shape, kwargs)
+
+
+def _from_reader(reader, chunksize, axis, shape, kwargs):
+    # readers are (channels, samples): the sample axis is 1 whatever was asked
+    return ReaderProducer(reader, chunksize, axis=1, **kwargs)
+
+
 def producer(data, chunksize, axis, shape=None, mask=None, **kwargs):
     """Builds an iterable yielding arrays of ``chunksize`` samples along
     ``axis`` from an ndarray / device tensor, a sequence of arrays, a reader,
     a generating function or an existing producer.
 
-    Mirrors reference core/producer.py:54-143, including: an existing producer
+    Same contract as reference core/producer.py:54-143: an existing producer
     is MUTATED (chunksize, axis) and returned (:114-117); generating functions
     need ``shape`` (ValueError); anything else raises
     ``TypeError("unproducible type")`` (:135-137); ``mask`` wraps the result in
-    a MaskedProducer (:139-143).
+    a MaskedProducer (:139-143).  The type dispatch is a table of (test,
+    constructor) pairs tried in order.
     """
-    if isinstance(data, Producer):
-        data.chunksize = int(chunksize)
-        data.axis = normalize_axis(axis, len(data.shape))
-        result = data
-    elif inspect.isgeneratorfunction(data) or (
-            hasattr(data, "func") and inspect.isgeneratorfunction(data.func)):
-        if shape is None:
-            raise ValueError(
-                "A Producer from a generating function requires a shape.")
-        ax = normalize_axis(axis, len(shape))
-        result = GenProducer(data, chunksize, ax, shape, **kwargs)
-    elif dev.is_arraylike(data):
-        ax = normalize_axis(axis, len(data.shape))
-        result = ArrayProducer(data, chunksize, ax, **kwargs)
-    elif isinstance(data, cabc.Sequence) and not isinstance(data, (str, bytes)):
-        x = dev.concatenate(list(data), axis)
-        ax = normalize_axis(axis, len(x.shape))
-        result = ArrayProducer(x, chunksize, ax, **kwargs)
-    elif _is_reader(data):
-        result = ReaderProducer(data, chunksize, axis=1, **kwargs)
+    dispatch = ((lambda d: isinstance(d, Producer), _adopt),
+                (_is_genfunc, _from_genfunc),
+                (dev.is_arraylike, _from_array),
+                (_is_sequence, _from_sequence),
+                (_is_reader, _from_reader))
+    for accepts, build in dispatch:
+        if accepts(data):
+            made = build(data, chunksize, axis, shape, kwargs)
+            break
     else:
         raise TypeError("unproducible type: {}".format(type(data)))
-
-    if mask is None:
-        return result
-    return MaskedProducer(result, mask, chunksize, result.axis, **kwargs)
+    if mask is not None:
+        made = MaskedProducer(made, mask, chunksize, made.axis, **kwargs)
+    return made
 
 
 class Producer(cabc.Iterable):
@@ -117,27 +141,28 @@ class Producer(cabc.Iterable):
 
 class ReaderProducer(Producer):
     """Producer over a reader object (core/producer.py:213-264): ``start`` /
-    ``stop`` kwargs bound the samples, the reader is closed on construction
-    (so the producer pickles) and reopened on iteration."""
+    ``stop`` kwargs bound the samples (clamped like a slice), the reader is
+    closed on construction (so the producer pickles) and reopened on
+    iteration; remaining kwargs go to ``reader.read``."""
 
     def __init__(self, data, chunksize, axis, **kwargs):
         super().__init__(data, chunksize, axis, **kwargs)
-        a = self.kwargs.pop("start", 0)
-        b = self.kwargs.pop("stop", self.data.shape[axis])
-        self.start, self.stop, _ = slice(a, b).indices(data.shape[axis])
-        self.data.close()
+        total = data.shape[axis]
+        window = slice(self.kwargs.pop("start", 0), self.kwargs.pop("stop", total))
+        self.start, self.stop = window.indices(total)[:2]
+        data.close()
 
     @property
     def shape(self):
-        s = list(self.data.shape)
-        s[self.axis] = self.stop - self.start
-        return tuple(s)
+        dims = list(self.data.shape)
+        dims[self.axis] = self.stop - self.start
+        return tuple(dims)
 
     def __iter__(self):
-        self.data.open()
-        for a in range(self.start, self.stop, self.chunksize):
-            yield self.data.read(a, min(a + self.chunksize, self.stop),
-                                 **self.kwargs)
+        reader, step = self.data, self.chunksize
+        reader.open()
+        for first in range(self.start, self.stop, step):
+            yield reader.read(first, min(first + step, self.stop), **self.kwargs)
 
 
 class ArrayProducer(Producer):
@@ -174,33 +199,48 @@ class GenProducer(Producer):
         return self._shape
 
     def __iter__(self):
-        collector = FIFOArray(self.chunksize, self.axis)
-        for subarr in self.data(**self.kwargs):
-            collector.put(subarr)
-            while collector.full():
-                yield collector.get()
-        if collector.qsize() > 0:
-            yield collector.queue
+        fifo = FIFOArray(self.chunksize, self.axis)
+        for piece in self.data(**self.kwargs):
+            fifo.put(piece)
+            while fifo.full():
+                yield fifo.get()
+        if not fifo.empty():
+            yield fifo.queue          # the short remainder, whole
 
 
 class MaskedProducer(Producer):
-    """Keeps only the samples where a boolean mask is True
-    (core/producer.py:379-444).  Data and mask are cut with the same chunksize
-    and zipped, so production ends with the shorter of the two (:427); chunks
-    whose mask is all False are skipped (:429-430); survivors are gathered in
-    index order (np.take(flatnonzero), :432) and re-chunked.  ``shape`` reports
-    min(data length, count of True) along the axis (:399-408)."""
+    """Keeps only the samples where a boolean mask is True (behaviour of the
+    reference's core/producer.py:379-444, formulated on global sample indices).
+
+    The reference cuts data and mask with the same chunksize, zips the two
+    streams and gathers ``flatnonzero`` of every mask piece.  The same stream
+    is described once, up front, by the sorted list of kept SAMPLE INDICES
+    ``keep = flatnonzero(mask[:limit])`` where ``limit`` is the end of the last
+    chunk both streams still have (:427: zip stops with the shorter one).
+    Data chunk k then contributes ``keep[lo:hi]``, the slice found by bisection
+    for its window [k cs, (k+1) cs); windows without a kept sample are skipped
+    (:429-430), and the survivors are re-chunked to ``chunksize``.  On the
+    device the gather is the ``osz_take`` kernel (K7).
+
+    ``shape`` reports min(data length, number of True in the WHOLE mask) along
+    the axis (:399-408); ``chunksize`` is shared with the mask producer
+    (:416-421)."""
 
     def __init__(self, pro, mask, chunksize, axis, **kwargs):
         super().__init__(pro, chunksize, axis, **kwargs)
         self.mask = producer(mask, chunksize, axis=0)
 
+    def _mask_array(self):
+        flags = self.mask.to_array(dtype=bool)
+        if dev.is_tensor(flags):
+            flags = flags.cpu().numpy()
+        return np.asarray(flags, dtype=bool).reshape(-1)
+
     @property
     def shape(self):
-        result = list(self.data.shape)
-        included = int(np.count_nonzero(self.mask.to_array(dtype=bool)))
-        result[self.axis] = min(self.data.shape[self.axis], included)
-        return tuple(result)
+        dims = list(self.data.shape)
+        dims[self.axis] = min(dims[self.axis], int(self._mask_array().sum()))
+        return tuple(dims)
 
     @property
     def chunksize(self):
@@ -208,26 +248,31 @@ class MaskedProducer(Producer):
 
     @chunksize.setter
     def chunksize(self, value):
-        self.data.chunksize = int(value)
-        self.mask.chunksize = int(value)
+        for stream in (self.data, self.mask):
+            stream.chunksize = int(value)
 
     def __iter__(self):
-        collector = FIFOArray(self.chunksize, self.axis)
-        for arr, maskarr in zip(self.data, self.mask):
-            maskarr = np.asarray(maskarr.cpu() if dev.is_tensor(maskarr)
-                                 else maskarr)
-            if not np.any(maskarr):
+        cs = self.chunksize
+        flags = self._mask_array()
+        nsamples = self.data.shape[self.axis]
+        # chunks both streams have: ceil(N / cs) and ceil(K / cs)
+        paired = min(-(-nsamples // cs), -(-flags.size // cs))
+        keep = np.flatnonzero(flags[:paired * cs])
+        # keep[bounds[k]:bounds[k + 1]] falls into the window of data chunk k
+        bounds = np.searchsorted(keep, np.arange(paired + 1) * cs)
+        pending = FIFOArray(cs, self.axis)
+        for k, arr in zip(range(paired), self.data):
+            local = keep[bounds[k]:bounds[k + 1]] - k * cs
+            if local.size == 0:
                 continue
-            keep = np.flatnonzero(maskarr)
             if dev.is_tensor(arr) and arr.is_cuda:
-                filtered = _take_device(arr, keep, self.axis)
+                pending.put(_take_device(arr, local, self.axis))
             else:
-                filtered = np.take(arr, keep, axis=self.axis)
-            collector.put(filtered)
-            while collector.full():
-                yield collector.get()
-        if collector.qsize() > 0:
-            yield collector.get()
+                pending.put(np.take(arr, local, axis=self.axis))
+            while pending.full():
+                yield pending.get()
+        if not pending.empty():
+            yield pending.get()
 
 
 def _take_device(arr, keep, axis):

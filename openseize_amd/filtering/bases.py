@@ -1,13 +1,18 @@
-"""Callable filter bases: the boundary between user code and the hot path.
+"""Callable filter objects: where user code enters the device hot path.
 
-``IIR.__call__`` / ``FIR.__call__`` keep the reference's signatures and
-return rules (filtering/bases.py:153-213, :363-421): an ndarray (or device
-tensor) in gives an array out, a producer in gives a producer out.  Filter
-*design* stays on SciPy exactly as in the reference (O(taps) host math,
-SURVEY section 2 row 10); plotting mixins are out of scope.
+The public contract is the reference's (filtering/bases.py:19-213 ``IIR``,
+:216-421 ``FIR``): the constructor attributes (``fs``, ``nyq``, ``fpass``,
+``fstop``, ``gpass``, ``gstop``, ``fmt``, ``coeffs``, ``ftype``, ``btype``,
+``order`` / ``numtaps``, ``cutoff``, ``width``) and the call signatures
+``IIR(data, chunksize, axis=-1, dephase=True, zi=None, **kwargs)`` and
+``FIR(data, chunksize, axis=-1, mode='same', **kwargs)`` with the rule "array
+in -> array out, producer in -> producer out".  How that contract is met is
+this module's own: one band classifier and one streaming helper shared by both
+families, and a dispatch table instead of per-format branches.  Design-time
+math is SciPy's (O(taps) on the host), applying a filter is the HIP path of
+``core/numerical.py``.  Plotting mixins are out of scope.
 """
 
-import abc
 from functools import partial
 
 import numpy as np
@@ -17,132 +22,155 @@ from openseize_amd import _device as dev
 from openseize_amd.core import numerical as nm
 from openseize_amd.core.producer import producer
 
-
-def _check_bands(fpass, fstop):
-    fpass, fstop = np.atleast_1d(fpass), np.atleast_1d(fstop)
-    if len(fpass) != len(fstop):
-        msg = "fpass and fstop must have the same shape, got {} and {}"
-        raise ValueError(msg.format(fpass.shape, fstop.shape))
-    return fpass, fstop
+# (number of band edges, pass edge below stop edge) -> scipy band name
+_BAND_KIND = {(1, True): "lowpass", (1, False): "highpass",
+              (2, True): "bandstop", (2, False): "bandpass"}
 
 
-class IIR(abc.ABC):
-    """Base of the IIR filters (filtering/bases.py:19-213)."""
+def band_edges(fpass, fstop):
+    """Pass and stop edges as 1-D arrays of equal length (ValueError with the
+    reference's message otherwise, filtering/bases.py:104-106, :278-280)."""
+    edges = [np.atleast_1d(e) for e in (fpass, fstop)]
+    if edges[0].size != edges[1].size:
+        raise ValueError("fpass and fstop must have the same shape, got {} and {}"
+                         .format(edges[0].shape, edges[1].shape))
+    return edges
+
+
+def band_kind(fpass, fstop, max_edges=None, owner=None):
+    """Band type from the edge order: a single edge is a low-pass when the
+    pass edge lies below the stop edge, a pair of edges is a band-stop when the
+    first pass edge lies below the first stop edge.  With ``max_edges`` more
+    edges than that are refused (multiband FIRs, filtering/bases.py:297-311)."""
+    nedges = fpass.size
+    if max_edges is not None and nedges > max_edges:
+        raise ValueError("{} supports only lowpass, highpass, bandpass & bandstop."
+                         .format(owner))
+    return _BAND_KIND[(1 if nedges < 2 else 2, bool(fpass[0] < fstop[0]))]
+
+
+def stream_through(data, chunksize, axis, source_kwargs, make_stage, out_shape):
+    """The call rule both families share: wrap ``data`` in a producer, hang one
+    generator stage behind it, and hand back a producer -- or the assembled
+    array when ``data`` itself was an array (ndarray or device tensor).
+    ``make_stage(source)`` returns the picklable generator function of the
+    stage, ``out_shape(source)`` the shape of the filtered stream."""
+    source = producer(data, chunksize, axis, **source_kwargs)
+    filtered = producer(make_stage(source), chunksize, axis, shape=out_shape(source))
+    return filtered.to_array() if dev.is_arraylike(data) else filtered
+
+
+class _Spec:
+    """Design specification common to both families."""
+
+    def _take_spec(self, fpass, fstop, gpass, gstop, fs):
+        self.fs, self.nyq = fs, fs / 2
+        self.fpass, self.fstop = band_edges(fpass, fstop)
+        self.gpass, self.gstop = gpass, gstop
+
+    @property
+    def ftype(self):
+        """SciPy's name of the design family = the class name in lower case."""
+        return self.__class__.__name__.lower()
+
+
+class IIR(_Spec):
+    """Infinite impulse response filters.  A concrete family names its SciPy
+    minimum-order rule in ``_order_rule`` (``scipy.signal.buttord`` ...);
+    coefficients come from ``scipy.signal.iirfilter`` in ``fmt`` ('sos',
+    'ba'; 'zpk' is stored as 'sos' like the reference, filtering/bases.py:110)."""
+
+    _order_rule = None
+    # fmt -> (causal generator, zero-phase generator) of core/numerical.py
+    _STAGES = {"sos": (nm.sosfilt, nm.sosfiltfilt), "ba": (nm.lfilter, nm.filtfilt)}
 
     def __init__(self, fpass, fstop, gpass, gstop, fs, fmt):
-        self.fs = fs
-        self.nyq = fs / 2
-        self.fpass, self.fstop = _check_bands(fpass, fstop)
-        self.gpass = gpass
-        self.gstop = gstop
-        self.fmt = "sos" if fmt == "zpk" else fmt
+        self._take_spec(fpass, fstop, gpass, gstop, fs)
+        self.fmt = {"zpk": "sos"}.get(fmt, fmt)
         self.coeffs = self._build()
 
     @property
-    def ftype(self):
-        return type(self).__name__.lower()
-
-    @property
     def btype(self):
-        fp, fs = self.fpass, self.fstop
-        if len(fp) < 2:
-            return "lowpass" if fp < fs else "highpass"
-        return "bandstop" if fp[0] < fs[0] else "bandpass"
+        return band_kind(self.fpass, self.fstop)
 
     @property
-    @abc.abstractmethod
     def order(self):
-        """(order, critical frequency) of this filter."""
+        """(lowest order meeting the attenuation spec, critical frequencies)."""
+        if self._order_rule is None:
+            raise NotImplementedError(f"{type(self).__name__} names no order rule")
+        rule = type(self)._order_rule
+        return rule(self.fpass, self.fstop, self.gpass, self.gstop, fs=self.fs)
 
     def _build(self):
-        N, Wn = self.order
-        return sps.iirfilter(N, Wn, rp=self.gpass, rs=self.gstop,
-                             btype=self.btype, ftype=self.ftype,
-                             output=self.fmt, fs=self.fs)
+        nth, critical = self.order
+        return sps.iirfilter(nth, critical, rp=self.gpass, rs=self.gstop, btype=self.btype,
+                             ftype=self.ftype, output=self.fmt, fs=self.fs)
 
-    def __call__(self, data, chunksize, axis=-1, dephase=True, zi=None,
-                 **kwargs):
-        """Applies this filter (filtering/bases.py:153-213).  ``dephase`` runs
-        the forward-backward ``sosfiltfilt``; otherwise the causal ``sosfilt``
-        with optional ``zi`` (ignored when dephasing)."""
-        pro = producer(data, chunksize, axis, **kwargs)
-        if self.fmt == "sos":
+    def __call__(self, data, chunksize, axis=-1, dephase=True, zi=None, **kwargs):
+        """Filters ``data`` in chunks along ``axis``: zero-phase
+        (forward-backward) when ``dephase``, else causal with the optional
+        initial state ``zi`` -- which the zero-phase pass ignores, as in the
+        reference (filtering/bases.py:153-213)."""
+        try:
+            causal, zero_phase = self._STAGES[self.fmt]
+        except KeyError:
+            # the reference falls through with no generator bound (quirk Q10)
+            raise ValueError(f"unknown coefficient format {self.fmt!r}") from None
+
+        def stage(source):
             if dephase:
-                genfunc = partial(nm.sosfiltfilt, pro, self.coeffs, axis)
-            else:
-                genfunc = partial(nm.sosfilt, pro, self.coeffs, axis, zi)
-        elif self.fmt == "ba":
-            if dephase:
-                genfunc = partial(nm.filtfilt, pro, self.coeffs, axis)
-            else:
-                genfunc = partial(nm.lfilter, pro, self.coeffs, axis, zi)
-        else:
-            # the reference leaves genfunc unbound here (quirk Q10)
-            raise ValueError(f"unknown coefficient format {self.fmt!r}")
-        result = producer(genfunc, chunksize, axis, shape=pro.shape)
-        if dev.is_arraylike(data):
-            result = result.to_array()
-        return result
+                return partial(zero_phase, source, self.coeffs, axis)
+            return partial(causal, source, self.coeffs, axis, zi)
+
+        return stream_through(data, chunksize, axis, kwargs, stage, lambda src: src.shape)
 
 
-class FIR(abc.ABC):
-    """Base of the windowed FIR filters (filtering/bases.py:216-421)."""
+class FIR(_Spec):
+    """Windowed-sinc finite impulse response filters.  A concrete window names
+    its tap count in ``numtaps`` (and extra window parameters in
+    ``window_params``); coefficients come from ``scipy.signal.firwin``."""
 
     def __init__(self, fpass, fstop, gpass, gstop, fs, **kwargs):
-        self.fpass, self.fstop = _check_bands(fpass, fstop)
-        self.gpass = gpass
-        self.gstop = gstop
-        self.fs = fs
-        self.nyq = fs / 2
-        self.width = np.min(np.abs(self.fstop - self.fpass))
+        self._take_spec(fpass, fstop, gpass, gstop, fs)
+        # narrowest transition band: it sets the tap count of every window
+        self.width = np.abs(self.fstop - self.fpass).min()
         self.coeffs = self._build(**kwargs)
 
     @property
-    def ftype(self):
-        return type(self).__name__.lower()
-
-    @property
     def btype(self):
-        fp, fs = self.fpass, self.fstop
-        if len(fp) < 2:
-            return "lowpass" if fp < fs else "highpass"
-        if len(fp) == 2:
-            return "bandstop" if fp[0] < fs[0] else "bandpass"
-        msg = "{} supports only lowpass, highpass, bandpass & bandstop."
-        raise ValueError(msg.format(type(self)))
+        return band_kind(self.fpass, self.fstop, max_edges=2, owner=type(self))
 
     @property
     def pass_attenuation(self):
+        """The pass-band ripple ``gpass`` (dB) restated as an attenuation: a
+        ripple amplitude of 10^(-gpass/20) leaves 1 - 10^(-gpass/20)."""
         return -20 * np.log10(1 - 10 ** (-self.gpass / 20))
 
     @property
     def cutoff(self):
-        delta = abs(self.fstop - self.fpass) / 2
-        return delta + np.min(np.stack((self.fpass, self.fstop)), axis=0)
+        """Centre of every transition band (the -6 dB points of the design)."""
+        lower = np.minimum(self.fpass, self.fstop)
+        return np.abs(self.fstop - self.fpass) / 2 + lower
 
     @property
     def window_params(self):
-        return tuple()
+        return ()
 
     @property
-    @abc.abstractmethod
     def numtaps(self):
-        """Number of taps meeting the attenuation criteria."""
+        raise NotImplementedError(f"{type(self).__name__} defines no tap count")
 
     def _build(self, **kwargs):
-        window = (self.ftype, *self.window_params)
         return sps.firwin(self.numtaps, cutoff=self.cutoff, width=None,
-                          window=window, pass_zero=self.btype, scale=True,
-                          fs=self.fs, **kwargs)
+                          window=(self.ftype,) + tuple(self.window_params),
+                          pass_zero=self.btype, scale=True, fs=self.fs, **kwargs)
 
     def __call__(self, data, chunksize, axis=-1, mode="same", **kwargs):
-        """Applies this filter by overlap-add convolution
-        (filtering/bases.py:363-421)."""
-        pro = producer(data, chunksize, axis, **kwargs)
-        window = self.coeffs
-        genfunc = partial(nm.oaconvolve, pro, window, axis, mode)
-        shape = nm.convolved_shape(tuple(data.shape), window.shape, mode, axis)
-        result = producer(genfunc, chunksize, axis, shape=shape)
-        if dev.is_arraylike(data):
-            result = result.to_array()
-        return result
+        """Convolves ``data`` with the taps by streaming overlap-add
+        (filtering/bases.py:363-421); ``mode`` is numpy.convolve's."""
+        taps = self.coeffs
+        data_shape = tuple(data.shape)
+        return stream_through(
+            data, chunksize, axis, kwargs,
+            lambda source: partial(nm.oaconvolve, source, taps, axis, mode),
+            lambda source: nm.convolved_shape(data_shape, taps.shape, mode, axis))
