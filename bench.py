@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X hot path.
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted
-on): 256 channels x float64, chunksize 2^20, 1024-tap FIR overlap-add
-(`firwin(1024, 0.2)`) chained into a 6-section Butterworth band-pass
-`sosfiltfilt` (`butter(6, [0.05, 0.3], 'bandpass')`).  A "step" is one chunk
-(256 x 2^20 channel-samples) through the whole chain in steady state:
+Default workload `chain` (BASELINE.json configs[2], the configuration the
+metric is quoted on): 256 channels x float64, chunksize 2^20, 1024-tap FIR
+overlap-add (`firwin(1024, 0.2)`) chained into a 6-section Butterworth
+band-pass `sosfiltfilt` (`butter(6, [0.05, 0.3], 'bandpass')`).  A "step" is one
+chunk (256 x 2^20 channel-samples) through the whole chain in steady state:
 
     FIR push(chunk k) -> [SOS forward(chunk k) + SOS backward(chunk k-2;
     chunk-local warm-up over forward chunk k-1)] in one launch
@@ -15,6 +15,19 @@ resident chunks keyed by (seed, channel, sample)); outputs land in a resident
 buffer.  With N GPUs every rank runs the same 256-channel shard workload on its
 own GPU (channels are independent: no data-path collective, weak scaling).
 
+Workload `welch` (BASELINE.json configs[3]): Welch PSD, nperseg 4096, 50 %
+overlap, 256 channels; the stream is split in TIME across the ranks (each rank
+pushes its own block of 2^20-sample chunks) and the per-rank periodogram sums
+meet in ONE RCCL all-reduce of (256 x 2049) float64 + the segment count -- the
+"segment-average reduce" of cfg-4, inside the timed region.  A small untimed
+pass then checks the reduced estimate against the single-rank PSD.
+
+Launching: `python bench.py --gpus N` with N > 1 starts N ranks itself (fresh
+child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before
+anything touches the GPU in the parent); under `torch.distributed.run` the
+ranks are already there and the script runs as one of them.  `--dry` runs the
+launcher, the barriers and the collectives on CPU (gloo) without any kernel.
+
 Prints ONE JSON line (see README / the driver contract) with `roofline` for
 the dominant kernel and, at N=1 on rank 0, `cpu_baseline` (the CPU oracle).
 """
@@ -23,6 +36,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,12 +50,16 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 C_PER_GPU = 256
 CHUNK = 1 << 20
 NTAPS = 1024
+NFFT = 4096              # cfg-4: nperseg 4096 (fs 4096, resolution 1.0), 50 % overlap
+RAGGED = 100_000_000 - 95 * CHUNK     # last chunk of the literal 1e8-sample stream
 # algorithmic HBM bytes per channel-sample of one launch
 KERNEL_BYTES = {"fir_oa": 16, "sos_dual": 32, "sos_fwd": 16, "sos_bwd": 16,
-                "sos_warmup": 0, "fir_seam": 0}
+                "sos_warmup": 0, "fir_seam": 0, "spec_fused": 8}
 CHAIN_BYTES = 48         # FIR 16 + sosfiltfilt 32 (unfused)
+METRIC = "Msamples/sec/node (FIR+IIR chain, 256ch f64); HBM GB/s vs roofline at 1/2/4/8 GPU"
 
 
+# --------------------------------------------------------------- CPU baseline
 def _cpu_worker(args):
     """One host core: the CPU oracle chain on `ch` channels x `n` samples."""
     h, sos, ch, n, seed = args
@@ -52,67 +71,172 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(h, sos):
-    """The CPU oracle (oracle/: NumPy FFT overlap-add + C DF2T loops) on a
-    bounded sample of the same workload: once on one core, once with one
-    process per available core (at most 16) over channel shards.  Runs BEFORE
-    the GPU is initialised (worker processes are forked)."""
+def _cpu_welch_worker(args):
+    ch, n, seed = args
+    from oracle import oracle as orc
+    x = np.random.default_rng(seed).standard_normal((ch, n))
+    t0 = time.perf_counter()
+    orc.psd(x, NFFT, resolution=1.0)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(workload, h, sos):
+    """The CPU oracle (oracle/: NumPy FFT overlap-add + C DF2T loops; NumPy
+    windowed rFFT for Welch) on a bounded sample of the same workload: once on
+    one core, once with one process per available core (at most 16) over
+    channel shards.  Runs BEFORE the GPU is initialised (workers are forked)."""
     import multiprocessing as mp
     from oracle import oracle as orc
     orc.build()
     ch, n = 16, 1 << 21
     avail = len(os.sched_getaffinity(0))
     procs = max(1, min(16, avail))
-    single = _cpu_worker((h, sos, ch, n, 0))
+    if workload == "welch":
+        worker, work = _cpu_welch_worker, lambda seed: (ch, n, seed)
+        what = "Welch PSD nfft 4096, 50 % overlap"
+    else:
+        worker, work = _cpu_worker, lambda seed: (h, sos, ch, n, seed)
+        what = "FIR(1024)+sosfiltfilt(6) chain, chunksize 2^20"
+    single = worker(work(0))
     value_1 = ch * n / single / 1e6
     value_p, wall = value_1, single
     if procs > 1:
         ctx = mp.get_context("fork")
         t0 = time.perf_counter()
         with ctx.Pool(procs) as pool:
-            pool.map(_cpu_worker, [(h, sos, ch, n, 100 + i) for i in range(procs)])
+            pool.map(worker, [work(100 + i) for i in range(procs)])
         wall = time.perf_counter() - t0
         value_p = procs * ch * n / wall / 1e6
     return {"value": value_p, "unit": "Msamples/s", "cores": procs, "kind": "port",
             "single_core_value": value_1,
-            "sample": f"{procs} processes x ({ch} ch x 2^21 samples), same "
-                      f"FIR(1024)+sosfiltfilt(6) chain, chunksize 2^20, "
+            "sample": f"{procs} processes x ({ch} ch x 2^21 samples), same {what}, "
                       f"{wall:.1f} s wall; 1 core alone: {value_1:.1f} Msamples/s; "
                       f"host exposes {avail} cores"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu", action="store_true",
-                    help="skip the cpu_baseline leg")
-    args = ap.parse_args()
+# ------------------------------------------------------------------- launcher
+def launch(args):
+    """--gpus N without a rank environment: start N ranks as fresh child
+    processes (one per GPU) and wait for them.  The parent never initialises
+    HIP; nothing is exec'ed from a process that touched the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:          # a dead rank leaves the others in a collective
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
-    import scipy.signal as sps
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    h = sps.firwin(NTAPS, 0.2)
-    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(h, sos)          # before any GPU initialisation
-    import torch
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+# --------------------------------------------------------------------- ranks
+class Ranks:
+    """Rank environment + the few collective helpers the bench needs."""
+
+    def __init__(self, dry):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dry = dry
+        self.dist = None
+        import torch
+        self.torch = torch
+        if not dry:
+            torch.cuda.set_device(self.local)
+        if self.world > 1 or "RANK" in os.environ:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if dry:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
+            self.dist = dist
+        self.device = "cpu" if dry else "cuda"
+
+    def sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        self.sync()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.sync()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def ranks_seen(self):
+        return self.dist.get_world_size() if self.dist is not None else 1
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def kernel_table(lib, samples_per_step):
+    """Per-kernel durations measured with HIP events on the launch stream."""
+    from openseize_amd import _lib
+    kernels = {}
+    for name, bps in KERNEL_BYTES.items():
+        n, ms = ctypes.c_int64(), ctypes.c_double()
+        _lib.check(lib.osz_profile_query(name.encode(), ctypes.byref(n), ctypes.byref(ms)))
+        if n.value:
+            avg = ms.value / n.value
+            kernels[name] = {"launches": n.value, "avg_ms": avg, "total_ms": ms.value,
+                             "achieved_gbps": bps * samples_per_step / (avg * 1e-3) / 1e9}
+    return kernels
+
+
+def roofline_of(kernels, samples_per_step):
+    dom = max(kernels, key=lambda nm: kernels[nm]["total_ms"])
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get(dom)
+    return {"kernel": dom, "bound": "hbm",
+            "achieved": kernels[dom]["achieved_gbps"], "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": kernels[dom]["achieved_gbps"] / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": KERNEL_BYTES[dom] * samples_per_step,
+            "avg_launch_ms": kernels[dom]["avg_ms"]}
+
+
+# ------------------------------------------------------------ workload: chain
+def run_chain(args, R, h, sos):
+    torch = R.torch
+    if R.dry:
+        R.barrier()
+        t0 = time.perf_counter()
+        time.sleep(1e-3 * args.steps)
+        elapsed = R.max_over_ranks(time.perf_counter() - t0)
+        R.barrier()
+        return elapsed, {}, None, None
     from openseize_amd import _device as dev
     from openseize_amd import _lib
     lib = _lib.load()
-
     C = C_PER_GPU
-    ring = [dev.synth_normal(C, CHUNK, seed=0, ch0=rank * C, n0=k * CHUNK)
-            for k in range(3)]
+    ring = [dev.synth_normal(C, CHUNK, seed=0, ch0=R.rank * C, n0=k * CHUNK) for k in range(3)]
     fir = dev.FirStream(h, C)
     iir = dev.SosStream(sos, C)
     fir_out = torch.empty((C, CHUNK), dtype=torch.float64, device="cuda")
@@ -135,14 +259,7 @@ def main():
     for _ in range(max(args.warmup, 2)):
         step(k)
         k += 1
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
+    R.barrier()
     _lib.check(lib.osz_profile_reset())
     _lib.check(lib.osz_profile_enable(1))
     t0 = time.perf_counter()
@@ -152,65 +269,212 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _lib.check(lib.osz_profile_enable(0))
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    barrier()
-
+    elapsed = R.max_over_ranks(elapsed)
+    R.barrier()
     # order-independent checksum of the last output chunk (also the 8 B/lane
     # streaming read of known size that calibrates FETCH_SIZE in the PMC runs)
     bits, fsum = dev.checksum(y_out)
+    kernels = kernel_table(lib, C * CHUNK)
+    extra = {"output_checksum": {"bits": f"{bits:#018x}", "sum": fsum}}
+    if args.full_stream:
+        del fwd, y_out, fir_out
+        fir.close()
+        iir.close()
+        extra["full_stream"] = full_stream_leg(R, ring, h, sos)
+    return elapsed, kernels, roofline_of(kernels, C * CHUNK), extra
 
-    samples_per_step = C * CHUNK
-    value = samples_per_step * args.steps * world / elapsed / 1e6
 
-    # per-kernel durations measured with HIP events on the launch stream
-    kernels = {}
-    for name, bps in KERNEL_BYTES.items():
-        n, ms = ctypes.c_int64(), ctypes.c_double()
-        _lib.check(lib.osz_profile_query(name.encode(), ctypes.byref(n),
-                                         ctypes.byref(ms)))
-        if n.value:
-            avg = ms.value / n.value
-            kernels[name] = {"launches": n.value, "avg_ms": avg,
-                             "total_ms": ms.value,
-                             "achieved_gbps": bps * samples_per_step / (avg * 1e-3) / 1e9}
-    dom = max(kernels, key=lambda nm: kernels[nm]["total_ms"])
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(dom)
-    roofline = {"kernel": dom, "bound": "hbm",
-                "achieved": kernels[dom]["achieved_gbps"], "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": kernels[dom]["achieved_gbps"] / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": KERNEL_BYTES[dom] * samples_per_step,
-                "avg_launch_ms": kernels[dom]["avg_ms"]}
+def full_stream_leg(R, ring, h, sos):
+    """The literal stream length of cfg-3 once, through the PUBLIC producer API:
+    96 chunks (95 x 2^20 + 385 280 samples = 1e8 per channel) of 256 channels
+    from the resident synth ring -> FIR(1024, 'same') producer -> sosfiltfilt
+    generator, outputs consumed and dropped.  Secondary number: `value` stays
+    the steady-state kernel sequence above."""
+    from functools import partial
+    from openseize_amd import producer
+    from openseize_amd.core import numerical as nm
+    torch = R.torch
+    C = ring[0].shape[0]
+    lengths = [CHUNK] * 95 + [RAGGED]
+    total = sum(lengths)
 
+    def source():
+        for k, m in enumerate(lengths):
+            yield ring[k % len(ring)][:, :m]
+
+    src = producer(source, CHUNK, -1, shape=(C, total))
+    fir = producer(partial(nm.oaconvolve, src, h, -1, "same"), CHUNK, -1, shape=(C, total))
+    R.barrier()
+    t0 = time.perf_counter()
+    got = 0
+    for out in nm.sosfiltfilt(fir, sos, -1):
+        got += out.shape[-1]
+    torch.cuda.synchronize()
+    secs = time.perf_counter() - t0
+    assert got == total, (got, total)
+    return {"chunks": len(lengths), "samples_per_channel": total, "channels": C,
+            "seconds": secs, "Msamples_s": C * total / secs / 1e6,
+            "path": "producer(gen) -> oaconvolve('same') -> GenProducer -> sosfiltfilt, "
+                    "device-resident ring of 3 synthesised chunks"}
+
+
+# ------------------------------------------------------------ workload: welch
+def run_welch(args, R):
+    torch = R.torch
+    import scipy.signal as sps
+    from openseize_amd import sharding
+    C = C_PER_GPU
+    stride = NFFT // 2
+    if R.dry:
+        # the partition + reduce logic without kernels: "periodograms" that are
+        # a known function of the global segment index
+        nseg_total = 40 * R.world + 3
+        nsamples = (nseg_total - 1) * stride + NFFT
+        a, b = sharding.time_block(nsamples, NFFT, stride, R.rank, R.world)
+        mine = range(a // stride, a // stride + (b - a - NFFT) // stride + 1) if b > a else range(0)
+        base = np.arange(4 * 33, dtype=np.float64).reshape(4, 33)
+        R.barrier()
+        t0 = time.perf_counter()
+        total = torch.from_numpy(sum((base * (g + 1) for g in mine), np.zeros_like(base)))
+        mean, cnt = sharding.reduce_segment_sums(total, len(mine))
+        elapsed = R.max_over_ranks(time.perf_counter() - t0)
+        R.barrier()
+        want = base * (nseg_total + 1) / 2
+        err = float(np.max(np.abs(mean.numpy() - want)) / np.max(want))
+        assert cnt == nseg_total and err < 1e-13, (cnt, nseg_total, err)
+        return elapsed, {}, None, {"welch_check": {"segments": cnt, "max_rel_err": err,
+                                                   "against": "closed form (dry run)"}}
+    from openseize_amd import _device as dev
+    from openseize_amd import _lib
+    lib = _lib.load()
+    w = sps.get_window("hann", NFFT)
+    scale = float(np.sqrt(1 / (float(NFFT) * np.sum(w ** 2))))      # fs = 4096, density
+    # this rank's time block: chunk k of the block starts at sample
+    # (rank * steps + k) * CHUNK of the stream; the ring repeats for timing only
+    ring = [dev.synth_normal(C, CHUNK, seed=0, n0=(R.rank * 3 + k) * CHUNK) for k in range(3)]
+    spec = dev.SpecStream(NFFT, NFFT, stride, w, scale, "constant", _lib.SPEC_PSD_MEAN, C)
+    comm = None
+    if args.reduce == "abi":
+        # an RCCL communicator made through the C ABI; the unique id travels over
+        # the torch.distributed group that exists anyway
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if R.rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(dev.RcclComm.unique_id()), dtype=torch.uint8))
+        if R.dist is not None:
+            R.dist.broadcast(uid, src=0)
+        comm = dev.RcclComm(R.world, R.rank, bytes(uid.cpu().numpy().tobytes()))
+    for k in range(max(args.warmup, 1)):
+        spec.push(ring[k % 3])
+    _lib.check(lib.osz_spec_reset(spec.h, dev.stream_ptr()))
+    R.barrier()
+    _lib.check(lib.osz_profile_reset())
+    _lib.check(lib.osz_profile_enable(1))
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        spec.push(ring[k % 3])
+    if comm is not None:
+        spec.welch_reduce(comm)                         # osz_welch_reduce (RCCL, C ABI)
+        cnt, mean = spec.mean_device()
+    else:
+        total, cnt = spec.export_sum()
+        mean, cnt = sharding.reduce_segment_sums(total, cnt)   # RCCL via torch.distributed
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.check(lib.osz_profile_enable(0))
+    elapsed = R.max_over_ranks(elapsed)
+    R.barrier()
+    spec.close()
+    kernels = kernel_table(lib, C * CHUNK)
+    # ---- untimed check: time split over the ranks == single-rank PSD
+    Cv, nv = 64, R.world * (1 << 18) + 1234
+
+    def block(a, b):
+        return dev.synth_normal(Cv, b - a, seed=7, n0=a)
+
+    cntv, _, pv = sharding.psd_time_split(block, 4096, R.rank, R.world, resolution=1.0,
+                                          nsamples=nv, shape=(Cv, nv), chunksize=1 << 18)
+    check = None
+    if R.rank == 0:
+        from openseize_amd.spectra.estimators import psd
+        c1, _, p1 = psd(block(0, nv), fs=4096, axis=-1, resolution=1.0)
+        err = float((pv - p1).abs().max() / p1.abs().max())
+        assert cntv == c1 and err < 1e-9, (cntv, c1, err)
+        check = {"segments": int(cntv), "max_rel_err": err, "reduce": args.reduce,
+                 "against": "single-rank psd() of the same synthetic stream"}
+    if comm is not None:
+        comm.close()
+    extra = {"welch_check": check, "segments_per_rank": int(cnt) // max(R.world, 1),
+             "reduce_bytes_per_rank": C * (NFFT // 2 + 1) * 8}
+    return elapsed, kernels, roofline_of(kernels, C * CHUNK), extra
+
+
+# ----------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("chain", "welch"), default="chain")
+    ap.add_argument("--reduce", choices=("torch", "abi"), default="torch",
+                    help="welch: all-reduce through torch.distributed (RCCL) or through "
+                         "osz_welch_reduce of the C ABI")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--full-stream", action="store_true",
+                    help="chain: also time the literal 96-chunk (1e8-sample) stream once "
+                         "through the public producer API")
+    ap.add_argument("--dry", action="store_true",
+                    help="launcher, barriers and collectives on CPU (gloo), no kernels")
+    args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch(args))
+
+    import scipy.signal as sps
+    h = sps.firwin(NTAPS, 0.2)
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu = None
+    if int(os.environ.get("RANK", "0")) == 0 and world_env == 1 and not (args.no_cpu or args.dry):
+        cpu = cpu_baseline(args.workload, h, sos)       # before any GPU initialisation
+    R = Ranks(args.dry)
+    if args.workload == "welch":
+        elapsed, kernels, roofline, extra = run_welch(args, R)
+        metric = "Msamples/sec/node (Welch PSD nperseg 4096, 50 % overlap, 256ch f64)"
+        bytes_per_sample, label = 8, (
+            "cfg-4: Welch PSD nperseg 4096, 50 % overlap, hann, 256 ch x 2^20-sample chunks per "
+            "GPU, stream split in time across ranks, one all-reduce of (256 x 2049) f64 + count")
+        parallelism = f"time-split x{R.world} + all-reduce"
+    else:
+        elapsed, kernels, roofline, extra = run_chain(args, R, h, sos)
+        metric = METRIC
+        bytes_per_sample, label = CHAIN_BYTES, (
+            "cfg-3: 256 ch/GPU x 2^20-sample chunks, FIR overlap-add 1024 taps -> 6-section "
+            "Butterworth band-pass sosfiltfilt, steady-state stream")
+        parallelism = f"channel-shard x{R.world}"
+    samples_per_step = C_PER_GPU * CHUNK
+    value = samples_per_step * args.steps * R.world / elapsed / 1e6
     out = {
-        "metric": "Msamples/sec/node (FIR+IIR chain, 256ch f64); HBM GB/s vs roofline at 1/2/4/8 GPU",
-        "value": value, "unit": "Msamples/s", "n_gpus": world,
+        "metric": metric, "value": value, "unit": "Msamples/s", "n_gpus": R.world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "cfg-3: 256 ch/GPU x 2^20-sample chunks, FIR "
-                               "overlap-add 1024 taps -> 6-section Butterworth "
-                               "band-pass sosfiltfilt, steady-state stream",
-                   "channels_per_gpu": C, "chunksize": CHUNK, "fir_taps": NTAPS,
-                   "sos_sections": int(sos.shape[0]), "parallelism": f"channel-shard x{world}"},
-        "chain_hbm_gbps": value * 1e6 * CHAIN_BYTES / 1e9 / world,
-        "chain_hbm_frac": value * 1e6 * CHAIN_BYTES / 1e9 / world / HBM_PEAK_GBPS,
+        "config": {"workload": label, "channels_per_gpu": C_PER_GPU, "chunksize": CHUNK,
+                   "fir_taps": NTAPS, "sos_sections": int(sos.shape[0]),
+                   "parallelism": parallelism},
+        "rccl_ranks": R.ranks_seen(),
+        "chain_hbm_gbps": value * 1e6 * bytes_per_sample / 1e9 / R.world,
+        "chain_hbm_frac": value * 1e6 * bytes_per_sample / 1e9 / R.world / HBM_PEAK_GBPS,
         "roofline": roofline, "kernels": kernels,
-        "output_checksum": {"bits": f"{bits:#018x}", "sum": fsum},
     }
+    if args.dry:
+        out["dry"] = True
+    if extra:
+        out.update(extra)
     if cpu is not None:
         out["cpu_baseline"] = cpu
-    if rank == 0:
+    if R.rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":

@@ -146,6 +146,12 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx,
 int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch);
 int osz_fir_destroy(osz_fir_t h);
 int osz_fir_reset(osz_fir_t h, void *stream);
+/* Checkpoint / resume (the de-facto state of the reference's
+ * generator is the overlap tail, core/numerical.py:223, :269): the carried
+ * tail(s) as osz_fir_state_size() host doubles.  Synchronous. */
+int64_t osz_fir_state_size(osz_fir_t h);
+int osz_fir_get_state(osz_fir_t h, double *state, void *stream);
+int osz_fir_set_state(osz_fir_t h, const double *state, void *stream);
 /* Consumes x (nch, n) and writes the n next samples of the full convolution,
  * minus the first `skip` of them, to y (nch, n - skip); 0 <= skip <= n. */
 int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n,
@@ -183,6 +189,11 @@ int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M,
                     int nch);
 int osz_poly_destroy(osz_poly_t h);
 int osz_poly_reset(osz_poly_t h, void *stream);
+/* Checkpoint / resume: [samples consumed, samples produced, input history]
+ * as osz_poly_state_size() host doubles.  Synchronous. */
+int64_t osz_poly_state_size(osz_poly_t h);
+int osz_poly_get_state(osz_poly_t h, double *state, void *stream);
+int osz_poly_set_state(osz_poly_t h, const double *state, void *stream);
 /* Number of output samples a push of n more input samples will produce
  * (final != 0: the stream ends with this push, total = ceil(N*L/M)). */
 int64_t osz_poly_out_count(osz_poly_t h, int64_t n, int final);
@@ -229,6 +240,40 @@ int osz_spec_sum(osz_spec_t h, double **dsum, int64_t *count);
 int osz_spec_export_sum(osz_spec_t h, double *dst, int64_t *count, void *stream);
 /* PSD_MEAN: mean = sum / count into host array (nch, nfreq). Synchronous. */
 int osz_spec_mean(osz_spec_t h, double *mean, int64_t *count, void *stream);
+
+/* PSD_MEAN: mean = sum / count into a caller-owned DEVICE buffer (nch, nfreq):
+ * the estimate never leaves HBM.  Asynchronous on `stream`. */
+int osz_spec_mean_device(osz_spec_t h, double *dmean, int64_t *count, void *stream);
+/* Checkpoint / resume: [carried samples, segment count, FIFO remainder
+ * (core/numerical.py:821), periodogram sum] as osz_spec_state_size() host
+ * doubles.  Synchronous. */
+int64_t osz_spec_state_size(osz_spec_t h);
+int osz_spec_get_state(osz_spec_t h, double *state, void *stream);
+int osz_spec_set_state(osz_spec_t h, const double *state, void *stream);
+
+/* ---- the one collective: Welch segment average over a time split ------ */
+/*
+ * The reference averages the periodograms of the whole stream with a running
+ * mean (spectra/estimators.py:149-152).  When the stream of a channel block is
+ * split in time across GPUs (one process per GPU), each rank's PSD_MEAN handle
+ * holds the sum over its own segments; osz_welch_reduce all-reduces (sum) the
+ * (nch, nfreq) accumulator and the segment count over the ranks of an RCCL
+ * communicator, in place: afterwards osz_spec_mean / _mean_device /
+ * _export_sum on ANY rank give the average over the whole stream.
+ * comm is an ncclComm_t (void*) of the RCCL instance this library binds at run
+ * time: the one already mapped in the process (a PyTorch host), else
+ * /opt/rocm/lib/librccl.so.1.  A host without PyTorch creates the
+ * communicator through the three helpers below; the 128-byte unique id
+ * travels from rank 0 to the others by the host's own means (file, socket).
+ * osz_welch_reduce synchronises `stream` (the count comes back to the host).
+ */
+#define OSZ_RCCL_ID_BYTES 128
+int osz_rccl_bind(const char *librccl_path /* NULL: default search */);
+int osz_rccl_unique_id(char *id128);
+int osz_rccl_comm_create(void **comm, int nranks, int rank, const char *id128);
+int osz_rccl_comm_destroy(void *comm);
+int osz_rccl_comm_size(void *comm, int *nranks);
+int osz_welch_reduce(osz_spec_t h, void *comm, void *stream);
 
 /* ---- K7: mask compaction ---------------------------------------------- */
 /* y[c, j] = x[c, idx[j]], j < nidx: np.take(arr, np.flatnonzero(mask), axis)

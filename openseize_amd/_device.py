@@ -177,10 +177,26 @@ class Layout:
 
 class _Handle:
     _destroy = None
+    _state = None          # prefix of the osz_*_state_size / _get_state / _set_state trio
 
     def __init__(self):
         self.h = ctypes.c_void_p()
         self.lib = require_gpu()
+
+    def get_state(self):
+        """The iterator's carried state as a flat host array (checkpoint)."""
+        n = getattr(self.lib, self._state + "_state_size")(self.h)
+        buf = np.empty(int(n))
+        _lib.check(getattr(self.lib, self._state + "_get_state")(self.h, host_dp(buf), stream_ptr()))
+        return buf
+
+    def set_state(self, state):
+        """Resume from a state taken with ``get_state`` on an identical handle."""
+        n = getattr(self.lib, self._state + "_state_size")(self.h)
+        buf = np.ascontiguousarray(state, dtype=np.float64)
+        if buf.shape != (int(n),):
+            raise ValueError(f"state must have {int(n)} entries, got {buf.shape}")
+        _lib.check(getattr(self.lib, self._state + "_set_state")(self.h, host_dp(buf), stream_ptr()))
 
     def close(self):
         if self.h:
@@ -270,6 +286,7 @@ class SosStream(_Handle):
 class FirStream(_Handle):
     """One iterator's overlap-add state (C ABI: osz_fir_*)."""
     _destroy = "osz_fir_destroy"
+    _state = "osz_fir"
 
     def __init__(self, taps, nch):
         super().__init__()
@@ -313,6 +330,7 @@ def chain_forward(fir, sos, x2d, out=None):
 class PolyStream(_Handle):
     """One iterator's polyphase resampler state (C ABI: osz_poly_*)."""
     _destroy = "osz_poly_destroy"
+    _state = "osz_poly"
 
     def __init__(self, taps, L, M, nch):
         super().__init__()
@@ -336,6 +354,7 @@ class PolyStream(_Handle):
 class SpecStream(_Handle):
     """One iterator's segmenter / windowed-DFT state (C ABI: osz_spec_*)."""
     _destroy = "osz_spec_destroy"
+    _state = "osz_spec"
 
     def __init__(self, nwin, nfft, stride, window, scale, detrend, mode, nch):
         super().__init__()
@@ -388,6 +407,51 @@ class SpecStream(_Handle):
         _lib.check(self.lib.osz_spec_mean(self.h, host_dp(out),
                                           ctypes.byref(cnt), stream_ptr()))
         return cnt.value, out
+
+    def mean_device(self, device="cuda"):
+        """(count, CUDA tensor (nch, nfreq)): the segment average taken on the
+        device (osz_spec_mean_device); nothing crosses PCIe."""
+        out = torch.empty((self.nch, self.nfreq), dtype=torch.float64, device=device)
+        cnt = ctypes.c_int64()
+        _lib.check(self.lib.osz_spec_mean_device(self.h, ptr(out), ctypes.byref(cnt),
+                                                 stream_ptr()))
+        return cnt.value, out
+
+    def welch_reduce(self, comm):
+        """All-reduce (sum) of the periodogram accumulator and the segment
+        count over the ranks of an ``RcclComm`` (osz_welch_reduce)."""
+        _lib.check(self.lib.osz_welch_reduce(self.h, comm.comm, stream_ptr()))
+
+
+class RcclComm:
+    """An RCCL communicator created through the C ABI (osz_rccl_*), for hosts
+    that do not run torch.distributed.  ``unique_id()`` on rank 0 gives the 128
+    bytes every rank passes to the constructor."""
+
+    def __init__(self, nranks, rank, unique_id):
+        self.lib = require_gpu()
+        self.comm = ctypes.c_void_p()
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be 128 bytes")
+        _lib.check(self.lib.osz_rccl_comm_create(ctypes.byref(self.comm), nranks, rank,
+                                                 bytes(unique_id)))
+
+    @staticmethod
+    def unique_id():
+        lib = require_gpu()
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(lib.osz_rccl_unique_id(buf))
+        return buf.raw
+
+    def size(self):
+        n = ctypes.c_int()
+        _lib.check(self.lib.osz_rccl_comm_size(self.comm, ctypes.byref(n)))
+        return n.value
+
+    def close(self):
+        if self.comm:
+            _lib.check(self.lib.osz_rccl_comm_destroy(self.comm))
+            self.comm = ctypes.c_void_p()
 
 
 def take(x2d, idx):

@@ -76,6 +76,9 @@ SIGNATURES = {
                                       ctypes.c_int]),
     "osz_fir_destroy": (ctypes.c_int, [c_vp]),
     "osz_fir_reset": (ctypes.c_int, [c_vp, c_vp]),
+    "osz_fir_state_size": (c_i64, [c_vp]),
+    "osz_fir_get_state": (ctypes.c_int, [c_vp, c_dp, c_vp]),
+    "osz_fir_set_state": (ctypes.c_int, [c_vp, c_dp, c_vp]),
     "osz_fir_push": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64,
                                     c_i64, c_vp]),
     "osz_fir_flush": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
@@ -84,6 +87,9 @@ SIGNATURES = {
                                        ctypes.c_int]),
     "osz_poly_destroy": (ctypes.c_int, [c_vp]),
     "osz_poly_reset": (ctypes.c_int, [c_vp, c_vp]),
+    "osz_poly_state_size": (c_i64, [c_vp]),
+    "osz_poly_get_state": (ctypes.c_int, [c_vp, c_dp, c_vp]),
+    "osz_poly_set_state": (ctypes.c_int, [c_vp, c_dp, c_vp]),
     "osz_poly_out_count": (c_i64, [c_vp, c_i64, ctypes.c_int]),
     "osz_poly_push": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_int,
                                      c_vp, c_i64, ctypes.POINTER(c_i64), c_vp]),
@@ -100,6 +106,17 @@ SIGNATURES = {
                                     ctypes.POINTER(c_i64)]),
     "osz_spec_export_sum": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
     "osz_spec_mean": (ctypes.c_int, [c_vp, c_dp, ctypes.POINTER(c_i64), c_vp]),
+    "osz_spec_mean_device": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
+    "osz_spec_state_size": (c_i64, [c_vp]),
+    "osz_spec_get_state": (ctypes.c_int, [c_vp, c_dp, c_vp]),
+    "osz_spec_set_state": (ctypes.c_int, [c_vp, c_dp, c_vp]),
+    "osz_rccl_bind": (ctypes.c_int, [ctypes.c_char_p]),
+    "osz_rccl_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "osz_rccl_comm_create": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_char_p]),
+    "osz_rccl_comm_destroy": (ctypes.c_int, [c_vp]),
+    "osz_rccl_comm_size": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int)]),
+    "osz_welch_reduce": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "osz_take": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp,
                                 c_i64, c_vp]),
     "osz_edf_decode": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp,

@@ -54,6 +54,10 @@ int current_device(int *dev);
 
 constexpr int kWave = 64;  // CDNA wavefront width
 
+// rccl.hip: in-place all-reduce(sum) of `count` float64 / int64 elements over
+// the ranks of an ncclComm_t; RCCL is bound at run time (dlopen)
+int rccl_allreduce_sum(void *buf, size_t count, bool is_f64, void *comm, hipStream_t st);
+
 // Optional per-kernel timing with HIP events on the launch stream
 // (osz_profile_enable / osz_profile_query): bench.py uses it to get each
 // kernel's average duration live, inside the timed region.

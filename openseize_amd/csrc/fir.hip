@@ -458,6 +458,48 @@ int osz_fir_reset(osz_fir_t h, void *stream) {
     return OSZ_OK;
 }
 
+// ---- checkpoint / resume: the carried tail of every piece, then the deferred sums
+int64_t osz_fir_state_size(osz_fir_t h) {
+    if (!h) return -1;
+    int64_t n = (int64_t)h->nch * h->dlen;
+    for (auto &pt : h->parts) n += (int64_t)h->nch * (pt.ntaps - 1);
+    return n;
+}
+
+static int fir_state_copy(osz_fir_t h, double *host, bool to_host, hipStream_t st) {
+    double *p = host;
+    for (auto &pt : h->parts) {
+        const size_t n = (size_t)h->nch * (pt.ntaps - 1);
+        if (n == 0) continue;
+        if (to_host)
+            OSZ_HIP(hipMemcpyAsync(p, pt.dstate[pt.cur], sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        else
+            OSZ_HIP(hipMemcpyAsync(pt.dstate[pt.cur], p, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        p += n;
+    }
+    if (h->dlen > 0) {
+        const size_t n = (size_t)h->nch * h->dlen;
+        if (to_host)
+            OSZ_HIP(hipMemcpyAsync(p, h->dD, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        else
+            OSZ_HIP(hipMemcpyAsync(h->dD, p, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    }
+    OSZ_HIP(hipStreamSynchronize(st));
+    return OSZ_OK;
+}
+
+int osz_fir_get_state(osz_fir_t h, double *state, void *stream) {
+    OSZ_REQUIRE(h && state, "osz_fir_get_state: null argument");
+    OSZ_SAME_DEVICE(h, "osz_fir_get_state");
+    return fir_state_copy(h, state, true, as_stream(stream));
+}
+
+int osz_fir_set_state(osz_fir_t h, const double *state, void *stream) {
+    OSZ_REQUIRE(h && state, "osz_fir_set_state: null argument");
+    OSZ_SAME_DEVICE(h, "osz_fir_set_state");
+    return fir_state_copy(h, const_cast<double *>(state), false, as_stream(stream));
+}
+
 int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y, int64_t ldy,
                  int64_t skip, void *stream) {
     OSZ_REQUIRE(h && x, "osz_fir_push: null argument");

@@ -296,6 +296,34 @@ int osz_poly_reset(osz_poly_t h, void *stream) {
     return OSZ_OK;
 }
 
+// ---- checkpoint / resume: [samples consumed, samples produced, history (nch x H)]
+int64_t osz_poly_state_size(osz_poly_t h) { return h ? 2 + (int64_t)h->nch * h->H : -1; }
+
+int osz_poly_get_state(osz_poly_t h, double *state, void *stream) {
+    OSZ_REQUIRE(h && state, "osz_poly_get_state: null argument");
+    OSZ_SAME_DEVICE(h, "osz_poly_get_state");
+    hipStream_t st = as_stream(stream);
+    state[0] = (double)h->nin;
+    state[1] = (double)h->nout;
+    OSZ_HIP(hipMemcpyAsync(state + 2, h->dhist[h->cur], sizeof(double) * (size_t)h->nch * h->H,
+                           hipMemcpyDeviceToHost, st));
+    OSZ_HIP(hipStreamSynchronize(st));
+    return OSZ_OK;
+}
+
+int osz_poly_set_state(osz_poly_t h, const double *state, void *stream) {
+    OSZ_REQUIRE(h && state, "osz_poly_set_state: null argument");
+    OSZ_SAME_DEVICE(h, "osz_poly_set_state");
+    OSZ_REQUIRE(state[0] >= 0 && state[1] >= 0, "osz_poly_set_state: negative counters");
+    hipStream_t st = as_stream(stream);
+    OSZ_HIP(hipMemcpyAsync(h->dhist[h->cur], state + 2, sizeof(double) * (size_t)h->nch * h->H,
+                           hipMemcpyHostToDevice, st));
+    OSZ_HIP(hipStreamSynchronize(st));
+    h->nin = (int64_t)state[0];
+    h->nout = (int64_t)state[1];
+    return OSZ_OK;
+}
+
 int64_t osz_poly_out_count(osz_poly_t h, int64_t n, int final_) {
     if (!h || n < 0) return -1;
     return poly_end(h, h->nin + n, final_) - h->nout;

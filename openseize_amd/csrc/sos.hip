@@ -251,13 +251,27 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
                 }
             }
             double z0 = 0.0, z1 = 0.0;
+            if (b2 == 1.0) {
+                // b2 = 1 (every section but the first of a Butterworth /
+                // Chebyshev / elliptic design): one multiply less per sample,
+                // bit-identical (1.0 * x == x); the branch is wave-uniform
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                const double xin = v[j];
-                const double y = fma(b0, xin, z0);
-                z0 = fma(na1, y, fma(b1, xin, z1));
-                z1 = fma(na2, y, b2 * xin);
-                v[j] = y;
+                for (int j = 0; j < T; ++j) {
+                    const double xin = v[j];
+                    const double y = fma(b0, xin, z0);
+                    z0 = fma(na1, y, fma(b1, xin, z1));
+                    z1 = fma(na2, y, xin);
+                    v[j] = y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const double xin = v[j];
+                    const double y = fma(b0, xin, z0);
+                    z0 = fma(na1, y, fma(b1, xin, z1));
+                    z1 = fma(na2, y, b2 * xin);
+                    v[j] = y;
+                }
             }
             const double e0raw = wave_full ? z0 : zc0, e1raw = wave_full ? z1 : zc1;
             // per-lane constants for later (issued early: the load flies meanwhile)

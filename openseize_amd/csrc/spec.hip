@@ -380,6 +380,7 @@ struct osz_spec_s {
     int64_t ncarry, ncap;
     double *dsum;       // (nch, nfreq) PSD_MEAN accumulator
     int64_t count;      // segments accumulated
+    int64_t *dcount;    // device scratch for the count of osz_welch_reduce
     // batched FFT staging, grow-only
     double *drows, *dspec;
     int64_t rows_cap;   // rows the staging buffers hold
@@ -463,6 +464,7 @@ int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride, const double 
     OSZ_HIP(hipMalloc(&p->dcarry[0], cb));
     OSZ_HIP(hipMalloc(&p->dcarry[1], cb));
     OSZ_HIP(hipMalloc(&p->dsum, ab));
+    OSZ_HIP(hipMalloc(&p->dcount, sizeof(int64_t)));
     OSZ_HIP(hipMemcpy(p->dwindow, window, sizeof(double) * nwin, hipMemcpyHostToDevice));
     OSZ_HIP(hipMemset(p->dsum, 0, ab));
     *h = p;
@@ -477,6 +479,7 @@ int osz_spec_destroy(osz_spec_t h) {
     (void)hipFree(h->dcarry[0]);
     (void)hipFree(h->dcarry[1]);
     (void)hipFree(h->dsum);
+    (void)hipFree(h->dcount);
     (void)hipFree(h->drows);
     (void)hipFree(h->dspec);
     (void)hipFree(h->dwork);
@@ -688,6 +691,75 @@ int osz_spec_export_sum(osz_spec_t h, double *dst, int64_t *count, void *stream)
     OSZ_HIP(hipMemcpyAsync(dst, h->dsum, sizeof(double) * (size_t)h->nch * h->nfreq,
                            hipMemcpyDeviceToDevice, as_stream(stream)));
     *count = h->count;
+    return OSZ_OK;
+}
+
+// dst = sum / count on the device (the divide of estimators.py:149-152's mean)
+__global__ void spec_mean_kernel(const double *sum, double *dst, size_t ne, double count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ne) dst[i] = sum[i] / count;
+}
+
+int osz_spec_mean_device(osz_spec_t h, double *dmean, int64_t *count, void *stream) {
+    OSZ_REQUIRE(h && dmean && count, "osz_spec_mean_device: null argument");
+    OSZ_REQUIRE(h->mode == OSZ_SPEC_PSD_MEAN, "osz_spec_mean_device: handle is not in PSD_MEAN mode");
+    OSZ_SAME_DEVICE(h, "osz_spec_mean_device");
+    const size_t ne = (size_t)h->nch * h->nfreq;
+    hipLaunchKernelGGL(spec_mean_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), h->dsum, dmean, ne, h->count > 0 ? (double)h->count : 1.0);
+    OSZ_HIP(hipGetLastError());
+    *count = h->count;
+    return OSZ_OK;
+}
+
+int osz_welch_reduce(osz_spec_t h, void *comm, void *stream) {
+    OSZ_REQUIRE(h && comm, "osz_welch_reduce: null argument");
+    OSZ_REQUIRE(h->mode == OSZ_SPEC_PSD_MEAN, "osz_welch_reduce: handle is not in PSD_MEAN mode");
+    OSZ_SAME_DEVICE(h, "osz_welch_reduce");
+    hipStream_t st = as_stream(stream);
+    OSZ_HIP(hipMemcpyAsync(h->dcount, &h->count, sizeof(int64_t), hipMemcpyHostToDevice, st));
+    int rc = rccl_allreduce_sum(h->dsum, (size_t)h->nch * h->nfreq, true, comm, st);
+    if (rc) return rc;
+    rc = rccl_allreduce_sum(h->dcount, 1, false, comm, st);
+    if (rc) return rc;
+    int64_t total = 0;
+    OSZ_HIP(hipMemcpyAsync(&total, h->dcount, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    OSZ_HIP(hipStreamSynchronize(st));
+    h->count = total;
+    return OSZ_OK;
+}
+
+// ---- checkpoint / resume: [ncarry, count, carry (nch x ncap), sum (nch x nfreq)]
+int64_t osz_spec_state_size(osz_spec_t h) {
+    return h ? 2 + (int64_t)h->nch * h->ncap + (int64_t)h->nch * h->nfreq : -1;
+}
+
+int osz_spec_get_state(osz_spec_t h, double *state, void *stream) {
+    OSZ_REQUIRE(h && state, "osz_spec_get_state: null argument");
+    OSZ_SAME_DEVICE(h, "osz_spec_get_state");
+    hipStream_t st = as_stream(stream);
+    const size_t nc = (size_t)h->nch * h->ncap, ns = (size_t)h->nch * h->nfreq;
+    state[0] = (double)h->ncarry;
+    state[1] = (double)h->count;
+    OSZ_HIP(hipMemcpyAsync(state + 2, h->dcarry[h->cur], sizeof(double) * nc, hipMemcpyDeviceToHost, st));
+    OSZ_HIP(hipMemcpyAsync(state + 2 + nc, h->dsum, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
+    OSZ_HIP(hipStreamSynchronize(st));
+    return OSZ_OK;
+}
+
+int osz_spec_set_state(osz_spec_t h, const double *state, void *stream) {
+    OSZ_REQUIRE(h && state, "osz_spec_set_state: null argument");
+    OSZ_SAME_DEVICE(h, "osz_spec_set_state");
+    const int64_t ncarry = (int64_t)state[0], count = (int64_t)state[1];
+    OSZ_REQUIRE(ncarry >= 0 && ncarry < h->nwin && count >= 0,
+                "osz_spec_set_state: ncarry=%lld count=%lld", (long long)ncarry, (long long)count);
+    hipStream_t st = as_stream(stream);
+    const size_t nc = (size_t)h->nch * h->ncap, ns = (size_t)h->nch * h->nfreq;
+    OSZ_HIP(hipMemcpyAsync(h->dcarry[h->cur], state + 2, sizeof(double) * nc, hipMemcpyHostToDevice, st));
+    OSZ_HIP(hipMemcpyAsync(h->dsum, state + 2 + nc, sizeof(double) * ns, hipMemcpyHostToDevice, st));
+    OSZ_HIP(hipStreamSynchronize(st));
+    h->ncarry = ncarry;
+    h->count = count;
     return OSZ_OK;
 }
 

@@ -80,28 +80,43 @@ def gather_channels(local, nch, axis=0, group=None):
 
 def psd_time_split(data, fs, rank, world, resolution=0.5, window="hann",
                    overlap=0.5, detrend="constant", scaling="density",
-                   group=None):
-    """Welch PSD of (channels, samples) data with the segments split across
-    the ranks of `group` and ONE all-reduce of the per-rank periodogram sums
-    (cfg-4's "RCCL segment-average reduce").  Every rank passes the same
-    full-length `data` (or a view of it); each reads only its own time block.
-    Returns (cnt, freqs, psd) identical on every rank."""
+                   group=None, nsamples=None, shape=None, chunksize=None):
+    """Welch PSD of a (channels..., samples) stream with the SEGMENTS split
+    across the ranks of ``group`` and ONE all-reduce of the per-rank
+    periodogram sums (cfg-4's "RCCL segment-average reduce",
+    reference spectra/estimators.py:149-152 for the whole stream).
+
+    ``data`` is either an array / device tensor (every rank passes a view of
+    the same stream and reads only its own time block), or a callable
+    ``data(start, stop)`` returning this rank's samples [start, stop) as an
+    array, tensor or producer -- a rank then never holds or even addresses the
+    rest of the stream (204.8 GB per rank at cfg-4); ``nsamples`` and ``shape``
+    (the shape of the whole stream) are required with a callable.
+    Returns (cnt, freqs, psd), identical on every rank."""
     nfft = int(fs / resolution)
     stride = nfft - int(nfft * overlap)
-    n = data.shape[-1]
-    a, b = time_block(n, nfft, stride, rank, world)
+    if callable(data):
+        if nsamples is None or shape is None:
+            raise ValueError("a callable source needs nsamples and shape")
+        full_shape = tuple(shape)
+    else:
+        full_shape = tuple(data.shape)
+        nsamples = full_shape[-1]
+    a, b = time_block(int(nsamples), nfft, stride, rank, world)
     freqs = np.fft.rfftfreq(nfft, 1 / fs)
     coeffs, scale = nm._window_and_scale(window, nfft, fs, scaling)
-    layout = dev.Layout(tuple(data.shape[:-1]) + (max(b - a, 0),), -1)
+    layout = dev.Layout(full_shape[:-1] + (max(b - a, 0),), -1)
     spec = dev.SpecStream(nfft, nfft, stride, coeffs, scale, detrend,
                           _lib.SPEC_PSD_MEAN, layout.nch)
     try:
         if b > a:
-            for arr in producer(data[..., a:b], int(fs) * 64, axis=-1):
+            block = data(a, b) if callable(data) else data[..., a:b]
+            cs = int(chunksize) if chunksize else int(fs) * 64
+            for arr in producer(block, cs, axis=-1):
                 x2d, _ = layout.to2d(arr)
                 spec.push(x2d)
         total, cnt = spec.export_sum()
     finally:
         spec.close()
     mean, cnt = reduce_segment_sums(total, cnt, group=group)
-    return cnt, freqs, mean.reshape(tuple(data.shape[:-1]) + (len(freqs),))
+    return cnt, freqs, mean.reshape(full_shape[:-1] + (len(freqs),))

@@ -37,7 +37,8 @@ def psd(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
             x2d, host = layout.to2d(arr)
             if x2d.shape[1]:
                 spec.push(x2d)
-        cnt, mean = spec.mean()
+        # device input: the average is taken on the device and stays there
+        cnt, mean = spec.mean() if host else spec.mean_device()
     finally:
         spec.close()
     if cnt == 0:
@@ -45,11 +46,9 @@ def psd(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
         raise UnboundLocalError(
             "no complete segment: data is shorter than nfft = int(fs/resolution)")
     result = mean.reshape(layout.other + (mean.shape[-1],))
-    result = np.moveaxis(result, -1, axis_n)
-    if not host:
-        import torch
-        result = torch.from_numpy(np.ascontiguousarray(result)).cuda()
-    return cnt, freqs, result
+    if host:
+        return cnt, freqs, np.moveaxis(result, -1, axis_n)
+    return cnt, freqs, result.movedim(-1, axis_n).contiguous()
 
 
 def stft(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,

@@ -84,6 +84,96 @@ def test_welch_reduce_gloo_world2():
         assert np.array_equal(full[:, 0], np.arange(5.0))
 
 
+def _run_bench(*flags):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags],
+                         capture_output=True, text=True, timeout=240, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout          # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_launcher_world2_dry():
+    """`python bench.py --gpus 2` starts two ranks itself (no torchrun): the
+    launcher, the barriers and the max-over-ranks timing on CPU (gloo), no
+    kernels; then the cfg-4 time split + segment-average all-reduce logic."""
+    out = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry")
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 2
+    assert out["scaling"] == "weak" and out["dry"] is True
+    out = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry",
+                     "--workload", "welch")
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
+    assert out["welch_check"]["segments"] == 83 and out["welch_check"]["max_rel_err"] < 1e-13
+
+
+def test_bench_under_torchrun_world2_dry():
+    """The driver's launch line: torch.distributed.run starts the ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+         os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry"],
+        capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0])["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+def test_psd_time_split_callable_source_and_abi_reduce(golden):
+    """A rank that synthesises only its own time block (callable source), and
+    the C-ABI collective on a one-rank RCCL communicator: osz_rccl_* +
+    osz_welch_reduce leave sum and count unchanged and the mean equals psd()."""
+    from openseize_amd import _device as dev, _lib
+    from openseize_amd.spectra.estimators import psd
+    C, n = 8, 300_000
+
+    def block(a, b):
+        return dev.synth_normal(C, b - a, seed=3, n0=a)
+
+    whole = block(0, n)
+    c1, f1, p1 = psd(whole, fs=4096, axis=-1, resolution=1.0)
+    acc = None
+    total = 0
+    for r in range(3):                                  # three "ranks", one after the other
+        a, b = sharding.time_block(n, 4096, 2048, r, 3)
+        c, _, p = psd(block(a, b), fs=4096, axis=-1, resolution=1.0)
+        acc = c * p if acc is None else acc + c * p
+        total += c
+    assert total == c1
+    assert float((acc / total - p1).abs().max()) < 1e-9 * float(p1.abs().max())
+    cnt, f, p = sharding.psd_time_split(block, 4096, 0, 1, resolution=1.0, nsamples=n,
+                                        shape=(C, n), chunksize=70_000)
+    assert cnt == c1 and np.array_equal(f, f1)
+    assert float((p - p1).abs().max()) < 1e-12 * float(p1.abs().max())
+    # C-ABI collective, one rank
+    import scipy.signal as sps
+    w = sps.get_window("hann", 4096)
+    scale = float(np.sqrt(1 / (4096.0 * np.sum(w ** 2))))
+    spec = dev.SpecStream(4096, 4096, 2048, w, scale, "constant", _lib.SPEC_PSD_MEAN, C)
+    spec.push(whole)
+    before, cb = spec.export_sum()
+    comm = dev.RcclComm(1, 0, dev.RcclComm.unique_id())
+    assert comm.size() == 1
+    spec.welch_reduce(comm)
+    after, ca = spec.export_sum()
+    assert ca == cb == c1 and torch.equal(before, after)
+    cm, mean = spec.mean_device()
+    assert cm == c1 and float((mean - p1).abs().max()) < 1e-12 * float(p1.abs().max())
+    comm.close()
+    spec.close()
+
+
 @pytest.mark.gpu
 def test_psd_time_split_single_gpu(golden):
     """world_size 1 on the GPU: the time-split driver equals psd(); two time
