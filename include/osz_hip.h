@@ -281,6 +281,56 @@ int osz_welch_reduce(osz_spec_t h, void *comm, void *stream);
 int osz_take(const double *x, int64_t ldx, int nch, const int64_t *idx,
              int64_t nidx, double *y, int64_t ldy, void *stream);
 
+/* ---- producer-level arithmetic on device chunks -- */
+/*
+ * Streaming per-channel moments: replaces the chunk loops of protools.mean /
+ * protools.std (core/protools.py:500-545, :547-592).  push folds one chunk
+ * x (nch, n): per channel the sum, the sum of squares and the count of its
+ * samples (NaNs skipped when ignore_nan, numpy.nanmean; deterministic order),
+ * then A += n * sum/count, B += n * sumsq/count, L += n -- the reference
+ * weights every chunk's (nan)mean by the chunk length.  finish writes
+ * mean = A/L and std = sqrt(B/L - mean^2) (:592) to device arrays (nch);
+ * either may be NULL.
+ */
+typedef struct osz_moments_s *osz_moments_t;
+int osz_moments_create(osz_moments_t *h, int nch);
+int osz_moments_destroy(osz_moments_t h);
+int osz_moments_reset(osz_moments_t h, void *stream);
+int osz_moments_push(osz_moments_t h, const double *x, int64_t ldx, int64_t n,
+                     int ignore_nan, void *stream);
+int osz_moments_finish(osz_moments_t h, double *dmean, double *dstd, void *stream);
+
+/* Mean / standard deviation along the FIRST axis of a (nred, ncols) matrix
+ * (numpy.(nan)mean, numpy.(nan)std per column): what protools.mean / std do
+ * chunk by chunk when the reduced axis is not the production axis
+ * (core/protools.py:538-545, :586-592).  Device outputs (ncols); either NULL. */
+int osz_col_moments(const double *x, int64_t ldx, int nred, int64_t ncols, int ignore_nan,
+                    double *dmean, double *dstd, void *stream);
+
+/* Elementwise y = x (op) operand with NumPy-style broadcasting reduced to the
+ * (channels, samples) layout: protools.add / multiply / multiply_along_axis
+ * (core/protools.py:72-180, :334-384), standardize's (x - mean) / std
+ * (:660-671) and power_norm's division (spectra/metrics.py:141).  a (and b
+ * for STANDARDIZE) are DEVICE arrays: one value, one per channel (row), one
+ * per sample (column), or a full (nch, n) matrix with pitch ldab. */
+enum { OSZ_EW_ADD = 0, OSZ_EW_MUL = 1, OSZ_EW_DIV = 2, OSZ_EW_STANDARDIZE = 3 };
+enum { OSZ_BCAST_SCALAR = 0, OSZ_BCAST_ROW = 1, OSZ_BCAST_COL = 2, OSZ_BCAST_FULL = 3 };
+int osz_ew(int op, const double *x, int64_t ldx, int nch, int64_t n, const double *a,
+           const double *b, int kind, int64_t ldab, double *y, int64_t ldy, void *stream);
+
+/* z = re + i im (interleaved c128, pitch in complex elements): the analytic
+ * signal x + i H(x) of experimental/coupling/transforms.py:186-192. */
+int osz_complex_join(const double *re, int64_t ldre, const double *im, int64_t ldim,
+                     int nch, int64_t n, double *z, int64_t ldz, void *stream);
+/* mag = |z| (numpy.abs), phase = numpy.angle(z) mapped to [0, 2 pi)
+ * (transforms.py:75-107); either output may be NULL. */
+int osz_magphase(const double *z, int64_t ldz, int nch, int64_t n, double *mag,
+                 double *phase, int64_t ldo, void *stream);
+/* out[c] = scipy.integrate.simpson(p[c, a : a + m], dx = dx): the band power
+ * of spectra/metrics.py:80-87 on the (nch, nfreq) device estimate. */
+int osz_simpson(const double *p, int64_t ldp, int nch, int64_t a, int64_t m, double dx,
+                double *out, void *stream);
+
 /* ---- EDF record decode ----------------------------- */
 /*
  * Replaces the host-side unpacking of edf.Reader (reference

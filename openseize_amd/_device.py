@@ -66,48 +66,6 @@ def squeeze(a, axis=None):
     return np.squeeze(a, axis)
 
 
-def mean(a, axis, keepdims=False, ignore_nan=True):
-    if is_tensor(a):
-        fn = torch.nanmean if ignore_nan else torch.mean
-        return fn(a, dim=axis, keepdim=keepdims)
-    return (np.nanmean if ignore_nan else np.mean)(a, axis=axis, keepdims=keepdims)
-
-
-def std(a, axis, keepdims=False, ignore_nan=True):
-    if is_tensor(a):
-        mu = mean(a, axis, True, ignore_nan)
-        out = torch.sqrt(mean((a - mu) ** 2, axis, True, ignore_nan))
-        return out if keepdims else out.squeeze(axis)
-    return (np.nanstd if ignore_nan else np.std)(a, axis=axis, keepdims=keepdims)
-
-
-def sqrt(a):
-    return torch.sqrt(a) if is_tensor(a) else np.sqrt(a)
-
-
-def to_complex(re, im):
-    """re + 1j * im as a complex128 array of the operands' kind."""
-    if is_tensor(re) or is_tensor(im):
-        re = re if is_tensor(re) else torch.from_numpy(np.ascontiguousarray(re)).to(im.device)
-        im = im if is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im)).to(re.device)
-        return torch.complex(re.to(torch.float64), im.to(torch.float64))
-    return np.asarray(re, dtype=np.float64) + 1j * np.asarray(im, dtype=np.float64)
-
-
-def absolute(a):
-    return torch.abs(a) if is_tensor(a) else np.abs(a)
-
-
-def angle_0_2pi(a):
-    """Phase of complex values mapped to [0, 2 pi)."""
-    if is_tensor(a):
-        phi = torch.angle(a)
-        return torch.where(phi < 0, phi + 2 * np.pi, phi)
-    phi = np.angle(a)
-    phi[phi < 0] += 2 * np.pi
-    return phi
-
-
 def require_gpu():
     lib = _lib.load()          # raises OszLibraryError when the .so is missing
     if torch is None or not torch.cuda.is_available():
@@ -452,6 +410,86 @@ class RcclComm:
         if self.comm:
             _lib.check(self.lib.osz_rccl_comm_destroy(self.comm))
             self.comm = ctypes.c_void_p()
+
+
+class MomentsStream(_Handle):
+    """Streaming per-channel mean / std over the chunks of a producer
+    (C ABI: osz_moments_*)."""
+    _destroy = "osz_moments_destroy"
+
+    def __init__(self, nch):
+        super().__init__()
+        self.nch = nch
+        _lib.check(self.lib.osz_moments_create(ctypes.byref(self.h), nch))
+
+    def push(self, x2d, ignore_nan=True):
+        _lib.check(self.lib.osz_moments_push(self.h, ptr(x2d), x2d.stride(0), x2d.shape[1],
+                                             int(bool(ignore_nan)), stream_ptr()))
+
+    def finish(self, device="cuda"):
+        """(mean, std) as CUDA tensors (nch,)."""
+        mean = torch.empty(self.nch, dtype=torch.float64, device=device)
+        sd = torch.empty_like(mean)
+        _lib.check(self.lib.osz_moments_finish(self.h, ptr(mean), ptr(sd), stream_ptr()))
+        return mean, sd
+
+
+def col_moments(x2d, ignore_nan=True):
+    """(mean, std) along the first axis of a (nred, ncols) CUDA tensor."""
+    lib = require_gpu()
+    mean = torch.empty(x2d.shape[1], dtype=torch.float64, device=x2d.device)
+    sd = torch.empty_like(mean)
+    _lib.check(lib.osz_col_moments(ptr(x2d), x2d.stride(0), x2d.shape[0], x2d.shape[1],
+                                   int(bool(ignore_nan)), ptr(mean), ptr(sd), stream_ptr()))
+    return mean, sd
+
+
+def ew(op, x2d, a, b=None, kind=_lib.BCAST_SCALAR):
+    """osz_ew: y = x (op) a [, b] with operands indexed per `kind`.  a / b are
+    float64 CUDA tensors (one value, (nch,), (n,) or (nch, n))."""
+    lib = require_gpu()
+    y = torch.empty((x2d.shape[0], x2d.shape[1]), dtype=torch.float64, device=x2d.device)
+    ldab = a.stride(0) if kind == _lib.BCAST_FULL else 0
+    if kind == _lib.BCAST_FULL and b is not None and b.stride(0) != ldab:
+        b = b.contiguous()
+        a = a.contiguous()
+        ldab = a.stride(0)
+    _lib.check(lib.osz_ew(op, ptr(x2d), x2d.stride(0), x2d.shape[0], x2d.shape[1], ptr(a),
+                          ptr(b) if b is not None else None, kind, ldab, ptr(y),
+                          max(y.stride(0), 1), stream_ptr()))
+    return y
+
+
+def complex_join(re2d, im2d):
+    """re + 1j * im as a complex128 CUDA tensor (osz_complex_join)."""
+    lib = require_gpu()
+    z = torch.empty(tuple(re2d.shape), dtype=torch.complex128, device=re2d.device)
+    _lib.check(lib.osz_complex_join(ptr(re2d), re2d.stride(0), ptr(im2d), im2d.stride(0),
+                                    re2d.shape[0], re2d.shape[1], ptr(z), max(z.stride(0), 1),
+                                    stream_ptr()))
+    return z
+
+
+def magphase(z2d, want_mag=True, want_phase=True):
+    """(|z|, angle(z) in [0, 2 pi)) of a complex128 CUDA tensor (nch, n)
+    (osz_magphase); an output that is not wanted is None."""
+    lib = require_gpu()
+    shape = tuple(z2d.shape)
+    mag = torch.empty(shape, dtype=torch.float64, device=z2d.device) if want_mag else None
+    ph = torch.empty(shape, dtype=torch.float64, device=z2d.device) if want_phase else None
+    _lib.check(lib.osz_magphase(ptr(z2d), z2d.stride(0), shape[0], shape[1],
+                                ptr(mag) if want_mag else None, ptr(ph) if want_phase else None,
+                                max(shape[1], 1), stream_ptr()))
+    return mag, ph
+
+
+def simpson(p2d, a, m, dx):
+    """scipy.integrate.simpson(p[:, a:a+m], dx=dx) per row on the device."""
+    lib = require_gpu()
+    out = torch.empty(p2d.shape[0], dtype=torch.float64, device=p2d.device)
+    _lib.check(lib.osz_simpson(ptr(p2d), p2d.stride(0), p2d.shape[0], int(a), int(m), float(dx),
+                               ptr(out), stream_ptr()))
+    return out
 
 
 def take(x2d, idx):

@@ -21,6 +21,8 @@ OSZ_ERR_STATE = -4
 OSZ_ERR_UNSUPPORTED = -5
 
 SPEC_PSD_MEAN, SPEC_PSD_SEGMENTS, SPEC_DFT_SEGMENTS = 0, 1, 2
+EW_ADD, EW_MUL, EW_DIV, EW_STANDARDIZE = 0, 1, 2, 3
+BCAST_SCALAR, BCAST_ROW, BCAST_COL, BCAST_FULL = 0, 1, 2, 3
 DETREND = {"constant": 0, "linear": 1}
 
 
@@ -117,6 +119,20 @@ SIGNATURES = {
     "osz_rccl_comm_destroy": (ctypes.c_int, [c_vp]),
     "osz_rccl_comm_size": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int)]),
     "osz_welch_reduce": (ctypes.c_int, [c_vp, c_vp, c_vp]),
+    "osz_moments_create": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int]),
+    "osz_moments_destroy": (ctypes.c_int, [c_vp]),
+    "osz_moments_reset": (ctypes.c_int, [c_vp, c_vp]),
+    "osz_moments_push": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_int, c_vp]),
+    "osz_moments_finish": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "osz_col_moments": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_vp,
+                                       c_vp]),
+    "osz_ew": (ctypes.c_int, [ctypes.c_int, c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp,
+                              ctypes.c_int, c_i64, c_vp, c_i64, c_vp]),
+    "osz_complex_join": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, ctypes.c_int, c_i64, c_vp,
+                                        c_i64, c_vp]),
+    "osz_magphase": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "osz_simpson": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_i64, ctypes.c_double,
+                                   c_vp, c_vp]),
     "osz_take": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp,
                                 c_i64, c_vp]),
     "osz_edf_decode": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp,

@@ -291,27 +291,66 @@ def _ba_to_sos(coeffs):
     return sps.tf2sos(b, a), order
 
 
-def lfilter(pro, coeffs, axis, zi=None):
-    """Transfer-function (b, a) forward filter with carried state
-    (core/numerical.py:414-446), run on the device as a biquad cascade (see
-    ``_ba_to_sos``).  ``zi`` has ``max(len(a), len(b)) - 1`` entries along axis
-    (:437-440); it is supported for orders <= 2, where the cascade state IS
-    the direct-form state."""
-    sos, order = _ba_to_sos(coeffs)
-    if zi is None:
-        yield from sosfilt(pro, sos, axis, zi=None)
-        return
-    if order > 2:
-        raise NotImplementedError(
-            "lfilter with user zi is implemented for filter orders <= 2; "
-            "use fmt='sos' for higher orders")
+def _cascade_state_map(sos):
+    """Matrix M (2S x 2S) with  M @ s = n  where s = (z_00, z_01, z_10, ...)
+    are the DF2T states of the sections of a cascade and n the coefficients
+    (powers of q = z^-1, constant first) of the numerator of its ZERO-INPUT
+    response  Y(q) = N(q) / A(q),  A = prod A_j.
+
+    A section in state (z0, z1) emits (z0 + z1 q) / A_s(q) on its own; the
+    sections after it filter that and the ones before it contribute their
+    denominators to the common A, so section s adds
+    (z_s0 + z_s1 q) * prod_{j > s} B_j(q) * prod_{j < s} A_j(q)  to N.
+    A direct-form II transposed filter (b, a) in state z has N(q) = sum z_i q^i,
+    so equating the two numerators maps one state onto the other."""
+    nsec = sos.shape[0]
+    cols = []
+    for s in range(nsec):
+        poly = np.ones(1)
+        for j in range(nsec):
+            if j < s:
+                poly = np.convolve(poly, sos[j, 3:] / sos[j, 3])
+            elif j > s:
+                poly = np.convolve(poly, sos[j, :3] / sos[j, 3])
+        base = np.zeros(2 * nsec)
+        base[:len(poly)] = poly
+        cols += [base, np.roll(base, 1)]          # z_s0 * P_s(q), z_s1 * q P_s(q)
+    return np.stack(cols, axis=1)
+
+
+def _ba_zi_to_sos_zi(zi, order, sos, axis):
+    """User ``zi`` of a (b, a) filter (``order`` entries along axis, the state
+    scipy.signal.lfilter takes) -> the equivalent ``zi`` of its biquad cascade,
+    shaped (nsections, ..., 2 along axis, ...) for ``sosfilt``."""
     zi = np.asarray(zi, dtype=np.float64)
     ax = normalize_axis(axis, zi.ndim)
     if zi.shape[ax] != order:
         raise ValueError(f"zi must have {order} entries along axis {axis}")
-    pad = [(0, 0)] * zi.ndim
-    pad[ax] = (0, 2 - order)
-    yield from sosfilt(pro, sos, axis, zi=np.pad(zi, pad)[None, ...])
+    nsec = sos.shape[0]
+    z = np.moveaxis(zi, ax, -1)
+    rhs = np.zeros(z.shape[:-1] + (2 * nsec,))
+    rhs[..., :order] = z
+    M = _cascade_state_map(sos)
+    try:
+        states = np.linalg.solve(M, rhs[..., None])[..., 0]
+    except np.linalg.LinAlgError:                 # sections sharing a root: minimum norm
+        states = np.einsum("ij,...j->...i", np.linalg.pinv(M), rhs)
+    states = states.reshape(z.shape[:-1] + (nsec, 2))
+    states = np.moveaxis(states, -2, 0)           # (nsec, ..., 2)
+    return np.moveaxis(states, -1, ax + 1)
+
+
+def lfilter(pro, coeffs, axis, zi=None):
+    """Transfer-function (b, a) forward filter with carried state
+    (core/numerical.py:414-446), run on the device as a biquad cascade (see
+    ``_ba_to_sos``).  ``zi`` has ``max(len(a), len(b)) - 1`` entries along axis
+    (:437-440) and is the direct-form state scipy.signal.lfilter takes; it is
+    mapped onto the cascade's section states (``_ba_zi_to_sos_zi``), so the
+    output continues exactly as the direct form would."""
+    sos, order = _ba_to_sos(coeffs)
+    if zi is not None:
+        zi = _ba_zi_to_sos_zi(zi, order, sos, axis)
+    yield from sosfilt(pro, sos, axis, zi=zi)
 
 
 def filtfilt(pro, coeffs, axis):

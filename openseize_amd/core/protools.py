@@ -4,18 +4,20 @@ Mirror of the reference's ``core/protools.py`` (cited per function), written
 from scratch.  ``pad`` is on the hot path (STFT boundary handling, reference
 core/numerical.py:1044,1051); the others are SURVEY section 8f rank 2 -- they
 keep a chain of producers (filter -> standardize -> psd ...) lazy and, for
-device-resident producers, resident in HBM.  None of them contains DSP
-numerics: every function maps produced chunks with an elementwise operation or
-folds them into per-channel moments, on whatever memory kind the chunks live in
-(ndarray on the host exactly like the reference, CUDA tensor on the device).
+device-resident producers, resident in HBM.  The shape bookkeeping (pad,
+squeeze, expand_dims, slicing) moves no sample; every function that computes
+(add, multiply, multiply_along_axis, mean, std, standardize) runs the kernels
+of ``csrc/glue.hip`` through the C ABI -- ``osz_ew``, ``osz_moments_*``,
+``osz_col_moments`` -- for host chunks (uploaded, result brought back as an
+ndarray) and device chunks alike: there is no NumPy arithmetic path.
 """
 
 from functools import partial
-from itertools import zip_longest
 
 import numpy as np
 
 from openseize_amd import _device as dev
+from openseize_amd import _lib
 from openseize_amd.core import arraytools
 from openseize_amd.core.producer import Producer, producer
 
@@ -84,40 +86,77 @@ def _map_gen(pro, func):
         yield func(arr)
 
 
-def _binary(pro, other, op, verb):
-    """pro (op) other for a numeric, an array broadcastable to every produced
-    chunk, or a producer of the same shape (core/protools.py:72-180)."""
+# -- elementwise arithmetic: one HIP kernel (osz_ew) whatever the operand is --
+def _as_device(value, device):
+    """float64 CUDA tensor of a number / ndarray / tensor (plumbing only)."""
+    import torch
+    if dev.is_tensor(value):
+        return value.to(device=device, dtype=torch.float64)
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(value, dtype=np.float64))).to(device)
+
+
+def _operand(value, layout, chunk_shape, device):
+    """Classifies an operand that broadcasts against a chunk and lays it out
+    for the (rows, samples) kernel: one value, one per row (constant along the
+    production axis), one per sample (constant across the other axes) or a
+    full matrix.  Returns (tensor, kind)."""
+    t = _as_device(value, device)
+    ndim = len(chunk_shape)
+    t = t.reshape((1,) * (ndim - t.ndim) + tuple(t.shape))
+    if t.numel() == 1:
+        return t.reshape(1), _lib.BCAST_SCALAR
+    if t.shape[layout.axis] == 1:
+        across = list(chunk_shape)
+        across[layout.axis] = 1
+        return t.broadcast_to(across).movedim(layout.axis, -1).reshape(-1).contiguous(), _lib.BCAST_ROW
+    if all(size == 1 for i, size in enumerate(t.shape) if i != layout.axis):
+        if t.shape[layout.axis] != chunk_shape[layout.axis]:
+            raise ValueError("operands could not be broadcast together with shapes "
+                             f"{tuple(chunk_shape)} {tuple(t.shape)}")
+        return t.reshape(-1).contiguous(), _lib.BCAST_COL
+    full, _ = layout.to2d(t.broadcast_to(tuple(chunk_shape)))
+    return full, _lib.BCAST_FULL
+
+
+def _apply(op, arr, axis, a, b=None):
+    """One chunk through osz_ew; host chunks go up and come back."""
+    layout = dev.Layout(arr.shape, axis)
+    x2d, host = layout.to2d(arr)
+    a2, kind = _operand(a, layout, arr.shape, x2d.device)
+    b2 = None if b is None else _operand(b, layout, arr.shape, x2d.device)[0]
+    return layout.from2d(dev.ew(op, x2d, a2, b2, kind), host)
+
+
+def _arith_gen(pro, other, op, verb):
+    """pro (op) other, chunk by chunk: ``other`` is a number, an array that
+    broadcasts against every produced chunk, or a producer of the same shape
+    (reference core/protools.py:72-180)."""
     if isinstance(other, Producer):
         if tuple(pro.shape) != tuple(other.shape):
             raise ValueError(f"producers can not be {verb} with shapes"
                              f"{pro.shape} {other.shape}")
-        if pro.chunksize != other.chunksize:
-            other.chunksize = pro.chunksize
-        for x, y in zip(pro, other):
-            yield op(x, y)
+        other.chunksize = pro.chunksize          # walk both streams in step
+        for left, right in zip(pro, other):
+            yield _apply(op, left, pro.axis, right)
     else:
         for arr in pro:
-            yield op(arr, _like(other, arr))
+            yield _apply(op, arr, pro.axis, other)
 
 
-def _like(value, ref):
-    """Host constants follow device chunks onto the device."""
-    if dev.is_tensor(ref) and isinstance(value, np.ndarray):
-        import torch
-        return torch.from_numpy(np.ascontiguousarray(value)).to(ref.device)
-    return value
+def _same_shape_producer(pro, genfunc):
+    return producer(genfunc, chunksize=pro.chunksize, axis=pro.axis, shape=pro.shape)
 
 
 def add(pro, other):
-    """core/protools.py:72-125."""
-    func = partial(_binary, pro, other, lambda x, y: x + y, "added together")
-    return producer(func, chunksize=pro.chunksize, axis=pro.axis, shape=pro.shape)
+    """Adds a number, array or producer to every produced array
+    (core/protools.py:72-125) with the device kernel ``osz_ew``."""
+    return _same_shape_producer(pro, partial(_arith_gen, pro, other, _lib.EW_ADD, "added together"))
 
 
 def multiply(pro, other):
-    """core/protools.py:127-180."""
-    func = partial(_binary, pro, other, lambda x, y: x * y, "multiplied")
-    return producer(func, chunksize=pro.chunksize, axis=pro.axis, shape=pro.shape)
+    """Multiplies every produced array by a number, array or producer
+    (core/protools.py:127-180) with the device kernel ``osz_ew``."""
+    return _same_shape_producer(pro, partial(_arith_gen, pro, other, _lib.EW_MUL, "multiplied"))
 
 
 def expand_dims(pro, axis=0):
@@ -135,29 +174,33 @@ def expand_dims(pro, axis=0):
 
 
 def multiply_along_axis(pro, arr, axis):
-    """Produced arrays times a 1-D array along one axis, the production axis
-    included (core/protools.py:334-384)."""
+    """Produced arrays times a 1-D array laid along one axis, the production
+    axis included (core/protools.py:334-384).  Along the production axis the
+    multiplier is walked in step with the data (one value per sample, kernel
+    operand kind COL); along any other axis it is constant over a chunk."""
     arr = np.array(arr)
     if arr.ndim > 1:
         raise ValueError("Dimensions of multiplier arr must be exactly 1.")
     if len(arr) != pro.shape[axis]:
         msg = "operands could not be broadcast together with shapes {} {}"
         raise ValueError(msg.format(pro.shape, arr.shape))
-    shape = np.ones(len(pro.shape), dtype=int)
-    shape[axis] = len(arr)
-    x = arr.reshape(shape)
-    if arraytools.normalize_axis(axis, pro.ndim) == pro.axis:
-        x = producer(x, chunksize=pro.chunksize, axis=pro.axis)
-    func = partial(_multiply_gen, pro, x)
-    return producer(func, chunksize=pro.chunksize, axis=pro.axis, shape=pro.shape)
+    along = arraytools.normalize_axis(axis, pro.ndim)
+    return _same_shape_producer(pro, partial(_scale_gen, pro, arr.astype(np.float64), along))
 
 
-def _multiply_gen(pro, multiplier):
-    factors = zip_longest(pro, multiplier, fillvalue=multiplier)
-    if isinstance(multiplier, Producer):
-        factors = zip(pro, multiplier)
-    for arr, mult in factors:
-        yield arr * _like(mult, arr)
+def _scale_gen(pro, factors, along):
+    laid = [1] * pro.ndim
+    if along != pro.axis:
+        laid[along] = len(factors)
+        for arr in pro:
+            yield _apply(_lib.EW_MUL, arr, pro.axis, factors.reshape(laid))
+        return
+    seen = 0
+    for arr in pro:
+        m = arr.shape[pro.axis]
+        laid[along] = m
+        yield _apply(_lib.EW_MUL, arr, pro.axis, factors[seen:seen + m].reshape(laid))
+        seen += m
 
 
 def slice_along_axis(pro, start=None, stop=None, step=None, axis=-1):
@@ -175,52 +218,108 @@ def slice_along_axis(pro, start=None, stop=None, step=None, axis=-1):
     return producer(func, pro.chunksize, pro.axis, shape=new_shape)
 
 
-def mean(pro, axis=-1, ignore_nan=True, keepdims=False):
-    """Mean along axis; along the production axis the chunk means are combined
-    weighted by chunk length (core/protools.py:500-545)."""
-    ax = arraytools.normalize_axis(axis, pro.ndim)
-    if pro.axis == ax:
-        sums, cnts = 0, 0
+# -- moments: streaming kernel along the production axis, per-chunk column
+# -- kernel along any other axis
+def _restore(vec, dims, at, keepdims, host):
+    """(prod(dims),) device vector -> array shaped ``dims`` (with a singleton
+    at ``at`` when keepdims) of the kind the chunks had."""
+    out = vec.reshape(tuple(dims))
+    if keepdims:
+        out = out.unsqueeze(at)
+    if not host:
+        return out
+    out = out.cpu().numpy()
+    return out[()] if out.ndim == 0 else out
+
+
+def _stream_moments(pro, ax, ignore_nan):
+    """One pass over the producer with the streaming moments kernel
+    (osz_moments_*): per-channel mean and std along the production axis."""
+    layout = dev.Layout(pro.shape, ax)
+    acc = dev.MomentsStream(layout.nch)
+    host = True
+    try:
         for arr in pro:
-            cnts += arr.shape[axis]
-            sums = sums + arr.shape[axis] * dev.mean(arr, axis, keepdims, ignore_nan)
-        return sums / cnts
-    avgs = [dev.mean(x, ax, True, ignore_nan) for x in pro]
-    result = dev.concatenate(avgs, pro.axis)
-    return result if keepdims else dev.squeeze(result, ax)
+            x2d, host = layout.to2d(arr)
+            acc.push(x2d, ignore_nan)
+        return layout, acc.finish(), host
+    finally:
+        acc.close()
+
+
+def _chunk_moments(arr, ax, ignore_nan):
+    """Mean and std of ONE chunk along a non-production axis (osz_col_moments):
+    returns ((mean, std) with a singleton at ax, came_from_host)."""
+    import torch
+    host = not dev.is_tensor(arr) or not arr.is_cuda
+    t = _as_device(arr, "cuda")
+    moved = t.movedim(ax, 0)
+    rest = tuple(moved.shape[1:])
+    mu, sd = dev.col_moments(moved.reshape(moved.shape[0], -1).contiguous(), ignore_nan)
+    return tuple(v.reshape(rest).unsqueeze(ax) for v in (mu, sd)), host
+
+
+def _per_chunk_stat(pro, ax, ignore_nan, keepdims, which):
+    pieces, host = [], True
+    for arr in pro:
+        stats, host = _chunk_moments(arr, ax, ignore_nan)
+        pieces.append(stats[which])
+    result = dev.concatenate(pieces, pro.axis)
+    if not keepdims:
+        result = result.squeeze(ax)
+    return result.cpu().numpy() if host else result
+
+
+def mean(pro, axis=-1, ignore_nan=True, keepdims=False):
+    """Mean along axis (core/protools.py:500-545).  Along the production axis
+    every chunk's (nan)mean is weighted by the chunk length, exactly as the
+    reference combines them; the chunks are folded by the streaming moments
+    kernel in one pass.  Along another axis every chunk is reduced on its own
+    and the results are concatenated."""
+    ax = arraytools.normalize_axis(axis, pro.ndim)
+    if ax != pro.axis:
+        return _per_chunk_stat(pro, ax, ignore_nan, keepdims, 0)
+    layout, (mu, _), host = _stream_moments(pro, ax, ignore_nan)
+    return _restore(mu, layout.other, ax, keepdims, host)
 
 
 def std(pro, axis=-1, ignore_nan=True, keepdims=False):
-    """Standard deviation along axis, sqrt(E[x^2] - E[x]^2) over the chunks
-    along the production axis (core/protools.py:547-592)."""
+    """Standard deviation along axis (core/protools.py:547-592): along the
+    production axis sqrt(E[x^2] - E[x]^2) with both expectations combined over
+    the chunks like ``mean`` (one pass instead of the reference's two); along
+    another axis the two-pass (nan)std of every chunk."""
     ax = arraytools.normalize_axis(axis, pro.ndim)
-    if ax == pro.axis:
-        expected_squared = mean(pro, ax, ignore_nan, keepdims=keepdims) ** 2
-        sum_squares, cnts = 0, 0
-        for arr in pro:
-            cnts += arr.shape[axis]
-            sum_squares = sum_squares + arr.shape[axis] * dev.mean(
-                arr ** 2, axis, keepdims, ignore_nan)
-        return dev.sqrt(sum_squares / cnts - expected_squared)
-    stds = [dev.std(x, ax, True, ignore_nan) for x in pro]
-    result = dev.concatenate(stds, pro.axis)
-    return result if keepdims else dev.squeeze(result, ax)
+    if ax != pro.axis:
+        return _per_chunk_stat(pro, ax, ignore_nan, keepdims, 1)
+    layout, (_, sd), host = _stream_moments(pro, ax, ignore_nan)
+    return _restore(sd, layout.other, ax, keepdims, host)
 
 
 def standardize(pro, axis=-1, ignore_nan=True):
-    """(x - mean) / std along axis as a producer (core/protools.py:594-671)."""
-    means = mean(pro, axis, ignore_nan, keepdims=True)
-    stds = std(pro, axis, ignore_nan, keepdims=True)
-    func = partial(_standardize_gen, pro, means, stds, axis)
-    return producer(func, pro.chunksize, pro.axis, shape=pro.shape)
+    """(x - mean) / std along axis as a producer (core/protools.py:594-671).
+    Along the production axis the moments are taken first (one pass, on the
+    device) and every chunk is then normalised by ``osz_ew``; along another
+    axis each chunk is normalised by its own column moments."""
+    ax = arraytools.normalize_axis(axis, pro.ndim)
+    if ax != pro.axis:
+        return _same_shape_producer(pro, partial(_standardize_chunks, pro, ax, ignore_nan))
+    layout, (mu, sd), _ = _stream_moments(pro, ax, ignore_nan)
+    # plain host arrays keep the returned producer picklable
+    mu, sd = mu.cpu().numpy(), sd.cpu().numpy()
+    return _same_shape_producer(pro, partial(_standardize_rows, pro, mu, sd))
 
 
-def _standardize_gen(pro, means, stds, axis):
-    if arraytools.normalize_axis(axis, pro.ndim) == pro.axis:
-        for arr in pro:
-            yield (arr - means) / stds
-    else:
-        mean_pro = producer(means, chunksize=pro.chunksize, axis=pro.axis)
-        std_pro = producer(stds, chunksize=pro.chunksize, axis=pro.axis)
-        for arr, mu, sd in zip(pro, mean_pro, std_pro):
-            yield (arr - mu) / sd
+def _standardize_rows(pro, mu, sd):
+    import torch
+    for arr in pro:
+        layout = dev.Layout(arr.shape, pro.axis)
+        x2d, host = layout.to2d(arr)
+        a, b = (torch.from_numpy(v).to(x2d.device) for v in (mu, sd))
+        yield layout.from2d(dev.ew(_lib.EW_STANDARDIZE, x2d, a, b, _lib.BCAST_ROW), host)
+
+
+def _standardize_chunks(pro, ax, ignore_nan):
+    for arr in pro:
+        (mu, sd), host = _chunk_moments(arr, ax, ignore_nan)
+        out = _apply(_lib.EW_STANDARDIZE, _as_device(arr, "cuda"), pro.axis, mu, sd)
+        yield out.cpu().numpy() if host else out

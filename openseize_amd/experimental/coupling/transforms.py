@@ -2,8 +2,8 @@
 section 8f rank 4): consumers of the FIR path.  Same interface as the
 reference's ``experimental/coupling/transforms.py`` (Transform :18-107,
 Analytic :110-192).  The Hilbert FIR runs through the overlap-add kernel; the
-elementwise parts (x + i h(x), |z|, angle) map over produced chunks on whatever
-memory kind they live in.
+elementwise parts are the device kernels ``osz_complex_join`` (x + i h(x)) and
+``osz_magphase`` (|z|, angle) of ``csrc/glue.hip``.
 """
 
 import abc
@@ -29,17 +29,24 @@ class Transform(abc.ABC):
     def estimate(self, data, **kwargs):
         """Returns a producer of complex values."""
 
-    def _envelope(self):
+    def _polar(self, which):
+        """|z| (which = 0) or the phase in [0, 2 pi) (which = 1) of every complex
+        chunk of ``signal`` with the device kernel ``osz_magphase``."""
         for arr in self.signal:
-            yield dev.absolute(arr)
+            layout = dev.Layout(arr.shape, self.axis)
+            z2d, host = _complex_rows(arr, layout)
+            part = dev.magphase(z2d, want_mag=which == 0, want_phase=which == 1)[which]
+            yield layout.from2d(part, host)
+
+    def _envelope(self):
+        yield from self._polar(0)
 
     @property
     def amplitudes(self):
         return producer(self._envelope, self.chunksize, self.axis, shape=self.signal.shape)
 
     def _phase(self):
-        for arr in self.signal:
-            yield dev.angle_0_2pi(arr)
+        yield from self._polar(1)
 
     @property
     def phases(self):
@@ -62,7 +69,22 @@ class Analytic(Transform):
                         self.axis, shape=source.shape)
 
 
+def _complex_rows(arr, layout):
+    """Complex chunk -> ((rows, n) complex128 CUDA tensor, came_from_host)."""
+    import numpy as np
+    import torch
+    host = not dev.is_tensor(arr)
+    t = torch.from_numpy(np.ascontiguousarray(arr)).cuda() if host else arr
+    host = host or not arr.is_cuda
+    t = t.cuda().to(torch.complex128).movedim(layout.axis, -1)
+    return t.reshape(layout.nch, t.shape[-1]).contiguous(), host
+
+
 def _join_complex(real_pro, imag_pro):
-    """Generator of re + 1j * im over two equally chunked producers."""
+    """Generator of re + 1j * im over two equally chunked producers, joined on
+    the device (``osz_complex_join``)."""
     for re, im in zip(real_pro, imag_pro):
-        yield dev.to_complex(re, im)
+        layout = dev.Layout(re.shape, real_pro.axis)
+        re2d, host = layout.to2d(re)
+        im2d, _ = layout.to2d(im)
+        yield layout.from2d(dev.complex_join(re2d, im2d), host)

@@ -1,0 +1,125 @@
+"""The C-ABI boundary on the GPU without PyTorch in the loop, and the
+checkpoint / resume entry points.
+
+* ``tests/host/abi_driver.c`` is compiled with gcc against include/osz_hip.h and
+  run as its own process: osz_malloc -> osz_memcpy_h2d -> osz_sos_forward /
+  osz_fir_push -> osz_memcpy_d2h against the reference's golden vector G3 and
+  numpy.convolve with G2's taps
+  (exactly the DeviceChunk stub of INTEGRATION.md, in C).
+* get_state / set_state of every iterator handle: a stream cut at a chunk
+  boundary and resumed on a fresh handle continues bit-identically.
+"""
+
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_host_drives_the_abi(golden, tmp_path):
+    g3, g2 = golden("g3_sosfilt.npz"), golden("g2_fir.npz")
+    x = np.ascontiguousarray(g3["x"], dtype=np.float64)            # (3, N)
+    nch, n = x.shape
+    sos = np.ascontiguousarray(g3["sos_butter_bp6"], dtype=np.float64)
+    want_sos = np.ascontiguousarray(g3["y_butter_bp6_cs1000"])
+    taps = np.ascontiguousarray(g2["h256"], dtype=np.float64)      # the taps of G2, on G3's signal
+    want_fir = np.stack([np.convolve(row, taps)[:n] for row in x])
+    case = tmp_path / "case.bin"
+    with open(case, "wb") as fh:
+        np.array([nch, n, sos.shape[0], len(taps), 1000], dtype=np.int64).tofile(fh)
+        for a in (sos, taps, x, want_sos, want_fir):
+            a.tofile(fh)
+    exe = tmp_path / "abi_driver"
+    lib_dir = os.path.join(ROOT, "openseize_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-O2", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "host", "abi_driver.c"), "-o", str(exe),
+                    "-L", lib_dir, "-losz_hip", f"-Wl,-rpath,{lib_dir}", "-lm"], check=True)
+    res = subprocess.run([str(exe), str(case)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "max_rel_err_sos" in res.stdout and "bad_create_rc=-1" in res.stdout
+
+
+def _split_resume(make, push, x, cut):
+    """One handle over the whole stream vs. a handle stopped at `cut`, its state
+    saved, and a NEW handle resumed from it."""
+    import torch
+    a = make()
+    whole = [push(a, x[:, :cut], False), push(a, x[:, cut:], True)]
+    a.close()
+    b = make()
+    first = push(b, x[:, :cut], False)
+    saved = b.get_state()
+    b.close()
+    c = make()
+    c.set_state(saved)
+    second = push(c, x[:, cut:], True)
+    c.close()
+    for u, v in zip(whole, (first, second)):
+        assert u.shape == v.shape and torch.equal(u, v)
+    return saved
+
+
+def test_checkpoint_resume_all_iterators():
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev, _lib
+    C, n, cut = 5, 60_000, 23_457
+    x = dev.synth_normal(C, n, seed=41)
+    # FIR (single part and partitioned)
+    for ntaps in (255, 5000):
+        h = sps.firwin(ntaps, 0.2)
+        st = _split_resume(lambda: dev.FirStream(h, C), lambda s, a, last: s.push(a.contiguous()), x, cut)
+        assert st.size == (C * (ntaps - 1) if ntaps <= 2049 else st.size)
+    # polyphase 3/2
+    hp = sps.firwin(91, 1 / 3)
+    _split_resume(lambda: dev.PolyStream(hp, 3, 2, C),
+                  lambda s, a, last: s.push(a.contiguous(), final=last), x, cut)
+    # spectra: STFT segments and the PSD accumulator
+    w = sps.get_window("hann", 1000)
+    for mode in (_lib.SPEC_DFT_SEGMENTS, _lib.SPEC_PSD_SEGMENTS):
+        _split_resume(lambda: dev.SpecStream(1000, 1000, 400, w, 0.01, "constant", mode, C),
+                      lambda s, a, last: s.push(a.contiguous()), x, cut)
+    w4 = sps.get_window("hann", 4096)
+
+    def run(resume):
+        s = dev.SpecStream(4096, 4096, 2048, w4, 0.01, "linear", _lib.SPEC_PSD_MEAN, C)
+        s.push(x[:, :cut].contiguous())
+        if resume:
+            saved = s.get_state()
+            s.close()
+            s = dev.SpecStream(4096, 4096, 2048, w4, 0.01, "linear", _lib.SPEC_PSD_MEAN, C)
+            s.set_state(saved)
+        s.push(x[:, cut:].contiguous())
+        total, cnt = s.export_sum()
+        s.close()
+        return total, cnt
+
+    (t0, c0), (t1, c1) = run(False), run(True)
+    assert c0 == c1 == (n - 4096) // 2048 + 1 and torch.equal(t0, t1)
+    # a state of the wrong size is refused
+    f = dev.FirStream(sps.firwin(31, 0.3), C)
+    with pytest.raises(ValueError):
+        f.set_state(np.zeros(7))
+    f.close()
+
+
+def test_psd_device_input_stays_on_device():
+    """psd() of a CUDA tensor returns a CUDA tensor averaged on the device
+    (osz_spec_mean_device) and equals the host-input result."""
+    import torch
+    from openseize_amd import _device as dev
+    from openseize_amd.spectra.estimators import psd
+    x = dev.synth_normal(6, 50_000, seed=5)
+    cd, fd, pd = psd(x, fs=1000, axis=-1, resolution=0.5)
+    ch, fh, ph = psd(x.cpu().numpy(), fs=1000, axis=-1, resolution=0.5)
+    assert isinstance(pd, torch.Tensor) and pd.is_cuda and isinstance(ph, np.ndarray)
+    assert cd == ch and np.array_equal(fd, fh)
+    assert np.array_equal(pd.cpu().numpy(), ph)
+    # sample axis first
+    c2, _, p2 = psd(x.T.contiguous(), fs=1000, axis=0, resolution=0.5)
+    assert tuple(p2.shape) == (len(fd), 6) and np.array_equal(p2.cpu().numpy(), ph.T)
