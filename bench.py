@@ -365,6 +365,11 @@ def run_welch(args, R):
         comm = dev.RcclComm(R.world, R.rank, bytes(uid.cpu().numpy().tobytes()))
     for k in range(max(args.warmup, 1)):
         spec.push(ring[k % 3])
+    if comm is not None:
+        spec.welch_reduce(comm)
+        spec.mean_device()
+    else:
+        sharding.reduce_segment_sums(*spec.export_sum())
     _lib.check(lib.osz_spec_reset(spec.h, dev.stream_ptr()))
     R.barrier()
     _lib.check(lib.osz_profile_reset())

@@ -191,9 +191,15 @@ def multiply_along_axis(pro, arr, axis):
 def _scale_gen(pro, factors, along):
     laid = [1] * pro.ndim
     if along != pro.axis:
+        # Reference quirk (Q14, pinned by the golden vectors): the multiplier is
+        # zipped with the producer as an ARRAY (zip_longest(pro, x, fillvalue=x),
+        # core/protools.py:378-384), so produced chunk k < len(arr) is scaled by
+        # the single value arr[k] and only later chunks by arr laid along its
+        # axis.  Replicated: it is what callers of the reference observe.
         laid[along] = len(factors)
-        for arr in pro:
-            yield _apply(_lib.EW_MUL, arr, pro.axis, factors.reshape(laid))
+        for k, arr in enumerate(pro):
+            scale = factors[k] if k < len(factors) else factors.reshape(laid)
+            yield _apply(_lib.EW_MUL, arr, pro.axis, scale)
         return
     seen = 0
     for arr in pro:

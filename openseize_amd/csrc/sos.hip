@@ -436,6 +436,287 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Second body of the same algorithm, trimmed for instruction count: the lean
+// kernels were measured at ~75 % VALU utilisation (profiles/r02_pmc_bench.json:
+// 89 vector instructions per sample against 42 for the bare recurrence + fix-up),
+// so vector instructions, not bytes, bound them.  Differences from sos_body:
+//   * the scan over the 64 lane blocks of a wave is lane-parallel end to end:
+//     after the four row_shr steps inside 16-lane rows, two more DPP steps
+//     (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) extend
+//     the inclusive prefix to the whole wave, and wave_shr:1 makes it
+//     exclusive.  The per-lane matrices A^(T k) they need (k = lane position
+//     inside the row / half wave / wave) come from a table in LDS, 65 x 4
+//     doubles per section, loaded once per workgroup.  Gone: 8 readlanes per
+//     state pair, the wave-uniform aggregate and row-start chains every lane
+//     recomputed, and the cndmask row selection;
+//   * the HBM <-> lane-block transposition is staged by COLUMN halves (all 64
+//     rows x 16 columns at a time) instead of row halves: every lane reads
+//     its own row in both halves, so there is no predicated half and no
+//     register copies behind it; the staging buffer keeps its size;
+//   * whole tiles only (n is a multiple of NW * 64 * T), state_out from LDS.
+// Same arithmetic per sample; results agree with sos_body to rounding.
+constexpr int kSos2MaxSec = 8;                 // sections whose tables fit beside 3 workgroups per CU
+constexpr int kSos2Tab = 65;                   // A^(T k), k = 0 .. 64
+
+struct Sos2Lds {
+    // doubles: staging NW * 64 * (T/2 + 1) | tables nsec * 4 * 65 | agg 2 * NW * 2 | sst 2 * 32 * 2
+    static __host__ __device__ constexpr int stage(int T, int NW) { return NW * 64 * (T / 2 + 1); }
+    static __host__ __device__ constexpr size_t bytes(int T, int NW, int nsec) {
+        return sizeof(double) * ((size_t)stage(T, NW) + (size_t)nsec * 4 * kSos2Tab + 2 * NW * 2 +
+                                 2 * kSosMaxSec * 2);
+    }
+};
+
+// lane i <- value of lane 15 of the previous row, rows 1 and 3 only (others get 0)
+__device__ __forceinline__ double dpp_bcast15(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// lanes 32..63 <- value of lane 31 (others get 0)
+__device__ __forceinline__ double dpp_bcast31(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// lane i <- lane i - 1 across the whole wave, 0 into lane 0
+__device__ __forceinline__ double dpp_wave_shr1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int T, int NW, bool REV>
+__device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__restrict__ sec,
+                                          const double *__restrict__ gtab, const int c,
+                                          const bool zero_init, const int64_t skip_store_tiles) {
+    static_assert(T == 32, "column-half staging is laid out for T = 32");
+    constexpr int HC = T / 2;                  // columns per staged half
+    constexpr int ROWH = HC + 1;               // LDS row stride (doubles): odd, conflict-free b64
+    constexpr int WAVE_ELEMS = 64 * T;
+    extern __shared__ double lds[];
+    double *tile = lds;                                        // NW * 64 * ROWH
+    double *tab = tile + Sos2Lds::stage(T, NW);                // [nsec][4][65]
+    double *agg = tab + a.nsec * 4 * kSos2Tab;                 // [2][NW][2]
+    double *sst = agg + 2 * NW * 2;                            // [2][kSosMaxSec][2]
+
+    const int w = threadIdx.x >> 6;
+    const int l = threadIdx.x & 63;
+    const int64_t n = a.n;
+    const double *xrow = a.x + (int64_t)c * a.ldx;
+    double *yrow = a.y ? a.y + (int64_t)c * a.ldy : nullptr;
+    double *wl = tile + w * 64 * ROWH;                         // this wave's private staging rows
+
+    for (int i = threadIdx.x; i < a.nsec * 4 * kSos2Tab; i += NW * 64) tab[i] = gtab[i];
+    if (threadIdx.x < a.nsec) {
+        const int s = threadIdx.x;
+        double z0, z1;
+        if (zero_init) {
+            z0 = z1 = 0.0;
+        } else if (a.state_in) {
+            z0 = a.state_in[((int64_t)s * a.nch + c) * 2 + 0];
+            z1 = a.state_in[((int64_t)s * a.nch + c) * 2 + 1];
+        } else {
+            const double x0 = xrow[REV ? n - 1 : 0];
+            z0 = a.zi_unit[2 * s + 0] * x0;
+            z1 = a.zi_unit[2 * s + 1] * x0;
+        }
+        sst[(0 * kSosMaxSec + s) * 2 + 0] = z0;
+        sst[(0 * kSosMaxSec + s) * 2 + 1] = z1;
+    }
+    __syncthreads();
+
+    const int64_t tile_elems = (int64_t)NW * WAVE_ELEMS;
+    const int64_t ntiles = n / tile_elems;
+    int parity = 0, aggbuf = 0;
+    const int myrow = REV ? (63 - l) : l;                      // row of the wave window this lane owns
+    // table indices of this lane: position in its row (+1), in its half wave (+1), in the wave
+    const int ka = (l & 15) + 1, kb = l >= 32 ? l - 31 : 0, kc = l;
+
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const int64_t pw = t * tile_elems + (int64_t)w * WAVE_ELEMS;
+        const int64_t mem_base = REV ? (n - pw - WAVE_ELEMS) : pw;
+        double v[T];
+        // ---- HBM -> LDS -> lane blocks, two column halves
+        {
+            const double *src = xrow + mem_base;
+            const bool al16 = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if (al16) {
+                    // lane l, step i: row 8 i + (l >> 3), columns 16 hh + 2 (l & 7) + {0, 1}
+                    const double2 *p2 = reinterpret_cast<const double2 *>(src + (l >> 3) * T + HC * hh) + (l & 7);
+                    double2 t2[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t2[i] = p2[i * (8 * T / 2)];
+                    double *st = wl + (l >> 3) * ROWH + 2 * (l & 7);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        st[i * 8 * ROWH] = t2[i].x;
+                        st[i * 8 * ROWH + 1] = t2[i].y;
+                    }
+                } else {
+                    // 8 bytes per lane: row 4 i + (l >> 4), column 16 hh + (l & 15)
+                    const double *p1 = src + (l >> 4) * T + HC * hh + (l & 15);
+                    double t1[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) t1[i] = p1[i * 4 * T];
+                    double *st = wl + (l >> 4) * ROWH + (l & 15);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) st[i * 4 * ROWH] = t1[i];
+                }
+                wave_lds_fence();
+                const double *blk = wl + myrow * ROWH;
+#pragma unroll
+                for (int j = 0; j < HC; ++j) v[REV ? (T - 1 - (HC * hh + j)) : (HC * hh + j)] = blk[j];
+                wave_lds_fence();
+            }
+        }
+
+        for (int s = 0; s < a.nsec; ++s) {
+            const SosSection *__restrict__ S = sec + s;
+            const double b0 = S->b0, b1 = S->b1, b2 = S->b2, na1 = -S->a1, na2 = -S->a2;
+            double z0 = 0.0, z1 = 0.0;
+            if (b2 == 1.0) {
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const double xin = v[j];
+                    const double y = fma(b0, xin, z0);
+                    z0 = fma(na1, y, fma(b1, xin, z1));
+                    z1 = fma(na2, y, xin);
+                    v[j] = y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const double xin = v[j];
+                    const double y = fma(b0, xin, z0);
+                    z0 = fma(na1, y, fma(b1, xin, z1));
+                    z1 = fma(na2, y, b2 * xin);
+                    v[j] = y;
+                }
+            }
+            // per-lane matrices of the later scan steps: requested now, used below
+            const double *ts = tab + s * 4 * kSos2Tab;
+            const double ma0 = ts[0 * kSos2Tab + ka], ma1 = ts[1 * kSos2Tab + ka];
+            const double ma2 = ts[2 * kSos2Tab + ka], ma3 = ts[3 * kSos2Tab + ka];
+            const double mb0 = ts[0 * kSos2Tab + kb], mb1 = ts[1 * kSos2Tab + kb];
+            const double mb2 = ts[2 * kSos2Tab + kb], mb3 = ts[3 * kSos2Tab + kb];
+            const double mc0 = ts[0 * kSos2Tab + kc], mc1 = ts[1 * kSos2Tab + kc];
+            const double mc2 = ts[2 * kSos2Tab + kc], mc3 = ts[3 * kSos2Tab + kc];
+            // 1. inclusive scan inside 16-lane rows (constant matrices A^(T 2^k))
+            double e0 = z0, e1 = z1;
+#define OSZ_SCAN_STEP(K, D)                                   \
+    {                                                         \
+        const double u0 = row_shr<D>(e0), u1 = row_shr<D>(e1); \
+        double r0, r1;                                        \
+        mat2_apply(S->P[K], u0, u1, r0, r1);                  \
+        e0 += r0;                                             \
+        e1 += r1;                                             \
+    }
+            OSZ_SCAN_STEP(0, 1)
+            OSZ_SCAN_STEP(1, 2)
+            OSZ_SCAN_STEP(2, 4)
+            OSZ_SCAN_STEP(3, 8)
+#undef OSZ_SCAN_STEP
+            // 2. rows 1, 3 take the total of the row before them ...
+            {
+                const double u0 = dpp_bcast15(e0), u1 = dpp_bcast15(e1);
+                e0 += fma(ma0, u0, ma1 * u1);
+                e1 += fma(ma2, u0, ma3 * u1);
+            }
+            // ... and lanes 32..63 the total of lanes 0..31: inclusive over the wave
+            {
+                const double u0 = dpp_bcast31(e0), u1 = dpp_bcast31(e1);
+                e0 += fma(mb0, u0, mb1 * u1);
+                e1 += fma(mb2, u0, mb3 * u1);
+            }
+            if (l == 63) {
+                agg[(aggbuf * NW + w) * 2 + 0] = e0;
+                agg[(aggbuf * NW + w) * 2 + 1] = e1;
+            }
+            const double p0 = dpp_wave_shr1(e0), p1 = dpp_wave_shr1(e1);   // exclusive, 0 in lane 0
+            __syncthreads();
+            // 3. wave-level replay (uniform): start state of this wave, end state of the tile
+            double s0 = sst[(parity * kSosMaxSec + s) * 2 + 0];
+            double s1 = sst[(parity * kSosMaxSec + s) * 2 + 1];
+            double sw0 = s0, sw1 = s1;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                if (q == w) {
+                    sw0 = s0;
+                    sw1 = s1;
+                }
+                double r0, r1;
+                mat2_apply(S->Q, s0, s1, r0, r1);
+                s0 = r0 + agg[(aggbuf * NW + q) * 2 + 0];
+                s1 = r1 + agg[(aggbuf * NW + q) * 2 + 1];
+            }
+            if (threadIdx.x == 0) {
+                sst[((parity ^ 1) * kSosMaxSec + s) * 2 + 0] = s0;
+                sst[((parity ^ 1) * kSosMaxSec + s) * 2 + 1] = s1;
+            }
+            aggbuf ^= 1;
+            // 4. this lane's true start state and the homogeneous fix-up
+            double h0 = fma(mc0, sw0, fma(mc1, sw1, p0));
+            double h1 = fma(mc2, sw0, fma(mc3, sw1, p1));
+#pragma unroll
+            for (int q = 0; q < T / 8; ++q) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    v[8 * q + r] = fma(S->G8[r][0], h0, fma(S->G8[r][1], h1, v[8 * q + r]));
+                if (q + 1 < T / 8) {
+                    double n0, n1;
+                    mat2_apply(S->A8, h0, h1, n0, n1);
+                    h0 = n0;
+                    h1 = n1;
+                }
+            }
+        }
+        parity ^= 1;
+
+        // ---- lane blocks -> LDS -> HBM, two column halves
+        if (yrow && t >= skip_store_tiles) {
+            double *dst = yrow + mem_base;
+            const bool al16 = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                double *blk = wl + myrow * ROWH;
+#pragma unroll
+                for (int j = 0; j < HC; ++j) blk[j] = v[REV ? (T - 1 - (HC * hh + j)) : (HC * hh + j)];
+                wave_lds_fence();
+                if (al16) {
+                    double2 *q2 = reinterpret_cast<double2 *>(dst + (l >> 3) * T + HC * hh) + (l & 7);
+                    const double *st = wl + (l >> 3) * ROWH + 2 * (l & 7);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        double2 o;
+                        o.x = st[i * 8 * ROWH];
+                        o.y = st[i * 8 * ROWH + 1];
+                        q2[i * (8 * T / 2)] = o;
+                    }
+                } else {
+                    double *q1 = dst + (l >> 4) * T + HC * hh + (l & 15);
+                    const double *st = wl + (l >> 4) * ROWH + (l & 15);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) q1[i * 4 * T] = st[i * 4 * ROWH];
+                }
+                wave_lds_fence();
+            }
+        }
+    }
+    // carried state of the chunk: the end state of its last tile
+    if (a.state_out && threadIdx.x < a.nsec) {
+        const int s = threadIdx.x;
+        a.state_out[((int64_t)s * a.nch + c) * 2 + 0] = sst[(parity * kSosMaxSec + s) * 2 + 0];
+        a.state_out[((int64_t)s * a.nch + c) * 2 + 1] = sst[(parity * kSosMaxSec + s) * 2 + 1];
+    }
+}
+
 template <int T, int NW, bool REV, bool GUARD>
 __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
                                                       const SosSection *__restrict__ sec) {

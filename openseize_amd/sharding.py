@@ -53,6 +53,10 @@ def reduce_segment_sums(total, count, group=None):
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     n = int(round(float(cnt.item())))
+    if n and total.is_cuda:
+        # the divide of the segment average is a kernel of this library too
+        from openseize_amd import _lib as lib
+        return dev.ew(lib.EW_DIV, total.reshape(total.shape[0], -1), cnt).reshape(total.shape), n
     return (total / n if n else total), n
 
 
