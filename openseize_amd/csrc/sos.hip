@@ -42,6 +42,8 @@ struct SosArgs {
     const double *zi_unit;   // (nsec, 2); used when state_in is null
     double *state_out;       // (nsec, nch, 2) or null
     int nsec, nch;
+    const double *tab2;      // per-lane scan matrices for sos_body2 ([nsec][4][65]) or null
+    int touch;               // sos_body2: touch-prefetch the next tile's window
 };
 
 // In-kernel phase stamps for the diagnostic build only
@@ -464,7 +466,7 @@ struct Sos2Lds {
     static __host__ __device__ constexpr int stage(int T, int NW) { return NW * 64 * (T / 2 + 1); }
     static __host__ __device__ constexpr size_t bytes(int T, int NW, int nsec) {
         return sizeof(double) * ((size_t)stage(T, NW) + (size_t)nsec * 4 * kSos2Tab + 2 * NW * 2 +
-                                 2 * kSosMaxSec * 2);
+                                 2 * kSosMaxSec * 2) + sizeof(int) * NW * 64;
     }
 };
 
@@ -490,7 +492,7 @@ __device__ __forceinline__ double dpp_wave_shr1(double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int T, int NW, bool REV>
+template <int T, int NW, bool REV, bool AL16, bool PF>
 __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__restrict__ sec,
                                           const double *__restrict__ gtab, const int c,
                                           const bool zero_init, const int64_t skip_store_tiles) {
@@ -503,8 +505,9 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
     double *tab = tile + Sos2Lds::stage(T, NW);                // [nsec][4][65]
     double *agg = tab + a.nsec * 4 * kSos2Tab;                 // [2][NW][2]
     double *sst = agg + 2 * NW * 2;                            // [2][kSosMaxSec][2]
+    int *dump = reinterpret_cast<int *>(sst + 2 * kSosMaxSec * 2);   // [NW][64] touch-prefetch sink
 
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: an SGPR
     const int l = threadIdx.x & 63;
     const int64_t n = a.n;
     const double *xrow = a.x + (int64_t)c * a.ldx;
@@ -534,47 +537,85 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
     const int64_t ntiles = n / tile_elems;
     int parity = 0, aggbuf = 0;
     const int myrow = REV ? (63 - l) : l;                      // row of the wave window this lane owns
-    // table indices of this lane: position in its row (+1), in its half wave (+1), in the wave
-    const int ka = (l & 15) + 1, kb = l >= 32 ? l - 31 : 0, kc = l;
+    // AL16: every row of x and y starts 16-byte aligned (decided by the host per
+    // launch): 16 bytes per lane on the HBM side, otherwise 8
+    constexpr bool al16 = AL16;
+    // 16 doubles of one column half of a wave window, HBM -> registers
+    double pf[HC];
+    auto request_half = [&](double *dstv, int64_t base, int hh) {
+        const double *src = xrow + base;
+        if (al16) {
+            const double2 *p2 = reinterpret_cast<const double2 *>(src + (l >> 3) * T + HC * hh) + (l & 7);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double2 q = p2[i * (8 * T / 2)];
+                dstv[2 * i] = q.x;
+                dstv[2 * i + 1] = q.y;
+            }
+        } else {
+            const double *p1 = src + (l >> 4) * T + HC * hh + (l & 15);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dstv[i] = p1[i * 4 * T];
+        }
+    };
+    if (PF && n >= (int64_t)NW * WAVE_ELEMS)
+        request_half(pf, REV ? (n - (int64_t)w * WAVE_ELEMS - WAVE_ELEMS) : (int64_t)w * WAVE_ELEMS, 0);
 
     for (int64_t t = 0; t < ntiles; ++t) {
         const int64_t pw = t * tile_elems + (int64_t)w * WAVE_ELEMS;
         const int64_t mem_base = REV ? (n - pw - WAVE_ELEMS) : pw;
         double v[T];
-        // ---- HBM -> LDS -> lane blocks, two column halves
-        {
-            const double *src = xrow + mem_base;
-            const bool al16 = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+        // ---- HBM -> LDS -> lane blocks, two column halves; the first half was
+        // requested a tile ago (below) and is in `pf` by now
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                if (al16) {
-                    // lane l, step i: row 8 i + (l >> 3), columns 16 hh + 2 (l & 7) + {0, 1}
-                    const double2 *p2 = reinterpret_cast<const double2 *>(src + (l >> 3) * T + HC * hh) + (l & 7);
-                    double2 t2[8];
+        for (int hh = 0; hh < 2; ++hh) {
+            if (hh == 1 || !PF) request_half(pf, mem_base, hh);
+            if (al16) {
+                // lane l, step i: row 8 i + (l >> 3), columns 16 hh + 2 (l & 7) + {0, 1}
+                double *st = wl + (l >> 3) * ROWH + 2 * (l & 7);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) t2[i] = p2[i * (8 * T / 2)];
-                    double *st = wl + (l >> 3) * ROWH + 2 * (l & 7);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        st[i * 8 * ROWH] = t2[i].x;
-                        st[i * 8 * ROWH + 1] = t2[i].y;
-                    }
-                } else {
-                    // 8 bytes per lane: row 4 i + (l >> 4), column 16 hh + (l & 15)
-                    const double *p1 = src + (l >> 4) * T + HC * hh + (l & 15);
-                    double t1[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) t1[i] = p1[i * 4 * T];
-                    double *st = wl + (l >> 4) * ROWH + (l & 15);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) st[i * 4 * ROWH] = t1[i];
+                for (int i = 0; i < 8; ++i) {
+                    st[i * 8 * ROWH] = pf[2 * i];
+                    st[i * 8 * ROWH + 1] = pf[2 * i + 1];
                 }
-                wave_lds_fence();
-                const double *blk = wl + myrow * ROWH;
+            } else {
+                // 8 bytes per lane: row 4 i + (l >> 4), column 16 hh + (l & 15)
+                double *st = wl + (l >> 4) * ROWH + (l & 15);
 #pragma unroll
-                for (int j = 0; j < HC; ++j) v[REV ? (T - 1 - (HC * hh + j)) : (HC * hh + j)] = blk[j];
-                wave_lds_fence();
+                for (int i = 0; i < 16; ++i) st[i * 4 * ROWH] = pf[i];
             }
+            wave_lds_fence();
+            const double *blk = wl + myrow * ROWH;
+#pragma unroll
+            for (int j = 0; j < HC; ++j) v[REV ? (T - 1 - (HC * hh + j)) : (HC * hh + j)] = blk[j];
+            wave_lds_fence();
+        }
+
+        // Touch the next tile's window (one dword per 128-byte line, two loads per
+        // lane = all 128 lines of the 16 KB) so that it is on its way into L2 /
+        // the Infinity Cache while this tile computes.
+        if (a.touch && t + 1 < ntiles) {
+            const int64_t nb = REV ? (mem_base - tile_elems) : (mem_base + tile_elems);
+            const int *pn = reinterpret_cast<const int *>(xrow + nb) + l * 32;
+            // LDS-DMA into a 256-byte dump area of this wave: no destination
+            // registers, nothing to keep alive; the bytes are never read.  As an
+            // asm statement: through the builtin the compiler orders every later
+            // workgroup barrier behind these loads (s_waitcnt vmcnt(0)), which
+            // is the stall the prefetch is there to remove.  Loads it does not
+            // know about only make its own counted vmcnt waits stricter (they
+            // are older than whatever it counts), never wrong.
+            const unsigned lds_off = __builtin_amdgcn_readfirstlane(
+                (unsigned)reinterpret_cast<uintptr_t>(dump) + (unsigned)w * 256u);
+            unsigned m0_saved;
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %1\n\t"
+                         "s_nop 0\n\t"
+                         "global_load_lds_dword %2, off\n\t"
+                         "global_load_lds_dword %3, off\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(m0_saved)
+                         : "s"(lds_off), "v"(pn), "v"(pn + 64 * 32)
+                         : "memory");
         }
 
         for (int s = 0; s < a.nsec; ++s) {
@@ -600,14 +641,17 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
                     v[j] = y;
                 }
             }
-            // per-lane matrices of the later scan steps: requested now, used below
+            // per-lane matrices A^(T k) of the later scan steps, k = this lane's
+            // position in its row (+1), in its half wave (+1), in the wave; the
+            // indices are recomputed per section from an opaque copy of the lane
+            // number (hoisted out of the tile loop they would cost registers the
+            // kernel does not have at three workgroups per CU)
+            int ll = l;
+            asm volatile("" : "+v"(ll));
+            const int ka = (ll & 15) + 1, kb = ll >= 32 ? ll - 31 : 0, kc = ll;
             const double *ts = tab + s * 4 * kSos2Tab;
             const double ma0 = ts[0 * kSos2Tab + ka], ma1 = ts[1 * kSos2Tab + ka];
             const double ma2 = ts[2 * kSos2Tab + ka], ma3 = ts[3 * kSos2Tab + ka];
-            const double mb0 = ts[0 * kSos2Tab + kb], mb1 = ts[1 * kSos2Tab + kb];
-            const double mb2 = ts[2 * kSos2Tab + kb], mb3 = ts[3 * kSos2Tab + kb];
-            const double mc0 = ts[0 * kSos2Tab + kc], mc1 = ts[1 * kSos2Tab + kc];
-            const double mc2 = ts[2 * kSos2Tab + kc], mc3 = ts[3 * kSos2Tab + kc];
             // 1. inclusive scan inside 16-lane rows (constant matrices A^(T 2^k))
             double e0 = z0, e1 = z1;
 #define OSZ_SCAN_STEP(K, D)                                   \
@@ -631,6 +675,8 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
             }
             // ... and lanes 32..63 the total of lanes 0..31: inclusive over the wave
             {
+                const double mb0 = ts[0 * kSos2Tab + kb], mb1 = ts[1 * kSos2Tab + kb];
+                const double mb2 = ts[2 * kSos2Tab + kb], mb3 = ts[3 * kSos2Tab + kb];
                 const double u0 = dpp_bcast31(e0), u1 = dpp_bcast31(e1);
                 e0 += fma(mb0, u0, mb1 * u1);
                 e1 += fma(mb2, u0, mb3 * u1);
@@ -641,6 +687,8 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
             }
             const double p0 = dpp_wave_shr1(e0), p1 = dpp_wave_shr1(e1);   // exclusive, 0 in lane 0
             __syncthreads();
+            const double mc0 = ts[0 * kSos2Tab + kc], mc1 = ts[1 * kSos2Tab + kc];
+            const double mc2 = ts[2 * kSos2Tab + kc], mc3 = ts[3 * kSos2Tab + kc];
             // 3. wave-level replay (uniform): start state of this wave, end state of the tile
             double s0 = sst[(parity * kSosMaxSec + s) * 2 + 0];
             double s1 = sst[(parity * kSosMaxSec + s) * 2 + 1];
@@ -679,12 +727,15 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
         }
         parity ^= 1;
 
-        // ---- lane blocks -> LDS -> HBM, two column halves
-        if (yrow && t >= skip_store_tiles) {
-            double *dst = yrow + mem_base;
-            const bool al16 = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+        // ---- lane blocks -> LDS -> HBM, two column halves.  Between them the
+        // next tile's first half is requested (the 32 registers the first half
+        // of the outputs just left): it lands while the second half is staged
+        // out -- the section loop has no registers to spare, this code does.
+        const bool store = yrow && t >= skip_store_tiles;
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < 2; ++hh) {
+            if (store) {
+                double *dst = yrow + mem_base;
                 double *blk = wl + myrow * ROWH;
 #pragma unroll
                 for (int j = 0; j < HC; ++j) blk[j] = v[REV ? (T - 1 - (HC * hh + j)) : (HC * hh + j)];
@@ -707,6 +758,9 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
                 }
                 wave_lds_fence();
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (PF && hh == 0 && t + 1 < ntiles)
+                request_half(pf, REV ? (mem_base - tile_elems) : (mem_base + tile_elems), 0);
         }
     }
     // carried state of the chunk: the end state of its last tile
@@ -765,6 +819,66 @@ template <int T, int NW, bool REV>
 __global__ __launch_bounds__(NW * 64, 3) void sos_split_lean_kernel(
     SosArgs a, const SosSection *__restrict__ sec, int nseg, int64_t seglen, int64_t pre) {
     sos_segment<T, NW, REV, true>(a, sec, blockIdx.x, blockIdx.y, nseg, seglen, pre);
+}
+
+// Time segment of one pass on the trimmed body (sos_body2).
+template <int T, int NW, bool REV, bool AL16, bool PF>
+__device__ __forceinline__ void sos_segment2(const SosArgs &a, const SosSection *__restrict__ sec,
+                                             const double *__restrict__ gtab, int c, int s, int nseg,
+                                             int64_t seglen, int64_t pre) {
+    const int64_t begin = (int64_t)s * seglen;
+    const int64_t len = (s == nseg - 1) ? a.n - begin : seglen;
+    const int64_t p = s > 0 ? pre : 0;
+    SosArgs b = a;
+    b.n = len + p;
+    if (REV) {
+        const int64_t lo = a.n - begin - len;
+        b.x = a.x + lo;
+        if (a.y) b.y = a.y + lo;
+    } else {
+        b.x = a.x + begin - p;
+        if (a.y) b.y = a.y + begin - p;
+    }
+    if (s != nseg - 1) b.state_out = nullptr;
+    sos_body2<T, NW, REV, AL16, PF>(b, sec, gtab, c, s > 0, p / ((int64_t)NW * 64 * T));
+}
+
+template <int T, int NW, bool REV, bool AL16, bool PF>
+__global__ __launch_bounds__(NW * 64, 3) void sos_split2_kernel(
+    SosArgs a, const SosSection *__restrict__ sec, const double *__restrict__ gtab, int nseg,
+    int64_t seglen, int64_t pre) {
+    sos_segment2<T, NW, REV, AL16, PF>(a, sec, gtab, blockIdx.x, blockIdx.y, nseg, seglen, pre);
+}
+
+template <int T, int NW, bool AL16, bool PF>
+__global__ __launch_bounds__(NW * 64, 3) void sos_dual2_kernel(
+    SosArgs f, SosArgs b, const SosSection *__restrict__ sec, const double *__restrict__ gtab,
+    int nseg, int64_t seglen_f, int64_t seglen_b, int64_t pre) {
+    const int pass = blockIdx.y / nseg, s = blockIdx.y % nseg;
+    if (pass == 0)
+        sos_segment2<T, NW, false, AL16, PF>(f, sec, gtab, blockIdx.x, s, nseg, seglen_f, pre);
+    else
+        sos_segment2<T, NW, true, AL16, PF>(b, sec, gtab, blockIdx.x, s, nseg, seglen_b, pre);
+}
+
+// every row of the pass starts 16-byte aligned (segments and tiles keep it)
+// OSZ_SOS_PF=1: request the next tile's first half into registers between the two
+// output halves (A/B knob; measured SLOWER, 1.88 ms against 1.76 ms for the dual
+// launch: the 32 extra live registers push the kernel into scratch spills)
+static bool sos_pf() {
+    static int pf = -1;
+    if (pf < 0) {
+        const char *e = getenv("OSZ_SOS_PF");
+        pf = (e && atoi(e) == 1) ? 1 : 0;
+    }
+    return pf == 1;
+}
+
+static bool sos_rows_aligned16(const SosArgs &a) {
+    auto ok = [](const void *p, int64_t ld) {
+        return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 1) == 0);
+    };
+    return ok(a.x, a.ldx) && ok(a.y, a.ldy) && (a.n & 1) == 0;
 }
 
 // Forward pass of one chunk and backward pass of another in ONE launch:
@@ -907,6 +1021,19 @@ static int64_t sos_warmup_len(const std::vector<SosSection> &secs, int64_t quant
     return cap;
 }
 
+// A^(T k), k = 0 .. 64, per section, element-major ([sec][4][65]) for sos_body2
+static void build_lane_table(const double *c, int T, double *out) {
+    const double a0 = c[3];
+    const ld_t A[4] = {-(ld_t)(c[4] / a0), 1.0L, -(ld_t)(c[5] / a0), 0.0L};
+    ld_t AT[4] = {1, 0, 0, 1};
+    for (int j = 0; j < T; ++j) mat2_mul(A, AT, AT);
+    ld_t M[4] = {1, 0, 0, 1};
+    for (int k = 0; k < kSos2Tab; ++k) {
+        for (int e = 0; e < 4; ++e) out[e * kSos2Tab + k] = (double)M[e];
+        mat2_mul(AT, M, M);
+    }
+}
+
 int sos_tables_for(osz_sos_s *h, int T, const SosSection **dsec) {
     if (T == h->T) {
         *dsec = h->dsec;
@@ -983,6 +1110,24 @@ static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
     const int64_t seg_tiles = (ntiles + nseg - 1) / nseg;
     nseg = (ntiles + seg_tiles - 1) / seg_tiles;
     const bool lean = sos_lean();
+    if constexpr (T == 32 && NW == 4) {
+        if (lean && a.tab2) {
+            const bool al = sos_rows_aligned16(a);
+            auto k2 = sos_pf() ? (al ? sos_split2_kernel<T, NW, REV, true, true>
+                                     : sos_split2_kernel<T, NW, REV, false, true>)
+                               : (al ? sos_split2_kernel<T, NW, REV, true, false>
+                                     : sos_split2_kernel<T, NW, REV, false, false>);
+            const size_t lds2 = Sos2Lds::bytes(T, NW, a.nsec);
+            OSZ_DYN_LDS(k2, lds2);
+            {
+                KernelTimer kt(REV ? (a.y ? "sos_bwd_split" : "sos_warmup") : "sos_fwd_split", st);
+                hipLaunchKernelGGL(k2, dim3(a.nch, (unsigned)nseg), dim3(NW * 64), lds2, st, a, a.sec,
+                                   a.tab2, (int)nseg, seg_tiles * tile, warm_len);
+            }
+            OSZ_HIP(hipGetLastError());
+            return OSZ_OK;
+        }
+    }
     auto kern = lean ? sos_split_lean_kernel<T, NW, REV> : sos_split_kernel<T, NW, REV>;
     const size_t lds = sizeof(double) * ((size_t)NW * (lean ? 32 : 64) * (T + kSosPad) +
                                          2 * NW * 2 + 2 * kSosMaxSec * 2);
@@ -1079,6 +1224,20 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     OSZ_HIP(hipMalloc(&p->dzi, sizeof(double) * nsec * 2));
     OSZ_HIP(hipMemcpy(p->dsec, secs.data(), sizeof(SosSection) * nsec, hipMemcpyHostToDevice));
     OSZ_HIP(hipMemset(p->dstate, 0, sb));
+    p->dtab2 = nullptr;
+    p->touch = 0;
+    if (const char *e = getenv("OSZ_SOS_TOUCH")) p->touch = atoi(e);
+    {
+        // the trimmed lean body (sos_body2): T = 32, NW = 4, up to 8 sections;
+        // OSZ_SOS_V2=0 keeps the first lean body (A/B runs)
+        const char *e = getenv("OSZ_SOS_V2");
+        if (T == 32 && NW == 4 && nsec <= kSos2MaxSec && !(e && atoi(e) == 0)) {
+            std::vector<double> tab((size_t)nsec * 4 * kSos2Tab);
+            for (int s = 0; s < nsec; ++s) build_lane_table(sos + 6 * s, T, tab.data() + (size_t)s * 4 * kSos2Tab);
+            OSZ_HIP(hipMalloc(&p->dtab2, tab.size() * sizeof(double)));
+            OSZ_HIP(hipMemcpy(p->dtab2, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
     // steady-state unit-step state of each section (what scipy.signal.sosfilt_zi
     // returns at numerical.py:378): with section DC gain g and unit input,
     // z0 = g - b0, z1 = b2 - a2*g; the next section sees the input scaled by g.
@@ -1126,6 +1285,7 @@ int osz_sos_destroy(osz_sos_t h) {
     (void)hipFree(h->dtmp);
     (void)hipFree(h->dcarry);
     (void)hipFree(h->dzi);
+    (void)hipFree(h->dtab2);
     delete h;
     return OSZ_OK;
 }
@@ -1192,6 +1352,8 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y, int64_
     a.state_out = h->dstate_alt;
     a.nsec = h->nsec;
     a.nch = h->nch;
+    a.tab2 = h->dtab2;
+    a.touch = h->touch;
     int rc = sos_launch<false>(a, h->dcarry, h->T, h->NW, h->warm_len, as_stream(stream));
     if (rc) return rc;
     std::swap(h->dstate, h->dstate_alt);
@@ -1221,6 +1383,8 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
     w.nsec = fw.nsec = bw.nsec = h->nsec;
     w.nch = fw.nch = bw.nch = h->nch;
     w.zi_unit = fw.zi_unit = bw.zi_unit = h->dzi;
+    w.tab2 = fw.tab2 = bw.tab2 = h->dtab2;
+    w.touch = fw.touch = bw.touch = h->touch;
     if (fb) {  // warm-up over the head of the next forward chunk: state only
         w.x = fb;
         w.ldx = ldfb;
@@ -1256,11 +1420,22 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
         if (nseg >= 2) {
             const int64_t sf = ((nx / tile + nseg - 1) / nseg) * tile;
             const int64_t sb = ((na / tile + nseg - 1) / nseg) * tile;
-            auto kern = sos_dual_lean_kernel<32, 4>;
-            const size_t lds = sizeof(double) * ((size_t)4 * 32 * (32 + kSosPad) + 2 * 4 * 2 +
-                                                 2 * kSosMaxSec * 2);
-            OSZ_DYN_LDS(kern, lds);
-            {
+            if (h->dtab2) {
+                const bool al = sos_rows_aligned16(fw) && sos_rows_aligned16(bw);
+                auto k2 = sos_pf() ? (al ? sos_dual2_kernel<32, 4, true, true>
+                                         : sos_dual2_kernel<32, 4, false, true>)
+                                   : (al ? sos_dual2_kernel<32, 4, true, false>
+                                         : sos_dual2_kernel<32, 4, false, false>);
+                const size_t lds2 = Sos2Lds::bytes(32, 4, h->nsec);
+                OSZ_DYN_LDS(k2, lds2);
+                KernelTimer kt("sos_dual", st);
+                hipLaunchKernelGGL(k2, dim3(h->nch, 2 * nseg), dim3(256), lds2, st, fw, bw, h->dsec,
+                                   h->dtab2, nseg, sf, sb, h->warm_len);
+            } else {
+                auto kern = sos_dual_lean_kernel<32, 4>;
+                const size_t lds = sizeof(double) * ((size_t)4 * 32 * (32 + kSosPad) + 2 * 4 * 2 +
+                                                     2 * kSosMaxSec * 2);
+                OSZ_DYN_LDS(kern, lds);
                 KernelTimer kt("sos_dual", st);
                 hipLaunchKernelGGL(kern, dim3(h->nch, 2 * nseg), dim3(256), lds, st, fw, bw,
                                    h->dsec, nseg, sf, sb, h->warm_len);
@@ -1289,6 +1464,8 @@ int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t n
     a.nsec = h->nsec;
     a.nch = h->nch;
     a.zi_unit = h->dzi;
+    a.tab2 = h->dtab2;
+    a.touch = h->touch;
     if (fb) {
         // warm-up over the next chunk: state only (numerical.py:397-399)
         // only the warm_len samples next to chunk a can influence the state
