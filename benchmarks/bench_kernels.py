@@ -199,6 +199,24 @@ def main():
     dt = (time.perf_counter() - t0) / 3
     out.append({"workload": "cfg-1 host-fed, chunksize 1e6", "seconds": dt,
                 "Msamples_s": xh.size / dt / 1e6})
+    # host-fed steady state: 16 ch x 2^23 samples (1 GiB) of ndarray through the
+    # 256-tap FIR in chunks of 2^18 ... 2^20 -- pinned ring + H2D / compute / D2H
+    # streams (dev.HostPipe); PCIe Gen5 x16 bounds it at ~63 GB/s / 16 B
+    xl = np.random.default_rng(1).standard_normal((16, 1 << 23))
+    for cs in (1 << 18, 1 << 20):
+        def fed():
+            total = 0
+            for piece in nm.oaconvolve(producer(xl, cs, -1), hh, -1, "same"):
+                total += piece.shape[-1]
+            return total
+        fed()
+        t0 = time.perf_counter()
+        got = fed()
+        dt = time.perf_counter() - t0
+        assert got == xl.shape[-1]
+        out.append({"workload": f"host-fed oaconvolve 16 ch x 2^23, 256 taps, chunksize {cs}",
+                    "seconds": dt, "Msamples_s": xl.size / dt / 1e6,
+                    "pcie_GBps_each_way": 8 * xl.size / dt / 1e9})
     for o in out:
         print(json.dumps(o))
 

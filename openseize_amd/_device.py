@@ -133,6 +133,132 @@ class Layout:
         return out.contiguous()
 
 
+# ---------------------------------------------------------------------------
+# host-fed streams: pinned staging + H2D / compute / D2H on three streams
+# ---------------------------------------------------------------------------
+_COPY_POOL = None
+
+
+def _copy_pool():
+    global _COPY_POOL
+    if _COPY_POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 4) // 2)))
+    return _COPY_POOL
+
+
+def _threaded_copy(dst, src):
+    """dst[...] = src for 2-D arrays, split over a few threads (numpy releases
+    the GIL in the copy): one core moves ~10 GB/s, PCIe wants more."""
+    rows, cols = dst.shape
+    if dst.size < (1 << 18):
+        np.copyto(dst, src)
+        return
+    parts = 8
+    if rows >= parts:
+        cuts = [(slice(r * rows // parts, (r + 1) * rows // parts), slice(None)) for r in range(parts)]
+    else:
+        cuts = [(slice(None), slice(c * cols // parts, (c + 1) * cols // parts)) for c in range(parts)]
+    list(_copy_pool().map(lambda sl: np.copyto(dst[sl], src[sl]), cuts))
+
+
+class HostPipe:
+    """Overlaps the transfers of a host-fed stream with its kernels.  The
+    reference's real sources are host ndarrays and EDF files
+    (core/producer.py:289-295, file_io/edf.py:558-586); taken one chunk at a
+    time, synchronously and from pageable memory, they reach ~1/8 of what PCIe
+    allows.  Here every chunk is copied (threaded) into a pinned ring buffer and
+    sent on an H2D stream, the kernels run on the compute stream, results leave
+    on a D2H stream into pinned arrays that are handed to the caller as
+    ndarrays (torch's caching pinned allocator recycles them once dropped), and
+    the generators built on ``run`` read one or two chunks ahead so the three
+    stages of neighbouring chunks overlap."""
+
+    def __init__(self, layout, slots=3):
+        require_gpu()
+        self.layout = layout
+        self.h2d = torch.cuda.Stream()
+        self.d2h = torch.cuda.Stream()
+        self.compute = torch.cuda.current_stream()
+        self.slots = [None] * slots          # (pinned tensor, last H2D event)
+        self.turn = 0
+
+    def upload(self, arr):
+        """ndarray chunk -> (float64 CUDA tensor (nch, n), ready event)."""
+        lay = self.layout
+        a = np.asarray(arr, dtype=np.float64)
+        moved = np.moveaxis(a, lay.axis, -1)
+        n = moved.shape[-1]
+        src = moved.reshape(lay.nch, n)
+        k = self.turn % len(self.slots)
+        self.turn += 1
+        slot = self.slots[k]
+        if slot is not None:
+            slot[1].synchronize()                        # its previous transfer has left the buffer
+        if slot is None or slot[0].numel() < lay.nch * n:
+            slot = [torch.empty(max(lay.nch * n, 1), dtype=torch.float64, pin_memory=True), None]
+        stage = slot[0][:lay.nch * n].view(lay.nch, n)
+        _threaded_copy(stage.numpy(), src)
+        with torch.cuda.stream(self.h2d):
+            x = torch.empty((lay.nch, n), dtype=torch.float64, device="cuda")
+            x.copy_(stage, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.h2d)
+        x.record_stream(self.compute)
+        slot[1] = ev
+        self.slots[k] = slot
+        return x, ev
+
+    def download(self, y2d):
+        """Device result -> (pinned host tensor, done event), behind the kernels
+        queued so far on the compute stream."""
+        done = torch.cuda.Event()
+        done.record(self.compute)
+        with torch.cuda.stream(self.d2h):
+            self.d2h.wait_event(done)
+            out = torch.empty(tuple(y2d.shape), dtype=y2d.dtype, pin_memory=True)
+            out.copy_(y2d, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.d2h)
+        y2d.record_stream(self.d2h)
+        return out, ev
+
+    def restore(self, out):
+        """Pinned (nch, m) result -> ndarray with the sample axis back in place."""
+        lay = self.layout
+        arr = out.numpy().reshape(lay.other + (out.shape[-1],))
+        return np.moveaxis(arr, -1, lay.axis)
+
+    def run(self, chunks, op, lookahead=2, tell_last=False):
+        """Generator: for every ndarray chunk, ``op(x2d) -> y2d`` (a CUDA tensor,
+        or None / zero columns for "nothing to emit") in stream order; yields
+        the results as ndarrays.  The next chunk is uploaded before the current
+        one is computed, and up to ``lookahead`` results are in flight.  With
+        ``tell_last`` the call is ``op(x2d, is_last_chunk)``."""
+        from collections import deque
+        it = iter(chunks)
+        flying = deque()
+        nxt = next(it, None)
+        staged = self.upload(nxt) if nxt is not None else None
+        while staged is not None:
+            x2d, ready = staged
+            nxt = next(it, None)
+            staged = self.upload(nxt) if nxt is not None else None
+            self.compute.wait_event(ready)
+            y2d = op(x2d, staged is None) if tell_last else op(x2d)
+            if y2d is not None and y2d.shape[-1] > 0:
+                flying.append(self.download(y2d))
+            while len(flying) > lookahead:
+                out, ev = flying.popleft()
+                ev.synchronize()
+                yield self.restore(out)
+        while flying:
+            out, ev = flying.popleft()
+            ev.synchronize()
+            yield self.restore(out)
+
+
 class _Handle:
     _destroy = None
     _state = None          # prefix of the osz_*_state_size / _get_state / _set_state trio

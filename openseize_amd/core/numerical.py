@@ -72,6 +72,12 @@ def convolve_slicer(arr, shape1, shape2, mode, axis):
     raise ValueError(f"unknown mode {mode!r}")
 
 
+def _chain_first(first, rest):
+    """The stream again after its first array has been peeked at."""
+    yield first
+    yield from rest
+
+
 def _oa_cuts(wlen, mode):
     """Samples dropped left of the first and right of the last segment
     (core/numerical.py:143-150)."""
@@ -121,6 +127,34 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
     pos, host, device = 0, True, "cuda"
     cur, fill = None, 0                      # open output buffer and its filled columns
     import torch
+
+    chunks = iter(pro)
+    first = next(chunks, None)
+    if first is not None and not dev.is_tensor(first):
+        # host-fed stream: transfers and kernels overlapped (dev.HostPipe); every
+        # piece crosses PCIe as it is, one push per chunk
+        state = {"pos": 0}
+
+        def push(x2d):
+            n = x2d.shape[1]
+            if n == 0:
+                return None
+            skip = min(max(lcut - state["pos"], 0), n)
+            state["pos"] += n
+            return fir.push(x2d, skip)
+
+        try:
+            pipe = dev.HostPipe(layout)
+            yield from pipe.run(_chain_first(first, chunks), push)
+            if state["pos"] > 0:
+                skip = min(max(lcut - state["pos"], 0), wlen - 1)
+                if wlen - 1 - skip - rcut > 0:
+                    tail = fir.flush("cuda", skip=skip, drop=rcut)
+                    yield layout.from2d(tail, True)
+        finally:
+            fir.close()
+        return
+    pro = _chain_first(first, chunks) if first is not None else ()
 
     def emit(buf, cols):
         return layout.from2d(buf if cols == buf.shape[1] else buf[:, :cols], host)
@@ -208,7 +242,17 @@ def sosfilt(pro, sos, axis, zi=None):
     try:
         if zi is not None:
             stream.set_state(_zi_to_2d(zi, sos.shape[0], layout))
-        for subarr in pro:
+        chunks = iter(pro)
+        first = next(chunks, None)
+        if first is None:
+            return
+        if not dev.is_tensor(first):
+            # host-fed: transfers overlapped with the kernels (dev.HostPipe)
+            yield from dev.HostPipe(layout).run(
+                _chain_first(first, chunks),
+                lambda x2d: stream.forward(x2d) if x2d.shape[1] else None)
+            return
+        for subarr in _chain_first(first, chunks):
             x2d, host = layout.to2d(subarr)
             if x2d.shape[1] == 0:
                 continue
@@ -402,6 +446,12 @@ def polyphase_resample(pro, L, M, fs, fir, axis, **kwargs):
     try:
         chunks = iter(pro)
         cur = next(chunks, None)
+        if cur is not None and not dev.is_tensor(cur):
+            # host-fed: transfers overlapped with the kernels (dev.HostPipe)
+            yield from dev.HostPipe(layout).run(
+                _chain_first(cur, chunks), lambda x2d, last: stream.push(x2d, final=last),
+                tell_last=True)
+            return
         while cur is not None:
             nxt = next(chunks, None)
             x2d, host = layout.to2d(cur)
