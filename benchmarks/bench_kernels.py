@@ -52,6 +52,20 @@ def main():
                 "algorithmic_GBps": 8 * CH * N / dt / 1e9})
     spec.close()
 
+    # the same through the 512-thread fft8 kernel (OSZ_SPEC_V8=2), and the other
+    # on-chip sizes (fs = nfft, 50 % overlap)
+    os.environ["OSZ_SPEC_V8"] = "2"
+    for nf in (4096, 512, 1024, 2048, 8192):
+        wn = sps.get_window("hann", nf)
+        sc = float(np.sqrt(1 / (float(nf) * np.sum(wn ** 2))))
+        sp8 = dev.SpecStream(nf, nf, nf // 2, wn, sc, "constant", _lib.SPEC_PSD_MEAN, CH)
+        dt = timed(lambda: sp8.push(x), 5)
+        out.append({"workload": f"Welch PSD 256 ch x 2^20, nfft {nf}, 50 % (fft8 kernel)",
+                    "ms_per_chunk": dt * 1e3, "Msamples_s": CH * N / dt / 1e6,
+                    "algorithmic_GBps": 8 * CH * N / dt / 1e9})
+        sp8.close()
+    os.environ.pop("OSZ_SPEC_V8")
+
     # cfg-5 part 1: polyphase downsample 5 -> 1, default Kaiser (113 taps)
     cutoff = 20480 / 10
     h = Kaiser(cutoff - cutoff / 10, cutoff + cutoff / 10, 20480, gpass=0.1, gstop=40).coeffs

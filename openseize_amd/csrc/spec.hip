@@ -17,12 +17,15 @@
 // reference becomes a (nch, < nfft) carry buffer on the device.
 #include <rocfft/rocfft.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
 #include "fft4096.h"
+#include "fft8.h"
 
 namespace osz {
 
@@ -366,6 +369,245 @@ __global__ void spec_partial_reduce_kernel(const double *partial, double *dsum, 
     dsum[(int64_t)c * kNF + k] += s;
 }
 
+// ---------------------------------------------------------------------------
+// Generic on-chip path for nfft = 512 ... 8192 (powers of two), nwin <= nfft,
+// any stride: the same scheme as spec_cube_kernel -- two real segments per
+// complex transform, detrend and window in registers, spectra separated with
+// one LDS exchange, power / scaling / segment sums in registers -- on the
+// 8-point-per-thread transforms of fft8.h: nfft / 8 threads per workgroup, about
+// half the registers per thread of the 4096-point cube kernel, so twice the
+// waves share a CU.  nfft = int(fs / resolution) of the reference
+// (spectra/estimators.py:144) is whatever the user's fs makes it; the powers of
+// two in this range stay on chip, everything else goes through rocFFT.
+struct Spec8Args {
+    const double *x;        // one contiguous source: segment s starts at column s * stride
+    const double *window;   // nwin
+    void *out;              // SEGMENTS modes: (nseg, nch, nfreq) f64 / c128
+    double *partial;        // PSD_MEAN: (nch, nruns, nfreq) sums of this launch
+    const double *tab;      // W_8192^j, j < 1024
+    int64_t ldx;
+    int64_t nseg;
+    int stride, nwin, nch, nruns;
+    double scale;
+};
+
+// All forward stages of one transform, a workgroup barrier between them.  The
+// thread index is made opaque again before every stage: LDS slot numbers
+// computed ahead of their stage would sit in registers the kernel does not have.
+template <int N, int S>
+struct Fwd8 {
+    static __device__ __forceinline__ void run(int tid, double *re, double *im,
+                                               const fft8::Twid<N> &tw, fft8::C2 *lds) {
+        double wr = tw.wr[S], wi = tw.wi[S];
+        asm volatile("" : "+v"(tid), "+v"(wr), "+v"(wi));   // no hoisting of slot numbers / twiddle powers
+        fft8::fwd_stage<N, S>(tid, re, im, wr, wi, lds);
+        if constexpr (S + 1 < fft8::Plan<N>::NS) {
+            __syncthreads();
+            Fwd8<N, S + 1>::run(tid, re, im, tw, lds);
+        }
+    }
+};
+
+template <int N, int MODE, bool LINEAR>
+__global__ __launch_bounds__(N / 8, 4) void spec8_kernel(Spec8Args a) {
+    using fft8::C2;
+    constexpr int NT = N / 8, L = fft8::ilog2(N), NF = N / 2 + 1, NWV = (NT + 63) / 64;
+    extern __shared__ C2 lds8[];
+    __shared__ double red[NWV][4];
+    const int t = threadIdx.x;
+    const int run = blockIdx.x;
+    const int c = blockIdx.y;
+    const double *xr = a.x + (int64_t)c * a.ldx;
+    const int64_t npairs = (a.nseg + 1) / 2;
+    const int64_t p0 = ((int64_t)run * npairs) / a.nruns;
+    const int64_t p1 = ((int64_t)(run + 1) * npairs) / a.nruns;
+    const double mid = 0.5 * (a.nwin - 1);
+    const double s2 = a.scale * a.scale;
+
+    fft8::Twid<N> tw;
+    fft8::twid_load<N>(t, a.tab, tw);
+    double win[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = NT * r + t;
+        const double wv = a.window[i < a.nwin ? i : 0];   // clamped address, no branch
+        win[r] = i < a.nwin ? wv : 0.0;                   // zero padding up to nfft
+    }
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    const bool fullwin = a.nwin == N;
+
+    for (int64_t p = p0; p < p1; ++p) {
+        const int64_t sa = 2 * p, sb = 2 * p + 1;
+        const bool has_b = sb < a.nseg;
+        const int64_t va = sa * (int64_t)a.stride;
+        double re[8], im[8];
+        const double *pa = xr + va + t;
+        if (fullwin) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) re[r] = pa[NT * r];
+            if (has_b) {
+                const double *pb = pa + a.stride;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) im[r] = pb[NT * r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) im[r] = 0.0;
+            }
+        } else {
+            // short window, zero padded to nfft: clamped index, zeros by select
+            const int64_t db = has_b ? a.stride : 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = NT * r + t;
+                const bool in = i < a.nwin;
+                const int ii = in ? NT * r : -t;         // pa[ii] stays inside the segment
+                const double xa = pa[ii], xb = pa[db + ii];
+                re[r] = in ? xa : 0.0;
+                im[r] = (in && has_b) ? xb : 0.0;
+            }
+        }
+        // ---- trend: block sums over the nwin samples (padding holds zeros)
+        double sum_a = 0.0, sum_b = 0.0, lin_a = 0.0, lin_b = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = NT * r + t;
+            sum_a += re[r];
+            sum_b += im[r];
+            if (LINEAR) {
+                lin_a += (i - mid) * re[r];
+                lin_b += (i - mid) * im[r];
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            sum_a += __shfl_down(sum_a, off, 64);
+            sum_b += __shfl_down(sum_b, off, 64);
+            if (LINEAR) {
+                lin_a += __shfl_down(lin_a, off, 64);
+                lin_b += __shfl_down(lin_b, off, 64);
+            }
+        }
+        if ((t & 63) == 0) {
+            red[t >> 6][0] = sum_a;
+            red[t >> 6][1] = sum_b;
+            red[t >> 6][2] = lin_a;
+            red[t >> 6][3] = lin_b;
+        }
+        __syncthreads();   // also: every bin read of the previous pair is done
+        double tot[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) {
+            tot[0] += red[q][0];
+            tot[1] += red[q][1];
+            if (LINEAR) {
+                tot[2] += red[q][2];
+                tot[3] += red[q][3];
+            }
+        }
+        const double mean_a = tot[0] / a.nwin, mean_b = tot[1] / a.nwin;
+        double slope_a = 0.0, slope_b = 0.0;
+        if (LINEAR) {
+            const double nn = (double)a.nwin;
+            const double sxx = nn * (nn * nn - 1.0) / 12.0;
+            slope_a = sxx > 0.0 ? tot[2] / sxx : 0.0;
+            slope_b = sxx > 0.0 ? tot[3] / sxx : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = NT * r + t;
+            if (LINEAR) {
+                re[r] = (re[r] - mean_a - slope_a * (i - mid)) * win[r];
+                im[r] = has_b ? (im[r] - mean_b - slope_b * (i - mid)) * win[r] : 0.0;
+            } else {
+                re[r] = (re[r] - mean_a) * win[r];
+                im[r] = has_b ? (im[r] - mean_b) * win[r] : 0.0;
+            }
+        }
+        // ---- forward transform of a + i b (one barrier per exchange)
+        int tt = t;   // opaque copy: keeps the LDS slot numbers out of loop-invariant registers
+        asm volatile("" : "+v"(tt));
+        Fwd8<N, 0>::run(tt, re, im, tw, lds8);
+        // ---- natural-order exchange: Z[k] of both spectra side by side
+        __syncthreads();   // every read of the last stage is done
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            lds8[fft8::swz_nat(fft8::revdigits<L>(fft8::idx_of<0>(tt, r)))] = C2{re[r], im[r]};
+        __syncthreads();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) {
+            const int k = tt + NT * jj;                // jj = 4: the Nyquist bin, thread 0 only
+            if (jj == 4 && t != 0) continue;
+            const C2 z = lds8[fft8::swz_nat(k)];
+            const C2 q = lds8[fft8::swz_nat((N - k) & (N - 1))];
+            const double ar = 0.5 * (z.re + q.re), ai = 0.5 * (z.im - q.im);
+            const double br = 0.5 * (z.im + q.im), bi = -0.5 * (z.re - q.re);
+            const bool dbl = (k != 0) && (k != N / 2);
+            if (MODE == OSZ_SPEC_DFT_SEGMENTS) {
+                double *o = (double *)a.out;
+                const int64_t ia = ((sa * a.nch + c) * (int64_t)NF + k) * 2;
+                o[ia] = ar * a.scale;
+                o[ia + 1] = ai * a.scale;
+                if (has_b) {
+                    const int64_t ib = ((sb * a.nch + c) * (int64_t)NF + k) * 2;
+                    o[ib] = br * a.scale;
+                    o[ib + 1] = bi * a.scale;
+                }
+            } else {
+                const double f = dbl ? 2.0 * s2 : s2;
+                const double pa = (ar * ar + ai * ai) * f;
+                const double pb = (br * br + bi * bi) * f;
+                if (MODE == OSZ_SPEC_PSD_SEGMENTS) {
+                    double *o = (double *)a.out;
+                    o[(sa * a.nch + c) * (int64_t)NF + k] = pa;
+                    if (has_b) o[(sb * a.nch + c) * (int64_t)NF + k] = pb;
+                } else {
+                    acc[jj] += has_b ? pa + pb : pa;
+                }
+            }
+        }
+    }
+    if (MODE == OSZ_SPEC_PSD_MEAN) {
+        double *o = a.partial + ((int64_t)c * a.nruns + run) * NF;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) o[t + NT * jj] = acc[jj];
+        if (t == 0) o[N / 2] = acc[4];
+    }
+}
+
+// dsum[c][k] += sum over runs of partial[c][run][k] for any nfreq
+__global__ void spec_partial_reduce_n_kernel(const double *partial, double *dsum, int nruns, int nf) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (k >= nf) return;
+    double s = 0.0;
+    for (int r = 0; r < nruns; ++r) s += partial[((int64_t)c * nruns + r) * nf + k];
+    dsum[(int64_t)c * nf + k] += s;
+}
+
+// W_8192^j, j < 1024: one table per device for every transform size of fft8.h
+int get_fft8_table(const double **out) {
+    static std::mutex mu;
+    static std::map<int, double *> per_device;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    OSZ_HIP(hipGetDevice(&dev));
+    double *&tab = per_device[dev];
+    if (!tab) {
+        const long double PI = acosl(-1.0L);
+        std::vector<double> h(2 * fft8::kTabLen);
+        for (int j = 0; j < fft8::kTabLen; ++j) {
+            const long double ang = -2.0L * PI * (long double)j / (long double)fft8::kTabN;
+            h[2 * j] = (double)cosl(ang);
+            h[2 * j + 1] = (double)sinl(ang);
+        }
+        OSZ_HIP(hipMalloc(&tab, h.size() * sizeof(double)));
+        OSZ_HIP(hipMemcpy(tab, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    *out = tab;
+    return OSZ_OK;
+}
+
 }  // namespace osz
 
 using namespace osz;
@@ -387,7 +629,10 @@ struct osz_spec_s {
     void *dwork;
     size_t work_cap;
     std::map<int64_t, rocfft_plan> *plans;  // keyed by batch (rows)
-    bool fused;          // nwin == nfft == 4096: on-chip path
+    bool fused;          // nwin == nfft == 4096: on-chip path (spec_cube_kernel)
+    bool fused8;         // nfft = 512 ... 8192, a power of two: on-chip path (spec8_kernel)
+    const double *tab8;  // twiddle table of fft8.h
+    double *dhead;       // fft8 path: carry ++ head of the chunk, (nch, ncap + nwin)
     double *dpartial;    // fused PSD_MEAN: (nch, nruns_cap, 2049)
     int64_t partial_cap;
     fft::Tables tb;
@@ -413,6 +658,120 @@ static int spec_plan(osz_spec_s *h, int64_t rows, rocfft_plan *out) {
                                (size_t)rows, nullptr));
     (*h->plans)[rows] = plan;
     *out = plan;
+    return OSZ_OK;
+}
+
+
+template <int N>
+static int spec8_launch(osz_spec_s *h, const Spec8Args &a, hipStream_t st) {
+    using kern_t = void (*)(Spec8Args);
+    static const kern_t ks[3][2] = {
+        {spec8_kernel<N, 0, false>, spec8_kernel<N, 0, true>},
+        {spec8_kernel<N, 1, false>, spec8_kernel<N, 1, true>},
+        {spec8_kernel<N, 2, false>, spec8_kernel<N, 2, true>}};
+    const kern_t k = ks[h->mode][h->detrend == OSZ_DETREND_LINEAR ? 1 : 0];
+    const size_t lds = sizeof(fft8::C2) * N;
+    OSZ_DYN_LDS(k, lds);
+    KernelTimer kt("spec_fused", st);
+    hipLaunchKernelGGL(k, dim3((unsigned)a.nruns, h->nch), dim3(N / 8), lds, st, a);
+    return OSZ_OK;
+}
+
+// head[c][0 : ncarry + m] = carry[c][0 : ncarry] ++ x[c][0 : m]
+__global__ void spec_head_kernel(const double *carry, int64_t ncap, int64_t ncarry, const double *x,
+                                 int64_t ldx, int64_t m, double *head, int64_t ldh) {
+    const int c = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncarry + m) return;
+    head[(int64_t)c * ldh + i] = i < ncarry ? carry[(int64_t)c * ncap + i] : x[(int64_t)c * ldx + (i - ncarry)];
+}
+
+// one launch of spec8_kernel over nseg segments of a contiguous source
+static int spec8_run(osz_spec_s *h, const double *src, int64_t ld, void *out, int64_t nseg,
+                     hipStream_t st) {
+    const int64_t npairs = (nseg + 1) / 2;
+    // runs: enough workgroups for a few rounds of the chip, long enough that the
+    // per-run set-up (twiddles, window, partial sums) stays small
+    int64_t R = (npairs * h->nch) / 2048;
+    if (const char *e = getenv("OSZ_SPEC_R")) R = atoi(e);
+    if (R > 64) R = 64;
+    if (R < 1) R = 1;
+    const int64_t nruns = (npairs + R - 1) / R;
+    Spec8Args a{};
+    a.x = src;
+    a.window = h->dwindow;
+    a.out = out;
+    a.tab = h->tab8;
+    a.ldx = ld;
+    a.nseg = nseg;
+    a.stride = h->stride;
+    a.nwin = h->nwin;
+    a.nch = h->nch;
+    a.nruns = (int)nruns;
+    a.scale = h->scale;
+    if (h->mode == OSZ_SPEC_PSD_MEAN) {
+        const int64_t need = (int64_t)h->nch * nruns * h->nfreq;
+        if (need > h->partial_cap) {
+            OSZ_HIP(hipStreamSynchronize(st));
+            (void)hipFree(h->dpartial);
+            h->dpartial = nullptr;
+            if (hipMalloc(&h->dpartial, sizeof(double) * need) != hipSuccess)
+                return fail(OSZ_ERR_NOMEM, "osz_spec_push: partial sums (%lld doubles)", (long long)need);
+            h->partial_cap = need;
+        }
+        a.partial = h->dpartial;
+    }
+    int rc;
+    switch (h->nfft) {
+        case 512: rc = spec8_launch<512>(h, a, st); break;
+        case 1024: rc = spec8_launch<1024>(h, a, st); break;
+        case 2048: rc = spec8_launch<2048>(h, a, st); break;
+        case 4096: rc = spec8_launch<4096>(h, a, st); break;
+        case 8192: rc = spec8_launch<8192>(h, a, st); break;
+        default: return fail(OSZ_ERR_INVALID, "spec8_push: nfft=%d", h->nfft);
+    }
+    if (rc) return rc;
+    OSZ_HIP(hipGetLastError());
+    if (h->mode == OSZ_SPEC_PSD_MEAN) {
+        hipLaunchKernelGGL(spec_partial_reduce_n_kernel, dim3((h->nfreq + 255) / 256, h->nch), dim3(256),
+                           0, st, h->dpartial, h->dsum, (int)nruns, h->nfreq);
+        OSZ_HIP(hipGetLastError());
+    }
+    return OSZ_OK;
+}
+
+// On-chip path for power-of-two nfft in [512, 8192] (spec8_kernel).  The kernel
+// reads ONE contiguous source.  The segments that begin in the carry of the
+// previous push (fewer than nwin / stride + 1 of them) are served from a small
+// head buffer = carry ++ the first nwin samples of the chunk; every other
+// segment lies inside the chunk.
+static int spec8_push(osz_spec_s *h, const double *x, int64_t ldx, int64_t n, void *out,
+                      int64_t nseg, hipStream_t st) {
+    int64_t nhead = h->ncarry > 0 ? (h->ncarry + h->stride - 1) / h->stride : 0;
+    if (nhead > nseg) nhead = nseg;
+    const size_t seg_out = (size_t)h->nch * h->nfreq * (h->mode == OSZ_SPEC_DFT_SEGMENTS ? 2 : 1);
+    if (nhead > 0) {
+        const int64_t ldh = h->ncap + h->nwin;
+        if (!h->dhead) {
+            if (hipMalloc(&h->dhead, sizeof(double) * (size_t)h->nch * ldh) != hipSuccess)
+                return fail(OSZ_ERR_NOMEM, "osz_spec_push: head buffer");
+        }
+        int64_t m = (nhead - 1) * h->stride + h->nwin - h->ncarry;   // chunk samples the head segments need
+        if (m > n) m = n;
+        if (m < 0) m = 0;
+        hipLaunchKernelGGL(spec_head_kernel, dim3((unsigned)((h->ncarry + m + 255) / 256), h->nch), dim3(256),
+                           0, st, h->dcarry[h->cur], h->ncap, h->ncarry, x, ldx, m, h->dhead, ldh);
+        OSZ_HIP(hipGetLastError());
+        int rc = spec8_run(h, h->dhead, ldh, out, nhead, st);
+        if (rc) return rc;
+    }
+    if (nseg > nhead) {
+        // segment nhead starts at virtual sample nhead * stride >= ncarry
+        const int64_t off = nhead * (int64_t)h->stride - h->ncarry;
+        void *o = out ? (void *)((double *)out + (size_t)nhead * seg_out) : nullptr;
+        int rc = spec8_run(h, x + off, ldx, o, nseg - nhead, st);
+        if (rc) return rc;
+    }
     return OSZ_OK;
 }
 
@@ -453,8 +812,20 @@ int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride, const double 
     {
         const char *e = getenv("OSZ_SPEC_FUSED");
         p->fused = (nwin == fft::N && nfft == fft::N) && !(e && atoi(e) == 0);
+        // OSZ_SPEC_V8: 0 = never the fft8 path, 2 = also for nwin == nfft == 4096
+        const char *e8 = getenv("OSZ_SPEC_V8");
+        const int v8 = e8 ? atoi(e8) : 1;
+        const bool pow2 = nfft >= 512 && nfft <= 8192 && (nfft & (nfft - 1)) == 0;
+        p->fused8 = pow2 && v8 != 0 && (!p->fused || v8 == 2);
+        if (p->fused8) p->fused = false;
+        p->tab8 = nullptr;
+        p->dhead = nullptr;
         if (p->fused) {
             int rc = get_fft_tables(p->tb);
+            if (rc) { delete p->plans; delete p; return rc; }
+        }
+        if (p->fused8) {
+            int rc = get_fft8_table(&p->tab8);
             if (rc) { delete p->plans; delete p; return rc; }
         }
     }
@@ -484,6 +855,7 @@ int osz_spec_destroy(osz_spec_t h) {
     (void)hipFree(h->dspec);
     (void)hipFree(h->dwork);
     (void)hipFree(h->dpartial);
+    (void)hipFree(h->dhead);
     delete h;
     return OSZ_OK;
 }
@@ -512,7 +884,11 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
     const int64_t total = h->ncarry + n;
     const int64_t nseg = osz_spec_seg_count(h, n);
     OSZ_REQUIRE(nseg == 0 || h->mode == OSZ_SPEC_PSD_MEAN || out, "osz_spec_push: null output");
-    if (nseg > 0 && h->fused) {
+    if (nseg > 0 && h->fused8) {
+        int rc = spec8_push(h, x, ldx, n, out, nseg, st);
+        if (rc) return rc;
+        h->count += nseg;
+    } else if (nseg > 0 && h->fused) {
         const int64_t npairs = (nseg + 1) / 2;
         // run length: long runs (a workgroup reloads its twiddles and window and
         // publishes partial sums once per run) while ~512 workgroups remain

@@ -18,3 +18,18 @@ def test_fft4096_host_replay():
         out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK" in out.stdout
+
+
+def test_fft8_host_replay():
+    """fft8.h (N = 512 ... 8192, 8 points per thread): forward against a naive
+    long-double DFT, inverse(forward) = N x, the digit-reversal map, the LDS
+    swizzles are bijections and every stage access is bank-conflict free for the
+    lane groups of MI355X_MICROARCH.md."""
+    src = os.path.join(ROOT, "tests", "host", "fft8_host_check.cpp")
+    inc = os.path.join(ROOT, "openseize_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "fft8_host_check")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", inc, src, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("worst_bank_ways=1") == 5
