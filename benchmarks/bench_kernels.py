@@ -64,6 +64,13 @@ def main():
                     "ms_per_chunk": dt * 1e3, "Msamples_s": CH * N / dt / 1e6,
                     "algorithmic_GBps": 8 * CH * N / dt / 1e9})
         sp8.close()
+    xs8 = x[:, : 1 << 18].contiguous()
+    st8 = dev.SpecStream(nfft, nfft, nfft // 2, w, scale, "constant", _lib.SPEC_DFT_SEGMENTS, CH)
+    dt = timed(lambda: st8.push(xs8), 5)
+    out.append({"workload": "cfg-5 STFT 256 ch x 2^18, nfft 4096, 50 % (fft8 kernel)",
+                "ms_per_chunk": dt * 1e3, "Msamples_s": CH * xs8.shape[1] / dt / 1e6,
+                "algorithmic_GBps": 24 * CH * xs8.shape[1] / dt / 1e9})
+    st8.close()
     os.environ.pop("OSZ_SPEC_V8")
 
     # cfg-5 part 1: polyphase downsample 5 -> 1, default Kaiser (113 taps)
