@@ -46,7 +46,7 @@ struct osz_sos_s {
     double *dcarry;     // device (nsec, nch, 2): state between the main and remainder launches
     double *dzi;        // device (nsec, 2): sosfilt_zi of this cascade
     int touch;          // tuning knob OSZ_SOS_TOUCH: touch-prefetch of the next tile
-    double *dtab2;      // device [nsec][4][65]: A^(T k) per section for sos_body2, or null
+    double *dtab2;      // device [nsec][4][66]: A^(T k) per section for sos_body2, or null
 };
 
 namespace osz {

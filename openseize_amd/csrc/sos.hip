@@ -42,7 +42,7 @@ struct SosArgs {
     const double *zi_unit;   // (nsec, 2); used when state_in is null
     double *state_out;       // (nsec, nch, 2) or null
     int nsec, nch;
-    const double *tab2;      // per-lane scan matrices for sos_body2 ([nsec][4][65]) or null
+    const double *tab2;      // per-lane scan matrices for sos_body2 ([nsec][4][66]) or null
     int touch;               // sos_body2: touch-prefetch the next tile's window
 };
 
@@ -459,10 +459,11 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
 //   * whole tiles only (n is a multiple of NW * 64 * T), state_out from LDS.
 // Same arithmetic per sample; results agree with sos_body to rounding.
 constexpr int kSos2MaxSec = 8;                 // sections whose tables fit beside 3 workgroups per CU
-constexpr int kSos2Tab = 65;                   // A^(T k), k = 0 .. 64
+constexpr int kSos2Tab = 66;                   // A^(T k), k = 0 .. 64, then one all-zero entry
+constexpr int kSos2Zero = 65;
 
 struct Sos2Lds {
-    // doubles: staging NW * 64 * (T/2 + 1) | tables nsec * 4 * 65 | agg 2 * NW * 2 | sst 2 * 32 * 2
+    // doubles: staging NW * 64 * (T/2 + 1) | tables nsec * 4 * 66 | agg 2 * NW * 2 | sst 2 * 32 * 2
     static __host__ __device__ constexpr int stage(int T, int NW) { return NW * 64 * (T / 2 + 1); }
     static __host__ __device__ constexpr size_t bytes(int T, int NW, int nsec) {
         return sizeof(double) * ((size_t)stage(T, NW) + (size_t)nsec * 4 * kSos2Tab + 2 * NW * 2 +
@@ -470,27 +471,25 @@ struct Sos2Lds {
     }
 };
 
-// lane i <- value of lane 15 of the previous row, rows 1 and 3 only (others get 0)
-__device__ __forceinline__ double dpp_bcast15(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+// DPP moves with bound_ctrl (lanes without a source read 0) and no `old`
+// operand: nothing to initialise in front of them.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov0(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
-// lanes 32..63 <- value of lane 31 (others get 0)
-__device__ __forceinline__ double dpp_bcast31(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
+// lane i <- lane i - D inside its 16-lane row, 0 for the first D lanes
+template <int D>
+__device__ __forceinline__ double dpp_row_shr0(double v) { return dpp_mov0<0x110 + D>(v); }
+// lane i <- lane 15 of the previous row.  Measured (benchmarks/dpp_probe.hip):
+// the lanes of row 0 have no source and keep THEIR OWN value, bound_ctrl or
+// not -- the scan multiplies what rows 0 and 2 receive by an all-zero matrix.
+__device__ __forceinline__ double dpp_bcast15(double v) { return dpp_mov0<0x142>(v); }
+// lanes 32..63 <- lane 31; lanes 0..31 keep their own value (zero matrix again)
+__device__ __forceinline__ double dpp_bcast31(double v) { return dpp_mov0<0x143>(v); }
 // lane i <- lane i - 1 across the whole wave, 0 into lane 0
-__device__ __forceinline__ double dpp_wave_shr1(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
+__device__ __forceinline__ double dpp_wave_shr1(double v) { return dpp_mov0<0x138>(v); }
 
 template <int T, int NW, bool REV, bool AL16, bool PF>
 __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__restrict__ sec,
@@ -502,7 +501,7 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
     constexpr int WAVE_ELEMS = 64 * T;
     extern __shared__ double lds[];
     double *tile = lds;                                        // NW * 64 * ROWH
-    double *tab = tile + Sos2Lds::stage(T, NW);                // [nsec][4][65]
+    double *tab = tile + Sos2Lds::stage(T, NW);                // [nsec][4][66]
     double *agg = tab + a.nsec * 4 * kSos2Tab;                 // [2][NW][2]
     double *sst = agg + 2 * NW * 2;                            // [2][kSosMaxSec][2]
     int *dump = reinterpret_cast<int *>(sst + 2 * kSosMaxSec * 2);   // [NW][64] touch-prefetch sink
@@ -648,38 +647,38 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
             // kernel does not have at three workgroups per CU)
             int ll = l;
             asm volatile("" : "+v"(ll));
-            const int ka = (ll & 15) + 1, kb = ll >= 32 ? ll - 31 : 0, kc = ll;
+            const int ka = (ll & 16) ? (ll & 15) + 1 : kSos2Zero, kb = ll >= 32 ? ll - 31 : kSos2Zero, kc = ll;
             const double *ts = tab + s * 4 * kSos2Tab;
             const double ma0 = ts[0 * kSos2Tab + ka], ma1 = ts[1 * kSos2Tab + ka];
             const double ma2 = ts[2 * kSos2Tab + ka], ma3 = ts[3 * kSos2Tab + ka];
-            // 1. inclusive scan inside 16-lane rows (constant matrices A^(T 2^k))
+            // 1. inclusive scan inside 16-lane rows (constant matrices A^(T 2^k)),
+            // every step e += M u as two chained FMAs per component
             double e0 = z0, e1 = z1;
-#define OSZ_SCAN_STEP(K, D)                                   \
-    {                                                         \
-        const double u0 = row_shr<D>(e0), u1 = row_shr<D>(e1); \
-        double r0, r1;                                        \
-        mat2_apply(S->P[K], u0, u1, r0, r1);                  \
-        e0 += r0;                                             \
-        e1 += r1;                                             \
+#define OSZ_SCAN_STEP(K, D)                                             \
+    {                                                                   \
+        const double u0 = dpp_row_shr0<D>(e0), u1 = dpp_row_shr0<D>(e1); \
+        e0 = fma(S->P[K][0], u0, fma(S->P[K][1], u1, e0));              \
+        e1 = fma(S->P[K][2], u0, fma(S->P[K][3], u1, e1));              \
     }
             OSZ_SCAN_STEP(0, 1)
             OSZ_SCAN_STEP(1, 2)
             OSZ_SCAN_STEP(2, 4)
             OSZ_SCAN_STEP(3, 8)
 #undef OSZ_SCAN_STEP
-            // 2. rows 1, 3 take the total of the row before them ...
+            // 2. rows 1, 3 take the total of the row before them (rows 0 and 2 read
+            // the all-zero table entry: the broadcast reaches them too) ...
             {
                 const double u0 = dpp_bcast15(e0), u1 = dpp_bcast15(e1);
-                e0 += fma(ma0, u0, ma1 * u1);
-                e1 += fma(ma2, u0, ma3 * u1);
+                e0 = fma(ma0, u0, fma(ma1, u1, e0));
+                e1 = fma(ma2, u0, fma(ma3, u1, e1));
             }
             // ... and lanes 32..63 the total of lanes 0..31: inclusive over the wave
             {
                 const double mb0 = ts[0 * kSos2Tab + kb], mb1 = ts[1 * kSos2Tab + kb];
                 const double mb2 = ts[2 * kSos2Tab + kb], mb3 = ts[3 * kSos2Tab + kb];
                 const double u0 = dpp_bcast31(e0), u1 = dpp_bcast31(e1);
-                e0 += fma(mb0, u0, mb1 * u1);
-                e1 += fma(mb2, u0, mb3 * u1);
+                e0 = fma(mb0, u0, fma(mb1, u1, e0));
+                e1 = fma(mb2, u0, fma(mb3, u1, e1));
             }
             if (l == 63) {
                 agg[(aggbuf * NW + w) * 2 + 0] = e0;
@@ -699,10 +698,11 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
                     sw0 = s0;
                     sw1 = s1;
                 }
-                double r0, r1;
-                mat2_apply(S->Q, s0, s1, r0, r1);
-                s0 = r0 + agg[(aggbuf * NW + q) * 2 + 0];
-                s1 = r1 + agg[(aggbuf * NW + q) * 2 + 1];
+                const double g0 = agg[(aggbuf * NW + q) * 2 + 0], g1 = agg[(aggbuf * NW + q) * 2 + 1];
+                const double r0 = fma(S->Q[0], s0, fma(S->Q[1], s1, g0));
+                const double r1 = fma(S->Q[2], s0, fma(S->Q[3], s1, g1));
+                s0 = r0;
+                s1 = r1;
             }
             if (threadIdx.x == 0) {
                 sst[((parity ^ 1) * kSosMaxSec + s) * 2 + 0] = s0;
@@ -1021,17 +1021,18 @@ static int64_t sos_warmup_len(const std::vector<SosSection> &secs, int64_t quant
     return cap;
 }
 
-// A^(T k), k = 0 .. 64, per section, element-major ([sec][4][65]) for sos_body2
+// A^(T k), k = 0 .. 64, per section, element-major ([sec][4][66]) for sos_body2
 static void build_lane_table(const double *c, int T, double *out) {
     const double a0 = c[3];
     const ld_t A[4] = {-(ld_t)(c[4] / a0), 1.0L, -(ld_t)(c[5] / a0), 0.0L};
     ld_t AT[4] = {1, 0, 0, 1};
     for (int j = 0; j < T; ++j) mat2_mul(A, AT, AT);
     ld_t M[4] = {1, 0, 0, 1};
-    for (int k = 0; k < kSos2Tab; ++k) {
+    for (int k = 0; k < kSos2Zero; ++k) {
         for (int e = 0; e < 4; ++e) out[e * kSos2Tab + k] = (double)M[e];
         mat2_mul(AT, M, M);
     }
+    for (int e = 0; e < 4; ++e) out[e * kSos2Tab + kSos2Zero] = 0.0;
 }
 
 int sos_tables_for(osz_sos_s *h, int T, const SosSection **dsec) {
