@@ -566,22 +566,28 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
         double v[T];
         // ---- HBM -> LDS -> lane blocks, two column halves; the first half was
         // requested a tile ago (below) and is in `pf` by now
+        // both halves are requested before the first one is staged: the second
+        // half's latency hides behind the first half's trip through LDS (the
+        // lane blocks are still empty here, the registers are there)
+        double pf1[HC];
+        if (!PF) request_half(pf, mem_base, 0);
+        request_half(pf1, mem_base, 1);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            if (hh == 1 || !PF) request_half(pf, mem_base, hh);
+            const double *src = hh == 0 ? pf : pf1;
             if (al16) {
                 // lane l, step i: row 8 i + (l >> 3), columns 16 hh + 2 (l & 7) + {0, 1}
                 double *st = wl + (l >> 3) * ROWH + 2 * (l & 7);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    st[i * 8 * ROWH] = pf[2 * i];
-                    st[i * 8 * ROWH + 1] = pf[2 * i + 1];
+                    st[i * 8 * ROWH] = src[2 * i];
+                    st[i * 8 * ROWH + 1] = src[2 * i + 1];
                 }
             } else {
                 // 8 bytes per lane: row 4 i + (l >> 4), column 16 hh + (l & 15)
                 double *st = wl + (l >> 4) * ROWH + (l & 15);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) st[i * 4 * ROWH] = pf[i];
+                for (int i = 0; i < 16; ++i) st[i * 4 * ROWH] = src[i];
             }
             wave_lds_fence();
             const double *blk = wl + myrow * ROWH;
