@@ -8,23 +8,31 @@ import scipy.signal as sps
 from openseize_amd.filtering.bases import FIR
 
 
+def _make_odd(count):
+    """Type I filters (odd length) only: an even count gains one tap."""
+    return count | 1
+
+
 class Kaiser(FIR):
     """Kaiser-window FIR; tap count and beta from the stricter of the pass
     and stop band attenuations (filtering/fir.py:52-137)."""
 
     def __init__(self, fpass, fstop, fs, gpass=1.0, gstop=40.0):
-        super().__init__(fpass, fstop, gpass, gstop, fs)
+        FIR.__init__(self, fpass, fstop, gpass, gstop, fs)
+
+    @property
+    def _design_attenuation(self):
+        """The stricter of the two band specifications, in dB."""
+        return max(self.pass_attenuation, self.gstop)
 
     @property
     def numtaps(self):
-        ripple = max(self.pass_attenuation, self.gstop)
-        ntaps, _ = sps.kaiserord(ripple, self.width / self.nyq)
-        return ntaps + 1 if ntaps % 2 == 0 else ntaps
+        count = sps.kaiserord(self._design_attenuation, self.width / self.nyq)[0]
+        return _make_odd(count)
 
     @property
     def window_params(self):
-        ripple = max(self.pass_attenuation, self.gstop)
-        return [sps.kaiser_beta(ripple)]
+        return [sps.kaiser_beta(self._design_attenuation)]
 
 
 class _FixedWindow(FIR):
@@ -39,8 +47,7 @@ class _FixedWindow(FIR):
 
     @property
     def numtaps(self):
-        ntaps = int(self._factor / (self.width / self.nyq))
-        return ntaps + 1 if ntaps % 2 == 0 else ntaps
+        return _make_odd(int(self._factor / (self.width / self.nyq)))
 
 
 class Rectangular(_FixedWindow):

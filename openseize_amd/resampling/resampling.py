@@ -15,39 +15,37 @@ from openseize_amd.filtering.fir import Kaiser
 
 
 def resampled_shape(pro, L, M, axis):
-    """ceil(N * L / M) along axis (resampling/resampling.py:72-92)."""
-    shape = list(pro.shape)
-    shape[axis] = int(np.ceil(pro.shape[axis] * L / M))
-    return tuple(shape)
+    """The producer's shape with ceil(N * L / M) samples along axis
+    (resampling/resampling.py:72-92), in exact integer arithmetic."""
+    dims = list(pro.shape)
+    dims[axis] = -((-int(dims[axis]) * int(L)) // int(M))
+    return tuple(dims)
 
 
-def _run(data, L, M, shape_LM, fs, chunksize, axis, kwargs):
-    pro = producer(data, chunksize, axis)
-    genfunc = partial(polyphase_resample, pro, L, M, fs, Kaiser, axis, **kwargs)
-    shape = resampled_shape(pro, L=shape_LM[0], M=shape_LM[1], axis=axis)
-    result = producer(genfunc, chunksize, axis, shape=shape)
-    return result.to_array() if dev.is_arraylike(data) else result
+def _rate_change(data, up, down, fs, chunksize, axis, kwargs):
+    """up / down (already in lowest terms, not 1 / 1) through the device
+    polyphase generator: array in -> array out, producer in -> producer out."""
+    source = producer(data, chunksize, axis)
+    stage = partial(polyphase_resample, source, up, down, fs, Kaiser, axis, **kwargs)
+    out = producer(stage, chunksize, axis, shape=resampled_shape(source, up, down, axis))
+    return out.to_array() if dev.is_arraylike(data) else out
+
+
+def resample(data, L, M, fs, chunksize, axis=-1, **kwargs):
+    """Rational L/M resampling (resampling/resampling.py:233-311): the ratio is
+    reduced to lowest terms; an identity ratio returns the input itself."""
+    common = int(np.gcd(L, M))
+    up, down = int(L) // common, int(M) // common
+    if (up, down) == (1, 1):
+        return data
+    return _rate_change(data, up, down, fs, chunksize, axis, kwargs)
 
 
 def downsample(data, M, fs, chunksize, axis=-1, **kwargs):
     """Polyphase decimation by M (resampling/resampling.py:95-161)."""
-    if M == 1:
-        return data
-    return _run(data, 1, M, (1, M), fs, chunksize, axis, kwargs)
+    return resample(data, 1, M, fs, chunksize, axis, **kwargs)
 
 
 def upsample(data, L, fs, chunksize, axis=-1, **kwargs):
     """Polyphase expansion by L (resampling/resampling.py:164-230)."""
-    if L == 1:
-        return data
-    return _run(data, L, 1, (L, 1), fs, chunksize, axis, kwargs)
-
-
-def resample(data, L, M, fs, chunksize, axis=-1, **kwargs):
-    """Rational L/M resampling, L and M reduced by their gcd
-    (resampling/resampling.py:233-311)."""
-    g = np.gcd(L, M)
-    l, m = L // g, M // g
-    if l == m == 1:
-        return data
-    return _run(data, int(l), int(m), (L, M), fs, chunksize, axis, kwargs)
+    return resample(data, L, 1, fs, chunksize, axis, **kwargs)
