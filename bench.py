@@ -53,8 +53,9 @@ NTAPS = 1024
 NFFT = 4096              # cfg-4: nperseg 4096 (fs 4096, resolution 1.0), 50 % overlap
 RAGGED = 100_000_000 - 95 * CHUNK     # last chunk of the literal 1e8-sample stream
 # algorithmic HBM bytes per channel-sample of one launch
-KERNEL_BYTES = {"fir_oa": 16, "sos_dual": 32, "sos_fwd": 16, "sos_bwd": 16,
-                "sos_warmup": 0, "fir_seam": 0, "spec_fused": 8}
+KERNEL_BYTES = {"fir_oa": 16, "sos_dual": 32, "sos_fwd": 16, "sos_bwd": 16, "sos_fwd_split": 16,
+                "sos_bwd_split": 16, "chain_fwd": 16, "sos_warmup": 0, "fir_seam": 0,
+                "spec_fused": 8}
 CHAIN_BYTES = 48         # FIR 16 + sosfiltfilt 32 (unfused)
 METRIC = "Msamples/sec/node (FIR+IIR chain, 256ch f64); HBM GB/s vs roofline at 1/2/4/8 GPU"
 
@@ -244,6 +245,13 @@ def run_chain(args, R, h, sos):
     y_out = torch.empty_like(fir_out)
 
     def step(k):
+        if args.fused:
+            # FIR + forward SOS of chunk k in ONE kernel (osz_chain_forward: the FIR
+            # output never reaches HBM), then the backward pass of chunk k-2
+            dev.chain_forward(fir, iir, ring[k % len(ring)], out=fwd[k % 3])
+            if k >= 2:
+                iir.backward(fwd[(k - 2) % 3], fwd[(k - 1) % 3], out=y_out)
+            return
         # chunk k: FIR, then ONE launch = forward(chunk k) + backward(chunk
         # k-2, warmed up over forward chunk k-1)  [osz_sosfiltfilt_step]
         fir.push(ring[k % len(ring)], 0, out=fir_out)
@@ -424,6 +432,9 @@ def main():
                     help="welch: all-reduce through torch.distributed (RCCL) or through "
                          "osz_welch_reduce of the C ABI")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--fused", action="store_true",
+                    help="chain: FIR + forward SOS as one kernel (osz_chain_forward) and a "
+                         "separate backward pass, 32 instead of 48 B per sample")
     ap.add_argument("--full-stream", action="store_true",
                     help="chain: also time the literal 96-chunk (1e8-sample) stream once "
                          "through the public producer API")

@@ -36,11 +36,12 @@ struct ChainArgs {
     double *fir_state_out;
     const double *sos_state_in;  // (nsec, nch, 2)
     double *sos_state_out;
+    const double *lane_tab;      // [nsec][4][kSos2Tab] for T = 2 NR, or null (first scan variant)
     int64_t npairs;              // whole pairs of blocks in this call
     int nruns, pre_pairs;
 };
 
-template <int NR>
+template <int NR, bool V2>
 __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs g,
                                                        const SosSection *__restrict__ sec) {
     constexpr int T = 2 * NR;        // samples per lane of the SOS tile: one pair = one tile
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs g,
     double *tile = reinterpret_cast<double *>(cube_lds);   // 256 * PITCH doubles, over the idle cube
     double *agg = tile + 2 * fft::cube::SLOTS;             // [2][4][2] wave aggregates
     double *sst = agg + 2 * 4 * 2;                         // [2][kSosMaxSec][2] tile start states
+    double *ltab = sst + 2 * kSosMaxSec * 2;               // [nsec][4][kSos2Tab] lane tables (if any)
     const FirArgs &a = g.f;
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
     const int w = t >> 6, l = t & 63;
@@ -72,6 +74,8 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs g,
         const int p = 256 * j + t;
         P.cr[j] = (run == 0 && p < wm1) ? g.fir_state_in[(int64_t)c * wm1 + p] : 0.0;
     }
+    if (V2)
+        for (int i = t; i < g.nsec * 4 * kSos2Tab; i += 256) ltab[i] = g.lane_tab[i];
     if (t < g.nsec) {
         sst[(0 * kSosMaxSec + t) * 2 + 0] = run == 0 ? g.sos_state_in[((int64_t)t * gridDim.y + c) * 2 + 0] : 0.0;
         sst[(0 * kSosMaxSec + t) * 2 + 1] = run == 0 ? g.sos_state_in[((int64_t)t * gridDim.y + c) * 2 + 1] : 0.0;
@@ -121,7 +125,10 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs g,
             for (int k = 0; k < T; ++k) v[k] = blk[k];
         }
         // one tile of the forward cascade; its first barrier also ends the block reads
-        sos_tile_full<T, 4>(v, sec, g.nsec, sst, agg, parity, aggbuf, w, l);
+        if (V2)
+            sos_tile_full2<T, 4>(v, sec, ltab, g.nsec, sst, agg, parity, aggbuf, w, l);
+        else
+            sos_tile_full<T, 4>(v, sec, g.nsec, sst, agg, parity, aggbuf, w, l);
         if (p >= p0) {
             double *blk = tile + PITCH * t;
 #pragma unroll
@@ -184,6 +191,11 @@ int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
             const SosSection *dsec = nullptr;
             int rc = sos_tables_for(sos, 2 * nr, &dsec);
             if (rc) return rc;
+            const double *ltab = nullptr;
+            if (!(getenv("OSZ_CHAIN_V2") && atoi(getenv("OSZ_CHAIN_V2")) == 0)) {
+                rc = sos_lane_table_for(sos, 2 * nr, &ltab);
+                if (rc) return rc;
+            }
             ChainArgs g{};
             g.f.x = x;
             g.f.y = f;
@@ -200,15 +212,23 @@ int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
             g.fir_state_out = pt.dstate[pt.cur ^ 1];
             g.sos_state_in = sos->dstate;
             g.sos_state_out = sos->dstate_alt;
+            g.lane_tab = ltab;
             g.npairs = npairs;
             g.nruns = (int)nruns;
             g.pre_pairs = (int)pre;
             using kern_t = void (*)(ChainArgs, const SosSection *);
-            static const kern_t kerns[8] = {chain_kernel<8>,  chain_kernel<9>,  chain_kernel<10>,
-                                            chain_kernel<11>, chain_kernel<12>, chain_kernel<13>,
-                                            chain_kernel<14>, chain_kernel<15>};
+            static const kern_t kerns1[8] = {chain_kernel<8, false>,  chain_kernel<9, false>,
+                                             chain_kernel<10, false>, chain_kernel<11, false>,
+                                             chain_kernel<12, false>, chain_kernel<13, false>,
+                                             chain_kernel<14, false>, chain_kernel<15, false>};
+            static const kern_t kerns2[8] = {chain_kernel<8, true>,  chain_kernel<9, true>,
+                                             chain_kernel<10, true>, chain_kernel<11, true>,
+                                             chain_kernel<12, true>, chain_kernel<13, true>,
+                                             chain_kernel<14, true>, chain_kernel<15, true>};
+            const kern_t *kerns = ltab ? kerns2 : kerns1;
             const size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS +
-                               sizeof(double) * (2 * 4 * 2 + 2 * kSosMaxSec * 2);
+                               sizeof(double) * (2 * 4 * 2 + 2 * kSosMaxSec * 2) +
+                               (ltab ? sizeof(double) * (size_t)sos->nsec * 4 * kSos2Tab : 0);
             OSZ_DYN_LDS(kerns[nr - 8], lds);
             {
                 KernelTimer kt("chain_fwd", st);

@@ -37,6 +37,7 @@ struct osz_sos_s {
     int nsec, nch;
     osz::SosSection *dsec;   // device, built for T samples per lane
     osz::SosSection *dsec_t[33];   // tables for other tile geometries (index = T), lazily built
+    double *dtab2_t[33];           // lane tables A^(T k) for other T ([nsec][4][66]), lazily built
     double coef[osz::kSosMaxSec * 6];   // host copy of the sections (b0 b1 b2 1 a1 a2)
     double *dstate;     // device (nsec, nch, 2): carried forward state (current)
     double *dstate_alt; // the other half of the ping-pong: a forward pass reads dstate and
@@ -55,4 +56,8 @@ int get_fft_tables(fft::Tables &out);
 // per-section tables of a cascade for a tile of T samples per lane, built on
 // first use and owned by the handle (sos.hip)
 int sos_tables_for(osz_sos_s *h, int T, const SosSection **dsec);
+// per-lane scan matrices A^(T k) ([nsec][4][kSos2Tab]) for a tile of T samples per
+// lane (sos_tile_full2), built on first use and owned by the handle; *dtab = null
+// when the cascade has more sections than the LDS table holds
+int sos_lane_table_for(osz_sos_s *h, int T, const double **dtab);
 }  // namespace osz

@@ -44,6 +44,11 @@ struct SosArgs {
     int nsec, nch;
     const double *tab2;      // per-lane scan matrices for sos_body2 ([nsec][4][66]) or null
     int touch;               // sos_body2: touch-prefetch the next tile's window
+    // sos_body2: rows processed BEFORE x, outputs discarded -- the chunk-local
+    // warm-up of sosfiltfilt (numerical.py:397-399) as a pre-roll of the
+    // backward pass instead of a launch of its own; npre a whole number of tiles
+    const double *prex;
+    int64_t ldprex, npre;
 };
 
 // In-kernel phase stamps for the diagnostic build only
@@ -458,10 +463,6 @@ __device__ __forceinline__ void sos_body(const SosArgs &a, const SosSection *__r
 //     register copies behind it; the staging buffer keeps its size;
 //   * whole tiles only (n is a multiple of NW * 64 * T), state_out from LDS.
 // Same arithmetic per sample; results agree with sos_body to rounding.
-constexpr int kSos2MaxSec = 8;                 // sections whose tables fit beside 3 workgroups per CU
-constexpr int kSos2Tab = 66;                   // A^(T k), k = 0 .. 64, then one all-zero entry
-constexpr int kSos2Zero = 65;
-
 struct Sos2Lds {
     // doubles: staging NW * 64 * (T/2 + 1) | tables nsec * 4 * 66 | agg 2 * NW * 2 | sst 2 * 32 * 2
     static __host__ __device__ constexpr int stage(int T, int NW) { return NW * 64 * (T / 2 + 1); }
@@ -470,26 +471,6 @@ struct Sos2Lds {
                                  2 * kSosMaxSec * 2) + sizeof(int) * NW * 64;
     }
 };
-
-// DPP moves with bound_ctrl (lanes without a source read 0) and no `old`
-// operand: nothing to initialise in front of them.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov0(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-// lane i <- lane i - D inside its 16-lane row, 0 for the first D lanes
-template <int D>
-__device__ __forceinline__ double dpp_row_shr0(double v) { return dpp_mov0<0x110 + D>(v); }
-// lane i <- lane 15 of the previous row.  Measured (benchmarks/dpp_probe.hip):
-// the lanes of row 0 have no source and keep THEIR OWN value, bound_ctrl or
-// not -- the scan multiplies what rows 0 and 2 receive by an all-zero matrix.
-__device__ __forceinline__ double dpp_bcast15(double v) { return dpp_mov0<0x142>(v); }
-// lanes 32..63 <- lane 31; lanes 0..31 keep their own value (zero matrix again)
-__device__ __forceinline__ double dpp_bcast31(double v) { return dpp_mov0<0x143>(v); }
-// lane i <- lane i - 1 across the whole wave, 0 into lane 0
-__device__ __forceinline__ double dpp_wave_shr1(double v) { return dpp_mov0<0x138>(v); }
 
 template <int T, int NW, bool REV, bool AL16, bool PF>
 __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__restrict__ sec,
@@ -523,7 +504,8 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
             z0 = a.state_in[((int64_t)s * a.nch + c) * 2 + 0];
             z1 = a.state_in[((int64_t)s * a.nch + c) * 2 + 1];
         } else {
-            const double x0 = xrow[REV ? n - 1 : 0];
+            const double x0 = a.prex ? a.prex[(int64_t)c * a.ldprex + (REV ? a.npre - 1 : 0)]
+                                     : xrow[REV ? n - 1 : 0];
             z0 = a.zi_unit[2 * s + 0] * x0;
             z1 = a.zi_unit[2 * s + 1] * x0;
         }
@@ -541,8 +523,8 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
     constexpr bool al16 = AL16;
     // 16 doubles of one column half of a wave window, HBM -> registers
     double pf[HC];
-    auto request_half = [&](double *dstv, int64_t base, int hh) {
-        const double *src = xrow + base;
+    auto request_half = [&](double *dstv, const double *rowp, int64_t base, int hh) {
+        const double *src = rowp + base;
         if (al16) {
             const double2 *p2 = reinterpret_cast<const double2 *>(src + (l >> 3) * T + HC * hh) + (l & 7);
 #pragma unroll
@@ -558,11 +540,16 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
         }
     };
     if (PF && n >= (int64_t)NW * WAVE_ELEMS)
-        request_half(pf, REV ? (n - (int64_t)w * WAVE_ELEMS - WAVE_ELEMS) : (int64_t)w * WAVE_ELEMS, 0);
+        request_half(pf, xrow, REV ? (n - (int64_t)w * WAVE_ELEMS - WAVE_ELEMS) : (int64_t)w * WAVE_ELEMS, 0);
+    const double *prow = (!PF && a.prex) ? a.prex + (int64_t)c * a.ldprex : nullptr;
+    const int64_t pre_tiles = prow ? a.npre / tile_elems : 0;
 
-    for (int64_t t = 0; t < ntiles; ++t) {
+    for (int64_t tall = 0; tall < pre_tiles + ntiles; ++tall) {
+        const bool pre = tall < pre_tiles;                      // a pre-roll tile: no output
+        const int64_t t = pre ? tall : tall - pre_tiles;
         const int64_t pw = t * tile_elems + (int64_t)w * WAVE_ELEMS;
-        const int64_t mem_base = REV ? (n - pw - WAVE_ELEMS) : pw;
+        const int64_t mem_base = REV ? ((pre ? a.npre : n) - pw - WAVE_ELEMS) : pw;
+        const double *srow = pre ? prow : xrow;
         double v[T];
         // ---- HBM -> LDS -> lane blocks, two column halves; the first half was
         // requested a tile ago (below) and is in `pf` by now
@@ -570,8 +557,8 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
         // half's latency hides behind the first half's trip through LDS (the
         // lane blocks are still empty here, the registers are there)
         double pf1[HC];
-        if (!PF) request_half(pf, mem_base, 0);
-        request_half(pf1, mem_base, 1);
+        if (!PF) request_half(pf, srow, mem_base, 0);
+        request_half(pf1, srow, mem_base, 1);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const double *src = hh == 0 ? pf : pf1;
@@ -599,7 +586,7 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
         // Touch the next tile's window (one dword per 128-byte line, two loads per
         // lane = all 128 lines of the 16 KB) so that it is on its way into L2 /
         // the Infinity Cache while this tile computes.
-        if (a.touch && t + 1 < ntiles) {
+        if (a.touch && !pre && t + 1 < ntiles) {
             const int64_t nb = REV ? (mem_base - tile_elems) : (mem_base + tile_elems);
             const int *pn = reinterpret_cast<const int *>(xrow + nb) + l * 32;
             // LDS-DMA into a 256-byte dump area of this wave: no destination
@@ -737,7 +724,7 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
         // next tile's first half is requested (the 32 registers the first half
         // of the outputs just left): it lands while the second half is staged
         // out -- the section loop has no registers to spare, this code does.
-        const bool store = yrow && t >= skip_store_tiles;
+        const bool store = yrow && !pre && t >= skip_store_tiles;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             if (store) {
@@ -766,7 +753,7 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
             }
             __builtin_amdgcn_sched_barrier(0);
             if (PF && hh == 0 && t + 1 < ntiles)
-                request_half(pf, REV ? (mem_base - tile_elems) : (mem_base + tile_elems), 0);
+                request_half(pf, xrow, REV ? (mem_base - tile_elems) : (mem_base + tile_elems), 0);
         }
     }
     // carried state of the chunk: the end state of its last tile
@@ -846,6 +833,7 @@ __device__ __forceinline__ void sos_segment2(const SosArgs &a, const SosSection 
         if (a.y) b.y = a.y + begin - p;
     }
     if (s != nseg - 1) b.state_out = nullptr;
+    if (s != 0) b.prex = nullptr;
     sos_body2<T, NW, REV, AL16, PF>(b, sec, gtab, c, s > 0, p / ((int64_t)NW * 64 * T));
 }
 
@@ -884,7 +872,7 @@ static bool sos_rows_aligned16(const SosArgs &a) {
     auto ok = [](const void *p, int64_t ld) {
         return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 1) == 0);
     };
-    return ok(a.x, a.ldx) && ok(a.y, a.ldy) && (a.n & 1) == 0;
+    return ok(a.x, a.ldx) && ok(a.y, a.ldy) && ok(a.prex, a.ldprex) && (a.n & 1) == 0;
 }
 
 // Forward pass of one chunk and backward pass of another in ONE launch:
@@ -1058,6 +1046,22 @@ int sos_tables_for(osz_sos_s *h, int T, const SosSection **dsec) {
     return OSZ_OK;
 }
 
+int sos_lane_table_for(osz_sos_s *h, int T, const double **dtab) {
+    *dtab = nullptr;
+    if (h->nsec > kSos2MaxSec) return OSZ_OK;
+    if (T < 2 || T > 32) return fail(OSZ_ERR_INVALID, "sos_lane_table_for: T=%d not in [2, 32]", T);
+    if (!h->dtab2_t[T]) {
+        std::vector<double> tab((size_t)h->nsec * 4 * kSos2Tab);
+        for (int s = 0; s < h->nsec; ++s)
+            build_lane_table(h->coef + 6 * s, T, tab.data() + (size_t)s * 4 * kSos2Tab);
+        OSZ_HIP(hipMalloc(&h->dtab2_t[T], tab.size() * sizeof(double)));
+        OSZ_HIP(hipMemcpy(h->dtab2_t[T], tab.data(), tab.size() * sizeof(double),
+                          hipMemcpyHostToDevice));
+    }
+    *dtab = h->dtab2_t[T];
+    return OSZ_OK;
+}
+
 }  // namespace osz
 
 using namespace osz;
@@ -1220,6 +1224,7 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     p->nsec = nsec;
     p->nch = nch;
     for (int i = 0; i < 33; ++i) p->dsec_t[i] = nullptr;
+    for (int i = 0; i < 33; ++i) p->dtab2_t[i] = nullptr;
     for (int i = 0; i < 6 * nsec; ++i) p->coef[i] = sos[i];
     const size_t sb = sizeof(double) * (size_t)nsec * nch * 2;
     OSZ_HIP(hipMalloc(&p->dsec, sizeof(SosSection) * nsec));
@@ -1287,6 +1292,7 @@ int osz_sos_destroy(osz_sos_t h) {
     if (!h) return OSZ_OK;
     (void)hipFree(h->dsec);
     for (int i = 0; i < 33; ++i) (void)hipFree(h->dsec_t[i]);
+    for (int i = 0; i < 33; ++i) (void)hipFree(h->dtab2_t[i]);
     (void)hipFree(h->dstate);
     (void)hipFree(h->dstate_alt);
     (void)hipFree(h->dtmp);
@@ -1392,7 +1398,16 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
     w.zi_unit = fw.zi_unit = bw.zi_unit = h->dzi;
     w.tab2 = fw.tab2 = bw.tab2 = h->dtab2;
     w.touch = fw.touch = bw.touch = h->touch;
-    if (fb) {  // warm-up over the head of the next forward chunk: state only
+    // The chunk-local warm-up (numerical.py:397-399) rides the dual launch as a
+    // pre-roll of the backward pass's first segment when it is exactly whole
+    // tiles of the trimmed body; otherwise it is a small launch of its own.
+    const bool dual2 = sos_lean() && h->dtab2 && !sos_pf() && h->warm_len == tile &&
+                       (nx / tile) >= 8 && (na / tile) >= 8;
+    if (fb && dual2 && nb >= h->warm_len) {
+        bw.prex = fb;
+        bw.ldprex = ldfb;
+        bw.npre = h->warm_len;
+    } else if (fb) {  // warm-up over the head of the next forward chunk: state only
         w.x = fb;
         w.ldx = ldfb;
         w.n = nb < h->warm_len ? nb : h->warm_len;
@@ -1451,6 +1466,16 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
             std::swap(h->dstate, h->dstate_alt);
             return OSZ_OK;
         }
+    }
+    if (bw.prex) {   // not the trimmed dual launch after all: the warm-up as its own launch
+        w.x = fb;
+        w.ldx = ldfb;
+        w.n = bw.npre;
+        w.state_out = h->dtmp;
+        int rcw = sos_launch<true>(w, h->dcarry, h->T, h->NW, h->warm_len, st);
+        if (rcw) return rcw;
+        bw.state_in = h->dtmp;
+        bw.prex = nullptr;
     }
     int rc = sos_launch_dual<32, 4>(fw, bw, st);
     if (rc) return rc;

@@ -149,4 +149,139 @@ __device__ __forceinline__ void sos_tile_full(double *v, const SosSection *__res
     parity ^= 1;
 }
 
+constexpr int kSos2MaxSec = 8;                 // sections whose tables fit beside 3 workgroups per CU
+constexpr int kSos2Tab = 66;                   // A^(T k), k = 0 .. 64, then one all-zero entry
+constexpr int kSos2Zero = 65;
+
+
+// DPP moves with bound_ctrl (lanes without a source read 0) and no `old`
+// operand: nothing to initialise in front of them.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov0(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// lane i <- lane i - D inside its 16-lane row, 0 for the first D lanes
+template <int D>
+__device__ __forceinline__ double dpp_row_shr0(double v) { return dpp_mov0<0x110 + D>(v); }
+// lane i <- lane 15 of the previous row.  Measured (benchmarks/dpp_probe.hip):
+// the lanes of row 0 have no source and keep THEIR OWN value, bound_ctrl or
+// not -- the scan multiplies what rows 0 and 2 receive by an all-zero matrix.
+__device__ __forceinline__ double dpp_bcast15(double v) { return dpp_mov0<0x142>(v); }
+// lanes 32..63 <- lane 31; lanes 0..31 keep their own value (zero matrix again)
+__device__ __forceinline__ double dpp_bcast31(double v) { return dpp_mov0<0x143>(v); }
+// lane i <- lane i - 1 across the whole wave, 0 into lane 0
+__device__ __forceinline__ double dpp_wave_shr1(double v) { return dpp_mov0<0x138>(v); }
+
+// The same tile computation with the trimmed scan of sos_body2 (sos.hip): the
+// inclusive prefix over the 64 lane blocks of a wave is formed lane-parallel
+// (row_shr x 4, row_bcast:15, row_bcast:31) with per-lane matrices A^(T k) from
+// a table in LDS (`tab`: [nsec][4][kSos2Tab], built for THIS T), wave_shr:1
+// makes it exclusive; FMA-chained steps; b2 == 1 sections skip a multiply.
+template <int T, int NW>
+__device__ __forceinline__ void sos_tile_full2(double *v, const SosSection *__restrict__ sec,
+                                               const double *tab, int nsec, double *sst,
+                                               double *agg, int &parity, int &aggbuf, int w,
+                                               int l) {
+    for (int s = 0; s < nsec; ++s) {
+        const SosSection *__restrict__ S = sec + s;
+        const double b0 = S->b0, b1 = S->b1, b2 = S->b2, na1 = -S->a1, na2 = -S->a2;
+        double z0 = 0.0, z1 = 0.0;
+        if (b2 == 1.0) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const double xin = v[j];
+                const double y = fma(b0, xin, z0);
+                z0 = fma(na1, y, fma(b1, xin, z1));
+                z1 = fma(na2, y, xin);
+                v[j] = y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const double xin = v[j];
+                const double y = fma(b0, xin, z0);
+                z0 = fma(na1, y, fma(b1, xin, z1));
+                z1 = fma(na2, y, b2 * xin);
+                v[j] = y;
+            }
+        }
+        int ll = l;
+        asm volatile("" : "+v"(ll));
+        const int ka = (ll & 16) ? (ll & 15) + 1 : kSos2Zero, kb = ll >= 32 ? ll - 31 : kSos2Zero, kc = ll;
+        const double *ts = tab + s * 4 * kSos2Tab;
+        const double ma0 = ts[0 * kSos2Tab + ka], ma1 = ts[1 * kSos2Tab + ka];
+        const double ma2 = ts[2 * kSos2Tab + ka], ma3 = ts[3 * kSos2Tab + ka];
+        double e0 = z0, e1 = z1;
+#define OSZ_SCAN_STEP(K, D)                                             \
+    {                                                                   \
+        const double u0 = dpp_row_shr0<D>(e0), u1 = dpp_row_shr0<D>(e1); \
+        e0 = fma(S->P[K][0], u0, fma(S->P[K][1], u1, e0));              \
+        e1 = fma(S->P[K][2], u0, fma(S->P[K][3], u1, e1));              \
+    }
+        OSZ_SCAN_STEP(0, 1)
+        OSZ_SCAN_STEP(1, 2)
+        OSZ_SCAN_STEP(2, 4)
+        OSZ_SCAN_STEP(3, 8)
+#undef OSZ_SCAN_STEP
+        {
+            const double u0 = dpp_bcast15(e0), u1 = dpp_bcast15(e1);
+            e0 = fma(ma0, u0, fma(ma1, u1, e0));
+            e1 = fma(ma2, u0, fma(ma3, u1, e1));
+        }
+        {
+            const double mb0 = ts[0 * kSos2Tab + kb], mb1 = ts[1 * kSos2Tab + kb];
+            const double mb2 = ts[2 * kSos2Tab + kb], mb3 = ts[3 * kSos2Tab + kb];
+            const double u0 = dpp_bcast31(e0), u1 = dpp_bcast31(e1);
+            e0 = fma(mb0, u0, fma(mb1, u1, e0));
+            e1 = fma(mb2, u0, fma(mb3, u1, e1));
+        }
+        if (l == 63) {
+            agg[(aggbuf * NW + w) * 2 + 0] = e0;
+            agg[(aggbuf * NW + w) * 2 + 1] = e1;
+        }
+        const double p0 = dpp_wave_shr1(e0), p1 = dpp_wave_shr1(e1);
+        __syncthreads();
+        const double mc0 = ts[0 * kSos2Tab + kc], mc1 = ts[1 * kSos2Tab + kc];
+        const double mc2 = ts[2 * kSos2Tab + kc], mc3 = ts[3 * kSos2Tab + kc];
+        double s0 = sst[(parity * kSosMaxSec + s) * 2 + 0];
+        double s1 = sst[(parity * kSosMaxSec + s) * 2 + 1];
+        double sw0 = s0, sw1 = s1;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            if (q == w) {
+                sw0 = s0;
+                sw1 = s1;
+            }
+            const double g0 = agg[(aggbuf * NW + q) * 2 + 0], g1 = agg[(aggbuf * NW + q) * 2 + 1];
+            const double r0 = fma(S->Q[0], s0, fma(S->Q[1], s1, g0));
+            const double r1 = fma(S->Q[2], s0, fma(S->Q[3], s1, g1));
+            s0 = r0;
+            s1 = r1;
+        }
+        if (threadIdx.x == 0) {
+            sst[((parity ^ 1) * kSosMaxSec + s) * 2 + 0] = s0;
+            sst[((parity ^ 1) * kSosMaxSec + s) * 2 + 1] = s1;
+        }
+        aggbuf ^= 1;
+        double h0 = fma(mc0, sw0, fma(mc1, sw1, p0));
+        double h1 = fma(mc2, sw0, fma(mc3, sw1, p1));
+#pragma unroll
+        for (int q = 0; q < (T + 7) / 8; ++q) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (8 * q + r < T)
+                    v[8 * q + r] = fma(S->G8[r][0], h0, fma(S->G8[r][1], h1, v[8 * q + r]));
+            if (8 * (q + 1) < T) {
+                double n0, n1;
+                mat2_apply(S->A8, h0, h1, n0, n1);
+                h0 = n0;
+                h1 = n1;
+            }
+        }
+    }
+    parity ^= 1;
+}
+
 }  // namespace osz
