@@ -39,12 +39,12 @@ namespace osz {
 // and the hot loop then issues no table load at all (-3.5 % time against
 // loading 14 of them per pair before the second barrier, HPRE = 14; HPRE = 0
 // loads them where they are used).
-template <int NR, int HPRE = -1>
+template <int NR, int HPRE = -1, bool PF = false>
 __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     extern __shared__ fft::cube::C2 cube_lds[];
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
     const int64_t blk0 = fir_run_start(run, a.nblocks, a.nruns);
-    FirPair<NR, HPRE> P{a, t, a.wlen - 1, a.x + (int64_t)c * a.ldx, a.y + (int64_t)c * a.ldy,
+    FirPair<NR, HPRE, PF> P{a, t, a.wlen - 1, a.x + (int64_t)c * a.ldx, a.y + (int64_t)c * a.ldy,
                   fir_run_start(run + 1, a.nblocks, a.nruns), cube_lds};
     fft::cube::tw_load(t, a.tb, P.tw1, P.tw2);
 #pragma unroll
@@ -66,7 +66,20 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     for (int q = 0; q < 12; ++q) P.stamp_acc[q] = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.stamp_last)::"memory");
 #endif
-    for (; blk < P.blk1 && P.whole(blk); blk += 2) P.fast_pair(blk);
+    if (PF) {
+        // the last whole pair of the run requests itself again (unused, in bounds)
+        if (blk < P.blk1 && P.whole(blk)) {
+            P.next_blk = (blk + 2 < P.blk1 && P.whole(blk + 2)) ? blk + 2 : blk;
+            P.template fast_pair<false>(blk);
+            blk += 2;
+        }
+        for (; blk < P.blk1 && P.whole(blk); blk += 2) {
+            P.next_blk = (blk + 2 < P.blk1 && P.whole(blk + 2)) ? blk + 2 : blk;
+            P.template fast_pair<true>(blk);
+        }
+    } else {
+        for (; blk < P.blk1 && P.whole(blk); blk += 2) P.fast_pair(blk);
+    }
 #ifdef OSZ_FIR_STAMPS
     if (g_fir_stamps && (t & 63) == 0) {
         unsigned long long *o = g_fir_stamps + (((int64_t)c * a.nruns + run) * 4 + (t >> 6)) * 12;
@@ -353,9 +366,20 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
     {
         using kern_t = void (*)(FirArgs);
         // rows per block: 8 (2049 taps) .. 15 (<= 257 taps)
-        static const kern_t kerns[8] = {fir_oa_kernel<8>,  fir_oa_kernel<9>,  fir_oa_kernel<10>,
-                                        fir_oa_kernel<11>, fir_oa_kernel<12>, fir_oa_kernel<13>,
-                                        fir_oa_kernel<14>, fir_oa_kernel<15>};
+        static const kern_t kerns0[8] = {fir_oa_kernel<8>,  fir_oa_kernel<9>,  fir_oa_kernel<10>,
+                                         fir_oa_kernel<11>, fir_oa_kernel<12>, fir_oa_kernel<13>,
+                                         fir_oa_kernel<14>, fir_oa_kernel<15>};
+        // next pair's samples requested behind the spectrum multiply (see FirPair::nx)
+        static const kern_t kerns1[8] = {
+            fir_oa_kernel<8, 16, true>,  fir_oa_kernel<9, 16, true>,  fir_oa_kernel<10, 16, true>,
+            fir_oa_kernel<11, 16, true>, fir_oa_kernel<12, 16, true>, fir_oa_kernel<13, 16, true>,
+            fir_oa_kernel<14, 16, true>, fir_oa_kernel<15, 16, true>};
+        static int pf = -1;
+        if (pf < 0) {
+            const char *e = getenv("OSZ_FIR_PF");
+            pf = e ? atoi(e) : 1;   // measured: 1.086 -> 1.049 ms on the BASELINE chunk
+        }
+        const kern_t *kerns = pf ? kerns1 : kerns0;
         const int nr = pt.step / 256;
         size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS;
         if (const char *e = getenv("OSZ_FIR_LDS_PAD")) lds += (size_t)atoi(e) * 1024;   // occupancy experiments

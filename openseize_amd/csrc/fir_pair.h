@@ -68,12 +68,14 @@ __host__ __device__ __forceinline__ int64_t fir_run_start(int64_t r, int64_t nbl
 // weigh on the register allocation of the hot loop.
 // Measured and rejected on this kernel (profiles/README.md): requesting the
 // filter spectrum per pair (before the second barrier or at its use) instead
-// of keeping it resident, requesting the NEXT pair's samples ahead (after the
-// third barrier: +6 % time; before inverse pass 1 with the spectrum resident:
-// 162 spilled registers), twiddles loaded from the tables per pass (+13 %),
+// of keeping it resident WITHOUT using the freed registers (+3.5 %), requesting
+// the NEXT pair's samples ahead with the spectrum resident (after the third
+// barrier: +6 % time; before inverse pass 1: 162 spilled registers) -- the
+// variant that pays is PF below: spectrum per pair, next samples into its
+// registers, -3.4 % --, twiddles loaded from the tables per pass (+13 %),
 // running the FIR of chunk k+1 beside the IIR step of chunk k on a second
 // stream (+5 %, benchmarks/overlap_probe.py).
-template <int NR, int HPRE>
+template <int NR, int HPRE, bool PF = false>
 struct FirPair {
     using C2 = fft::cube::C2;
     static constexpr int NT_ = 16 - NR;   // register rows of the tail (wm1 <= 256 NT_)
@@ -87,6 +89,41 @@ struct FirPair {
     fft::cube::TwPow tw1, tw2;
     double cr[NT_];
     double Hr[HPRE < 0 ? 16 : 1], Hi[HPRE < 0 ? 16 : 1];   // HPRE < 0: spectrum resident
+    // PF: the NEXT pair's samples, requested right after this pair's spectrum
+    // multiply -- into the registers the filter spectrum has just left (PF goes
+    // with HPRE = 16: the spectrum is requested per pair, after pass 2, when the
+    // data registers are dead).  They fly while the three inverse passes run,
+    // and because they are OLDER than this pair's stores, waiting for them at
+    // the next pair does not wait for those stores (one vmcnt on gfx950).
+    double nx[PF ? 2 * NR : 1];
+    int64_t next_blk = 0;
+
+    // The requests are inline assembly, outside the compiler's vmcnt bookkeeping:
+    // at the loop top it would otherwise wait vmcnt(0..3), i.e. also for the
+    // previous pair's stores issued a moment ago.  Loads and stores retire in
+    // order on one counter, so nx has landed once at most 2 NR younger
+    // operations (this pair's stores; with accum also its 2 NR loads of y) are
+    // outstanding: wait_next() after the stores.  Untracked OLDER operations
+    // only make the compiler's own waits more conservative, never too short.
+    __device__ __forceinline__ void request_next(int64_t blk) {
+        int64_t off = blk * a.step + t;
+        asm volatile("" : "+v"(off));   // per pair: hoisted, 2 NR addresses would spill
+        const double *pa = xr + off;
+#pragma unroll
+        for (int j = 0; j < (PF ? 2 * NR : 0); j += 2) {
+            const double *pj = pa + 256 * j;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nx[PF ? j : 0]) : "v"(pj) : "memory");
+            if (j + 1 < 2 * NR)
+                asm volatile("global_load_dwordx2 %0, %1, off offset:2048"
+                             : "=v"(nx[PF ? j + 1 : 0]) : "v"(pj) : "memory");
+        }
+    }
+    __device__ __forceinline__ void wait_next() {
+        if (!PF) return;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NR) : "memory");
+#pragma unroll
+        for (int j = 0; j < (PF ? 2 * NR : 0); ++j) asm volatile("" : "+v"(nx[PF ? j : 0]));
+    }
 #ifdef OSZ_FIR_STAMPS
     unsigned long long stamp_acc[12], stamp_last;
 #endif
@@ -96,6 +133,9 @@ struct FirPair {
     }
 
     // forward transform, filter, inverse transform of the pair in re/im
+    // REQ (whole pairs of the PF kernel only): request the next pair's samples
+    // behind the spectrum multiply; the caller must wait_next()
+    template <bool REQ = false>
     __device__ __forceinline__ void transform(double *re, double *im) {
         // LDS slot numbers are recomputed per pair from an opaque copy of the
         // thread index: hoisted out of the loop they would pin 33 registers
@@ -126,6 +166,7 @@ struct FirPair {
             else if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
             else fft::cube::cmul(re[r], im[r], a.H[2 * k], a.H[2 * k + 1]);
         }
+        if (PF && REQ) request_next(next_blk);   // unconditional: nx must be dead above this line
         OSZ_FSTAMP(6);   // filter spectrum: loads + multiply
         fft::cube::i3(t, re, im, L);
         OSZ_FSTAMP(7);   // inverse pass 3
@@ -138,18 +179,28 @@ struct FirPair {
         fft::cube::i1(t, re, im, tw1, L);
     }
 
-    // a pair of whole blocks: no predication anywhere
+    // a pair of whole blocks: no predication anywhere.  FROM_NX: the samples were
+    // requested by the previous pair (PF); the first whole pair of a run loads
+    // its own, so that on EVERY path into the steady loop the requested samples
+    // are followed by one pair's stores and the compiler's wait at the loop top
+    // is vmcnt(stores), not vmcnt(0).
+    template <bool FROM_NX = false>
     __device__ __forceinline__ void fast_pair(int64_t blk) {
         const int64_t start_a = blk * a.step;
         double re[16], im[16];
         const double *pa = xr + start_a + t;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            re[j] = j < NR ? pa[256 * j] : 0.0;
-            im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
+            if (PF && FROM_NX) {
+                re[j] = j < NR ? nx[PF ? (j < NR ? j : 0) : 0] : 0.0;
+                im[j] = j < NR ? nx[PF ? (j < NR ? NR + j : 0) : 0] : 0.0;
+            } else {
+                re[j] = j < NR ? pa[256 * j] : 0.0;
+                im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
+            }
         }
         OSZ_FSTAMP(0);   // sample loads issued (and the previous pair's stores)
-        transform(re, im);
+        transform<true>(re, im);
         // re[j] = a[256 j + t], im[j] = b[256 j + t]
 #pragma unroll
         for (int j = 0; j < NT_; ++j) {
@@ -174,6 +225,7 @@ struct FirPair {
                 qa[256 * (j + NR)] = im[j];
             }
         }
+        wait_next();
         OSZ_FSTAMP(11);  // inverse pass 1 + overlap add + stores issued
     }
 

@@ -99,6 +99,25 @@ def test_oaconvolve_edges(osz):
         assert rel_err(y, orc.convolve_direct(xx, h, "full")) < RTOL
 
 
+def test_oaconvolve_every_block_height(osz):
+    """One filter length per compiled block height (8 ... 15 rows of 256 samples:
+    the whole-pair loop of fir_oa_kernel is a separate instantiation for each),
+    on runs long enough for the steady loop, several chunks (tail carried across
+    pushes, ragged last pair) and a partitioned filter (accumulating stores)."""
+    from scipy.signal import oaconvolve as sp_oa
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((3, 150001))
+    for rows in range(8, 16):
+        taps = 4096 - 256 * rows + 1 - int(rng.integers(0, 200))
+        h = rng.standard_normal(taps) / np.sqrt(taps)
+        for cs in (150001, 40000):
+            y = np.concatenate(list(osz.oaconvolve(producer(x, cs, -1), h, -1, "full")), -1)
+            assert rel_err(y, sp_oa(x, h[None], axes=-1)) < RTOL, (rows, taps, cs)
+    h = rng.standard_normal(4500) / 70
+    y = np.concatenate(list(osz.oaconvolve(producer(x, 150001, -1), h, -1, "same")), -1)
+    assert rel_err(y, sp_oa(x, h[None], mode="same", axes=-1)) < RTOL
+
+
 def test_oaconvolve_long_filters(osz):
     """More than 2049 taps: the filter is cut into 2048-tap pieces whose
     delayed outputs are accumulated (partitioned overlap-add)."""
