@@ -73,6 +73,24 @@ def main():
     st8.close()
     os.environ.pop("OSZ_SPEC_V8")
 
+    # nfft = 2 fs of the reference's default resolution at fs = 500 ... 10 000 Hz:
+    # the mixed-radix on-chip kernel (specmix.h) against the rocFFT staging route
+    for nf in ((10000,) if subset else (1000, 2000, 5000, 10000, 20000)):
+        wn = sps.get_window("hann", nf)
+        sc = float(np.sqrt(1 / (float(nf) * np.sum(wn ** 2))))
+        for route in ("specmix kernel", "rocFFT route"):
+            if route == "rocFFT route":
+                if subset or nf not in (1000, 10000):
+                    continue
+                os.environ["OSZ_SPEC_MIX"] = "0"
+            spm = dev.SpecStream(nf, nf, nf // 2, wn, sc, "constant", _lib.SPEC_PSD_MEAN, CH)
+            os.environ.pop("OSZ_SPEC_MIX", None)
+            dt = timed(lambda: spm.push(x), 5)
+            out.append({"workload": f"Welch PSD 256 ch x 2^20, nfft {nf}, 50 % ({route})",
+                        "ms_per_chunk": dt * 1e3, "Msamples_s": CH * N / dt / 1e6,
+                        "algorithmic_GBps": 8 * CH * N / dt / 1e9})
+            spm.close()
+
     # cfg-5 part 1: polyphase downsample 5 -> 1, default Kaiser (113 taps)
     cutoff = 20480 / 10
     h = Kaiser(cutoff - cutoff / 10, cutoff + cutoff / 10, 20480, gpass=0.1, gstop=40).coeffs

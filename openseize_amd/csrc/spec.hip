@@ -26,6 +26,7 @@
 #include "common.h"
 #include "fft4096.h"
 #include "fft8.h"
+#include "specmix.h"
 
 namespace osz {
 
@@ -661,6 +662,10 @@ struct osz_spec_s {
     bool fused;          // nwin == nfft == 4096: on-chip path (spec_cube_kernel)
     bool fused8;         // nfft = 512 ... 8192, a power of two: on-chip path (spec8_kernel)
     const double *tab8;  // twiddle table of fft8.h
+    bool mixed;          // even nfft = 2 * (product of 2, 3, 5) <= 20480: on-chip path (specmix_kernel)
+    int mix_npass, mix_radix[mix::kMaxPass];
+    double *dtwn;        // specmix: W_nfft^j, j < nfft
+    int *dpos;           // specmix: slot of Z[k] after the in-place passes
     double *dhead;       // fft8 path: carry ++ head of the chunk, (nch, ncap + nwin)
     double *dpartial;    // fused PSD_MEAN: (nch, nruns_cap, 2049)
     int64_t partial_cap;
@@ -719,9 +724,124 @@ __global__ void spec_head_kernel(const double *carry, int64_t ncap, int64_t ncar
     head[(int64_t)c * ldh + i] = i < ncarry ? carry[(int64_t)c * ncap + i] : x[(int64_t)c * ldx + (i - ncarry)];
 }
 
+// radix plan of the M = nfft / 2 point transform of specmix.h: 4s, a 2, 3s, 5s
+static bool specmix_plan(int nfft, int *npass, int *radix) {
+    if (nfft < 4 || (nfft & 1)) return false;
+    int m = nfft / 2, n = 0;
+    if (m > mix::kMaxM) return false;
+    auto take = [&](int r) {
+        while (m % r == 0 && n < mix::kMaxPass) {
+            radix[n++] = r;
+            m /= r;
+        }
+    };
+    take(4);
+    take(2);
+    take(3);
+    take(5);
+    *npass = n;
+    return m == 1 && n >= 1;
+}
+
+static int specmix_tables(osz_spec_s *h) {
+    const int N = h->nfft, M = N / 2;
+    const long double PI = acosl(-1.0L);
+    std::vector<double> tw(2 * (size_t)N);
+    for (int j = 0; j < N; ++j) {
+        const long double ang = -2.0L * PI * (long double)j / (long double)N;
+        tw[2 * j] = (double)cosl(ang);
+        tw[2 * j + 1] = (double)sinl(ang);
+    }
+    std::vector<int> pos(M);
+    for (int k = 0; k < M; ++k) {
+        int kk = k, S = M, p = 0;
+        for (int q = 0; q < h->mix_npass; ++q) {
+            const int r = h->mix_radix[q];
+            S /= r;
+            p += (kk % r) * S;
+            kk /= r;
+        }
+        pos[k] = p;
+    }
+    OSZ_HIP(hipMalloc(&h->dtwn, tw.size() * sizeof(double)));
+    OSZ_HIP(hipMalloc(&h->dpos, pos.size() * sizeof(int)));
+    OSZ_HIP(hipMemcpy(h->dtwn, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+    OSZ_HIP(hipMemcpy(h->dpos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice));
+    return OSZ_OK;
+}
+
+template <int NT>
+static int specmix_launch_nt(osz_spec_s *h, const mix::Args &a, hipStream_t st) {
+    using kern_t = void (*)(mix::Args);
+    static const kern_t ks[3][2] = {
+        {mix::specmix_kernel<0, false, NT>, mix::specmix_kernel<0, true, NT>},
+        {mix::specmix_kernel<1, false, NT>, mix::specmix_kernel<1, true, NT>},
+        {mix::specmix_kernel<2, false, NT>, mix::specmix_kernel<2, true, NT>}};
+    const kern_t k = ks[h->mode][h->detrend == OSZ_DETREND_LINEAR ? 1 : 0];
+    const size_t lds = sizeof(mix::C2) * (size_t)a.M;
+    OSZ_DYN_LDS(k, lds);
+    KernelTimer kt("spec_fused", st);
+    hipLaunchKernelGGL(k, dim3((unsigned)a.nruns, h->nch), dim3(NT), lds, st, a);
+    return OSZ_OK;
+}
+
+// one launch of specmix_kernel over nseg segments of a contiguous source
+static int specmix_run(osz_spec_s *h, const double *src, int64_t ld, void *out, int64_t nseg,
+                       hipStream_t st) {
+    int64_t R = (nseg * h->nch) / 2048;   // segments per run
+    if (const char *e = getenv("OSZ_SPEC_R")) R = atoi(e);
+    if (R > 64) R = 64;
+    if (R < 1) R = 1;
+    const int64_t nruns = (nseg + R - 1) / R;
+    mix::Args a{};
+    a.x = src;
+    a.window = h->dwindow;
+    a.out = out;
+    a.tw = h->dtwn;
+    a.pos = h->dpos;
+    a.ldx = ld;
+    a.nseg = nseg;
+    a.stride = h->stride;
+    a.nwin = h->nwin;
+    a.nch = h->nch;
+    a.nruns = (int)nruns;
+    a.N = h->nfft;
+    a.M = h->nfft / 2;
+    a.npass = h->mix_npass;
+    for (int q = 0; q < h->mix_npass; ++q) a.radix[q] = h->mix_radix[q];
+    a.scale = h->scale;
+    if (h->mode == OSZ_SPEC_PSD_MEAN) {
+        const int64_t need = (int64_t)h->nch * nruns * h->nfreq;
+        if (need > h->partial_cap) {
+            OSZ_HIP(hipStreamSynchronize(st));
+            (void)hipFree(h->dpartial);
+            h->dpartial = nullptr;
+            if (hipMalloc(&h->dpartial, sizeof(double) * need) != hipSuccess)
+                return fail(OSZ_ERR_NOMEM, "osz_spec_push: partial sums (%lld doubles)", (long long)need);
+            h->partial_cap = need;
+        }
+        a.partial = h->dpartial;
+    }
+    // threads: every bin k <= M needs a (thread, m < kAcc) pair
+    int rc;
+    if (a.M < 64 * mix::kAcc && a.M <= 256) rc = specmix_launch_nt<64>(h, a, st);
+    else if (a.M < 256 * mix::kAcc) rc = specmix_launch_nt<256>(h, a, st);
+    else if (a.M < 512 * mix::kAcc) rc = specmix_launch_nt<512>(h, a, st);
+    else rc = specmix_launch_nt<1024>(h, a, st);
+    if (rc) return rc;
+    OSZ_HIP(hipGetLastError());
+    if (h->mode == OSZ_SPEC_PSD_MEAN) {
+        hipLaunchKernelGGL(spec_partial_reduce_n_kernel, dim3((h->nfreq + 255) / 256, h->nch), dim3(256),
+                           0, st, h->dpartial, h->dsum, (int)nruns, h->nfreq);
+        OSZ_HIP(hipGetLastError());
+    }
+    return OSZ_OK;
+}
+
 // one launch of spec8_kernel over nseg segments of a contiguous source
 static int spec8_run(osz_spec_s *h, const double *src, int64_t ld, void *out, int64_t nseg,
                      hipStream_t st) {
+    if (h->mixed) return specmix_run(h, src, ld, out, nseg, st);
     const int64_t npairs = (nseg + 1) / 2;
     // runs: enough workgroups for a few rounds of the chip, long enough that the
     // per-run set-up (twiddles, window, partial sums) stays small
@@ -773,8 +893,9 @@ static int spec8_run(osz_spec_s *h, const double *src, int64_t ld, void *out, in
     return OSZ_OK;
 }
 
-// On-chip path for power-of-two nfft in [512, 8192] (spec8_kernel).  The kernel
-// reads ONE contiguous source.  The segments that begin in the carry of the
+// On-chip paths for power-of-two nfft in [512, 8192] (spec8_kernel) and for the
+// other even nfft made of factors 2, 3, 5 (specmix_kernel).  The kernels
+// read ONE contiguous source.  The segments that begin in the carry of the
 // previous push (fewer than nwin / stride + 1 of them) are served from a small
 // head buffer = carry ++ the first nwin samples of the chunk; every other
 // segment lies inside the chunk.
@@ -861,6 +982,16 @@ int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride, const double 
             int rc = get_fft8_table(&p->tab8);
             if (rc) { delete p->plans; delete p; return rc; }
         }
+        // OSZ_SPEC_MIX=0: never the mixed-radix on-chip path
+        const char *em = getenv("OSZ_SPEC_MIX");
+        p->dtwn = nullptr;
+        p->dpos = nullptr;
+        p->mixed = !p->fused && !p->fused8 && !(em && atoi(em) == 0) &&
+                   specmix_plan(nfft, &p->mix_npass, p->mix_radix);
+        if (p->mixed) {
+            int rc = specmix_tables(p);
+            if (rc) { (void)hipFree(p->dtwn); (void)hipFree(p->dpos); delete p->plans; delete p; return rc; }
+        }
     }
     const size_t cb = sizeof(double) * (size_t)nch * p->ncap;
     const size_t ab = sizeof(double) * (size_t)nch * p->nfreq;
@@ -889,6 +1020,8 @@ int osz_spec_destroy(osz_spec_t h) {
     (void)hipFree(h->dwork);
     (void)hipFree(h->dpartial);
     (void)hipFree(h->dhead);
+    (void)hipFree(h->dtwn);
+    (void)hipFree(h->dpos);
     delete h;
     return OSZ_OK;
 }
@@ -917,7 +1050,7 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
     const int64_t total = h->ncarry + n;
     const int64_t nseg = osz_spec_seg_count(h, n);
     OSZ_REQUIRE(nseg == 0 || h->mode == OSZ_SPEC_PSD_MEAN || out, "osz_spec_push: null output");
-    if (nseg > 0 && h->fused8) {
+    if (nseg > 0 && (h->fused8 || h->mixed)) {
         int rc = spec8_push(h, x, ldx, n, out, nseg, st);
         if (rc) return rc;
         h->count += nseg;

@@ -1,0 +1,271 @@
+// specmix.h -- on-chip spectra for the transform lengths fft8.h does not cover.
+//
+// nfft = int(fs / resolution) in the reference (spectra/estimators.py:144, default
+// resolution 0.5 -> nfft = 2 fs): 500, 1000, 2000, 5000, 10000 ... are products
+// of 2, 3 and 5 far more often than powers of two.  One workgroup walks a run of
+// segments of one channel; a segment of nfft real samples is packed into
+// M = nfft / 2 complex points z[j] = y[2j] + i y[2j+1] in LDS (16 B a point,
+// 80 KB at nfft = 10000), transformed IN PLACE by decimation-in-frequency passes
+// of radix 4, 2, 3, 5 (in that order: the even radices run while the butterfly
+// stride is long, the last passes -- stride 1 ... 25 -- are the odd ones, whose
+// 48- and 80-byte lane strides spread over all banks), one barrier per pass, and
+// untangled into the nfft / 2 + 1 bins of the real transform on the way out:
+//   X[k] = E[k] + W_nfft^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i (Z[k] - conj Z[M-k]) / 2.
+// In-place DIF leaves Z[k] at the digit-reversed slot pos[k] (host table).
+// Twiddles: one table W_nfft^j, j < nfft, in global memory (L2); a butterfly
+// loads W_B^inner once and squares / multiplies its way to the other powers.
+//
+// HBM traffic: the samples once (overlapping halves of consecutive segments of a
+// run come back from L2), the PSD partial sums once per run -- against the
+// rocFFT route's staging rows (prep -> r2c -> post: 5-10x the algorithmic bytes).
+#pragma once
+
+#include "common.h"
+
+namespace osz {
+namespace mix {
+
+struct C2 {
+    double re, im;
+};
+
+constexpr int kMaxPass = 14;   // 2^13 * ... : M <= 10240 needs at most 7 radix-4/2 passes
+constexpr int kAcc = 12;       // PSD sums per thread: bins t + NT m, m < kAcc
+constexpr int kMaxM = 10240;   // 160 KB of LDS
+
+struct Args {
+    const double *x;        // one contiguous source: segment s starts at column s * stride
+    const double *window;   // nwin
+    void *out;              // SEGMENTS modes: (nseg, nch, nfreq) f64 / c128
+    double *partial;        // PSD_MEAN: (nch, nruns, nfreq) sums of this launch
+    const double *tw;       // W_N^j = exp(-2 pi i j / N), j < N, (re, im) pairs
+    const int *pos;         // slot of Z[k] after the passes, k < M
+    int64_t ldx, nseg;
+    int stride, nwin, nch, nruns, N, M, npass;
+    int radix[kMaxPass];
+    double scale;
+};
+
+__device__ __forceinline__ C2 cmul(C2 a, C2 b) {
+    return C2{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+__device__ __forceinline__ C2 cadd(C2 a, C2 b) { return C2{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ C2 csub(C2 a, C2 b) { return C2{a.re - b.re, a.im - b.im}; }
+// a - i b, a + i b
+__device__ __forceinline__ C2 sub_i(C2 a, C2 b) { return C2{a.re + b.im, a.im - b.re}; }
+__device__ __forceinline__ C2 add_i(C2 a, C2 b) { return C2{a.re - b.im, a.im + b.re}; }
+
+// forward DFT (e^{-2 pi i / R}) of R points in registers
+template <int R>
+__device__ __forceinline__ void dft(C2 *v);
+
+template <>
+__device__ __forceinline__ void dft<2>(C2 *v) {
+    const C2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+template <>
+__device__ __forceinline__ void dft<3>(C2 *v) {
+    const double h = 0.86602540378443864676;   // sin(2 pi / 3)
+    const C2 t1 = cadd(v[1], v[2]);
+    const C2 d = csub(v[1], v[2]);
+    const C2 m1 = C2{v[0].re - 0.5 * t1.re, v[0].im - 0.5 * t1.im};
+    const C2 s = C2{h * d.re, h * d.im};
+    v[0] = cadd(v[0], t1);
+    v[1] = sub_i(m1, s);
+    v[2] = add_i(m1, s);
+}
+template <>
+__device__ __forceinline__ void dft<4>(C2 *v) {
+    const C2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
+    const C2 c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+    v[0] = cadd(a, c);
+    v[2] = csub(a, c);
+    v[1] = sub_i(b, d);
+    v[3] = add_i(b, d);
+}
+template <>
+__device__ __forceinline__ void dft<5>(C2 *v) {
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;   // cos(2 pi/5), cos(4 pi/5)
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;    // sin(2 pi/5), sin(4 pi/5)
+    const C2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+    const C2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    const C2 m1 = C2{v[0].re + c1 * t1.re + c2 * t2.re, v[0].im + c1 * t1.im + c2 * t2.im};
+    const C2 m2 = C2{v[0].re + c2 * t1.re + c1 * t2.re, v[0].im + c2 * t1.im + c1 * t2.im};
+    const C2 n1 = C2{s1 * t3.re + s2 * t4.re, s1 * t3.im + s2 * t4.im};
+    const C2 n2 = C2{s2 * t3.re - s1 * t4.re, s2 * t3.im - s1 * t4.im};
+    v[0] = C2{v[0].re + t1.re + t2.re, v[0].im + t1.im + t2.im};
+    v[1] = sub_i(m1, n1);
+    v[4] = add_i(m1, n1);
+    v[2] = sub_i(m2, n2);
+    v[3] = add_i(m2, n2);
+}
+
+// One in-place DIF pass of radix R over the M points: blocks of B = R S points,
+// butterfly (blk, inner) on the slots blk B + inner + q S, output q times W_B^(inner q).
+template <int R, int NT>
+__device__ __forceinline__ void pass(C2 *z, int t, int M, int S, int tstep, const double *tw) {
+    const int nb = M / R;
+    const int B = R * S;
+#pragma unroll 1
+    for (int b = t; b < nb; b += NT) {
+        int blk, inner;
+        if (S == 1) {
+            blk = b;
+            inner = 0;
+        } else {
+            blk = b / S;
+            inner = b - blk * S;
+        }
+        C2 *p = z + blk * B + inner;
+        C2 v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = p[q * S];
+        dft<R>(v);
+        if (S > 1) {
+            const int j = inner * tstep;
+            const C2 w1 = C2{tw[2 * j], tw[2 * j + 1]};
+            v[1] = cmul(v[1], w1);
+            if (R > 2) {
+                const C2 w2 = cmul(w1, w1);
+                v[2] = cmul(v[2], w2);
+                if (R > 3) {
+                    v[R > 3 ? 3 : 0] = cmul(v[R > 3 ? 3 : 0], cmul(w2, w1));
+                    if (R > 4) v[R > 4 ? 4 : 0] = cmul(v[R > 4 ? 4 : 0], cmul(w2, w2));
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) p[q * S] = v[q];
+    }
+}
+
+template <int MODE, bool LINEAR, int NT>
+__global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
+    extern __shared__ C2 zmix[];
+    constexpr int NWV = (NT + 63) / 64;
+    __shared__ double red[NWV][2];
+    C2 *z = zmix;
+    const int t = threadIdx.x;
+    const int run = blockIdx.x;
+    const int c = blockIdx.y;
+    const int M = a.M, N = a.N, NF = a.M + 1;
+    const double *xr = a.x + (int64_t)c * a.ldx;
+    const int64_t s0 = ((int64_t)run * a.nseg) / a.nruns;
+    const int64_t s1 = ((int64_t)(run + 1) * a.nseg) / a.nruns;
+    const double mid = 0.5 * (a.nwin - 1);
+    const double s2 = a.scale * a.scale;
+    double acc[kAcc];
+#pragma unroll
+    for (int m = 0; m < kAcc; ++m) acc[m] = 0.0;
+
+    for (int64_t s = s0; s < s1; ++s) {
+        const double *xs = xr + s * (int64_t)a.stride;
+        // ---- samples into LDS (raw), block sums for the trend
+        double sum = 0.0, lin = 0.0;
+        __syncthreads();   // the bin reads of the previous segment are done
+        for (int j = t; j < M; j += NT) {
+            const int i0 = 2 * j, i1 = 2 * j + 1;
+            const double v0 = i0 < a.nwin ? xs[i0] : 0.0;
+            const double v1 = i1 < a.nwin ? xs[i1] : 0.0;
+            sum += v0 + v1;
+            if (LINEAR) lin += (i0 - mid) * v0 + (i1 - mid) * v1;
+            z[j] = C2{v0, v1};
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            sum += __shfl_down(sum, off, 64);
+            if (LINEAR) lin += __shfl_down(lin, off, 64);
+        }
+        if ((t & 63) == 0) {
+            red[t >> 6][0] = sum;
+            red[t >> 6][1] = lin;
+        }
+        __syncthreads();
+        double tot = 0.0, tlin = 0.0;
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) {
+            tot += red[q][0];
+            if (LINEAR) tlin += red[q][1];
+        }
+        const double mean = tot / a.nwin;
+        double slope = 0.0;
+        if (LINEAR) {
+            const double nn = (double)a.nwin;
+            const double sxx = nn * (nn * nn - 1.0) / 12.0;
+            slope = sxx > 0.0 ? tlin / sxx : 0.0;
+        }
+        // ---- detrend and window in place (a thread rewrites the slots it filled)
+        for (int j = t; j < M; j += NT) {
+            const int i0 = 2 * j, i1 = 2 * j + 1;
+            const double w0 = i0 < a.nwin ? a.window[i0] : 0.0;
+            const double w1 = i1 < a.nwin ? a.window[i1] : 0.0;
+            C2 v = z[j];
+            if (LINEAR) {
+                v.re = (v.re - mean - slope * (i0 - mid)) * w0;
+                v.im = (v.im - mean - slope * (i1 - mid)) * w1;
+            } else {
+                v.re = (v.re - mean) * w0;
+                v.im = (v.im - mean) * w1;
+            }
+            z[j] = v;
+        }
+        // ---- M-point transform, in place
+        int B = M;
+        for (int p = 0; p < a.npass; ++p) {
+            __syncthreads();
+            const int r = a.radix[p];
+            const int S = B / r;
+            const int tstep = N / B;
+            if (r == 4) pass<4, NT>(z, t, M, S, tstep, a.tw);
+            else if (r == 5) pass<5, NT>(z, t, M, S, tstep, a.tw);
+            else if (r == 2) pass<2, NT>(z, t, M, S, tstep, a.tw);
+            else pass<3, NT>(z, t, M, S, tstep, a.tw);
+            B = S;
+        }
+        __syncthreads();
+        // ---- bins 0 ... M of the real transform (opaque thread index: hoisted out
+        // of the segment loop, the table addresses of all kAcc bins would spill)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int m = 0; m < kAcc; ++m) {
+            const int k = tt + NT * m;
+            asm volatile("" ::: "memory");   // one bin at a time: hoisted, the loads of all kAcc bins spill
+            if (k <= M) {
+                const int ka = k == M ? 0 : k;
+                const int kb = (k == 0 || k == M) ? 0 : M - k;
+                const C2 za = z[a.pos[ka]], zb = z[a.pos[kb]];
+                const double er = 0.5 * (za.re + zb.re), ei = 0.5 * (za.im - zb.im);
+                const double dr = 0.5 * (za.re - zb.re), di = 0.5 * (za.im + zb.im);
+                const double orr = di, oi = -dr;                    // O = -i D
+                const double wr = a.tw[2 * k], wi = a.tw[2 * k + 1];
+                const double xr_ = er + (wr * orr - wi * oi);
+                const double xi_ = ei + (wr * oi + wi * orr);
+                if (MODE == OSZ_SPEC_DFT_SEGMENTS) {
+                    double *o = (double *)a.out + ((s * a.nch + c) * (int64_t)NF + k) * 2;
+                    o[0] = xr_ * a.scale;
+                    o[1] = xi_ * a.scale;
+                } else {
+                    const bool dbl = (k != 0) && (k != M);
+                    const double pw = (xr_ * xr_ + xi_ * xi_) * (dbl ? 2.0 * s2 : s2);
+                    if (MODE == OSZ_SPEC_PSD_SEGMENTS)
+                        ((double *)a.out)[(s * a.nch + c) * (int64_t)NF + k] = pw;
+                    else
+                        acc[m] += pw;
+                }
+            }
+        }
+    }
+    if (MODE == OSZ_SPEC_PSD_MEAN) {
+        double *o = a.partial + ((int64_t)c * a.nruns + run) * NF;
+#pragma unroll
+        for (int m = 0; m < kAcc; ++m) {
+            const int k = t + NT * m;
+            if (k <= M) o[k] = acc[m];
+        }
+    }
+}
+
+}  // namespace mix
+}  // namespace osz
