@@ -724,7 +724,7 @@ __global__ void spec_head_kernel(const double *carry, int64_t ncap, int64_t ncar
     head[(int64_t)c * ldh + i] = i < ncarry ? carry[(int64_t)c * ncap + i] : x[(int64_t)c * ldx + (i - ncarry)];
 }
 
-// radix plan of the M = nfft / 2 point transform of specmix.h: 4s, a 2, 3s, 5s
+// radix plan of the M = nfft / 2 point transform of specmix.h: 10s, 4s, a 2, 3s, 5s
 static bool specmix_plan(int nfft, int *npass, int *radix) {
     if (nfft < 4 || (nfft & 1)) return false;
     int m = nfft / 2, n = 0;
@@ -735,6 +735,7 @@ static bool specmix_plan(int nfft, int *npass, int *radix) {
             m /= r;
         }
     };
+    take(10);
     take(4);
     take(2);
     take(3);
@@ -822,11 +823,13 @@ static int specmix_run(osz_spec_s *h, const double *src, int64_t ld, void *out, 
         }
         a.partial = h->dpartial;
     }
-    // threads: every bin k <= M needs a (thread, m < kAcc) pair
+    // threads: a radix-10 pass has M / 10 butterflies -- one per thread; every
+    // bin k <= M then has its (thread, m < kAcc) pair as well
     int rc;
-    if (a.M < 64 * mix::kAcc && a.M <= 256) rc = specmix_launch_nt<64>(h, a, st);
-    else if (a.M < 256 * mix::kAcc) rc = specmix_launch_nt<256>(h, a, st);
-    else if (a.M < 512 * mix::kAcc) rc = specmix_launch_nt<512>(h, a, st);
+    if (a.M <= 640) rc = specmix_launch_nt<64>(h, a, st);
+    else if (a.M <= 1280) rc = specmix_launch_nt<128>(h, a, st);
+    else if (a.M <= 2560) rc = specmix_launch_nt<256>(h, a, st);
+    else if (a.M <= 5120) rc = specmix_launch_nt<512>(h, a, st);
     else rc = specmix_launch_nt<1024>(h, a, st);
     if (rc) return rc;
     OSZ_HIP(hipGetLastError());

@@ -6,7 +6,7 @@
 // segments of one channel; a segment of nfft real samples is packed into
 // M = nfft / 2 complex points z[j] = y[2j] + i y[2j+1] in LDS (16 B a point,
 // 80 KB at nfft = 10000), transformed IN PLACE by decimation-in-frequency passes
-// of radix 4, 2, 3, 5 (in that order: the even radices run while the butterfly
+// of radix 10, 4, 2, 3, 5 (in that order: the even radices run while the butterfly
 // stride is long, the last passes -- stride 1 ... 25 -- are the odd ones, whose
 // 48- and 80-byte lane strides spread over all banks), one barrier per pass, and
 // untangled into the nfft / 2 + 1 bins of the real transform on the way out:
@@ -31,6 +31,7 @@ struct C2 {
 
 constexpr int kMaxPass = 14;   // 2^13 * ... : M <= 10240 needs at most 7 radix-4/2 passes
 constexpr int kAcc = 12;       // PSD sums per thread: bins t + NT m, m < kAcc
+constexpr int kBatch = 4;      // sample trips whose loads are in flight together (divides kAcc)
 constexpr int kMaxM = 10240;   // 160 KB of LDS
 
 struct Args {
@@ -102,6 +103,26 @@ __device__ __forceinline__ void dft<5>(C2 *v) {
     v[3] = add_i(m2, n2);
 }
 
+// 10 = 2 x 5 by the prime-factor mapping: no twiddles inside the butterfly.
+// Inputs n = (5 n1 + 2 n2) mod 10, outputs k = (5 k1 + 6 k2) mod 10.
+template <>
+__device__ __forceinline__ void dft<10>(C2 *v) {
+    C2 a[5] = {v[0], v[2], v[4], v[6], v[8]};
+    C2 b[5] = {v[5], v[7], v[9], v[1], v[3]};
+    dft<5>(a);
+    dft<5>(b);
+    v[0] = cadd(a[0], b[0]);
+    v[5] = csub(a[0], b[0]);
+    v[6] = cadd(a[1], b[1]);
+    v[1] = csub(a[1], b[1]);
+    v[2] = cadd(a[2], b[2]);
+    v[7] = csub(a[2], b[2]);
+    v[8] = cadd(a[3], b[3]);
+    v[3] = csub(a[3], b[3]);
+    v[4] = cadd(a[4], b[4]);
+    v[9] = csub(a[4], b[4]);
+}
+
 // One in-place DIF pass of radix R over the M points: blocks of B = R S points,
 // butterfly (blk, inner) on the slots blk B + inner + q S, output q times W_B^(inner q).
 template <int R, int NT>
@@ -126,14 +147,12 @@ __device__ __forceinline__ void pass(C2 *z, int t, int M, int S, int tstep, cons
         if (S > 1) {
             const int j = inner * tstep;
             const C2 w1 = C2{tw[2 * j], tw[2 * j + 1]};
-            v[1] = cmul(v[1], w1);
-            if (R > 2) {
-                const C2 w2 = cmul(w1, w1);
-                v[2] = cmul(v[2], w2);
-                if (R > 3) {
-                    v[R > 3 ? 3 : 0] = cmul(v[R > 3 ? 3 : 0], cmul(w2, w1));
-                    if (R > 4) v[R > 4 ? 4 : 0] = cmul(v[R > 4 ? 4 : 0], cmul(w2, w2));
-                }
+            C2 wq = w1;
+            v[1] = cmul(v[1], wq);
+#pragma unroll
+            for (int q = 2; q < R; ++q) {
+                wq = cmul(wq, w1);
+                v[q] = cmul(v[q], wq);
             }
         }
 #pragma unroll
@@ -162,16 +181,39 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
 
     for (int64_t s = s0; s < s1; ++s) {
         const double *xs = xr + s * (int64_t)a.stride;
-        // ---- samples into LDS (raw), block sums for the trend
+        // ---- samples into LDS (raw), block sums for the trend.  The trip count
+        // is at most kAcc (the launch picks NT so): unrolled in batches whose
+        // loads are in flight together -- a rolled loop is a chain of HBM latencies.
         double sum = 0.0, lin = 0.0;
         __syncthreads();   // the bin reads of the previous segment are done
-        for (int j = t; j < M; j += NT) {
-            const int i0 = 2 * j, i1 = 2 * j + 1;
-            const double v0 = i0 < a.nwin ? xs[i0] : 0.0;
-            const double v1 = i1 < a.nwin ? xs[i1] : 0.0;
-            sum += v0 + v1;
-            if (LINEAR) lin += (i0 - mid) * v0 + (i1 - mid) * v1;
-            z[j] = C2{v0, v1};
+        // opaque thread index, again before every phase: hoisted out of the segment
+        // loop, the addresses / masks / ramp values of all kAcc trips would spill
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int h = 0; h < kAcc; h += kBatch) {
+            if (NT * h >= M) break;   // uniform
+            double v0[kBatch], v1[kBatch];
+            asm volatile("" : "+v"(tt));
+#pragma unroll
+            for (int m = 0; m < kBatch; ++m) {
+                const unsigned j = tt + NT * (h + m);
+                const unsigned i0 = 2 * j, i1 = 2 * j + 1;
+                // clamped addresses, zeros by select: no branch around the loads
+                const double a0 = xs[i0 < (unsigned)a.nwin ? i0 : 0u], a1 = xs[i1 < (unsigned)a.nwin ? i1 : 0u];
+                v0[m] = i0 < (unsigned)a.nwin ? a0 : 0.0;
+                v1[m] = i1 < (unsigned)a.nwin ? a1 : 0.0;
+            }
+#pragma unroll
+            for (int m = 0; m < kBatch; ++m) {
+                const int j = tt + NT * (h + m);
+                const int i0 = 2 * j, i1 = 2 * j + 1;
+                if (j < M) {
+                    sum += v0[m] + v1[m];
+                    if (LINEAR) lin += (i0 - mid) * v0[m] + (i1 - mid) * v1[m];
+                    z[j] = C2{v0[m], v1[m]};
+                }
+            }
         }
         for (int off = 32; off > 0; off >>= 1) {
             sum += __shfl_down(sum, off, 64);
@@ -196,19 +238,36 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
             slope = sxx > 0.0 ? tlin / sxx : 0.0;
         }
         // ---- detrend and window in place (a thread rewrites the slots it filled)
-        for (int j = t; j < M; j += NT) {
-            const int i0 = 2 * j, i1 = 2 * j + 1;
-            const double w0 = i0 < a.nwin ? a.window[i0] : 0.0;
-            const double w1 = i1 < a.nwin ? a.window[i1] : 0.0;
-            C2 v = z[j];
-            if (LINEAR) {
-                v.re = (v.re - mean - slope * (i0 - mid)) * w0;
-                v.im = (v.im - mean - slope * (i1 - mid)) * w1;
-            } else {
-                v.re = (v.re - mean) * w0;
-                v.im = (v.im - mean) * w1;
+#pragma unroll
+        for (int h = 0; h < kAcc; h += kBatch) {
+            if (NT * h >= M) break;   // uniform
+            double w0[kBatch], w1[kBatch];
+            asm volatile("" : "+v"(tt));
+#pragma unroll
+            for (int m = 0; m < kBatch; ++m) {
+                const unsigned j = tt + NT * (h + m);
+                const unsigned i0 = 2 * j, i1 = 2 * j + 1;
+                const double a0 = a.window[i0 < (unsigned)a.nwin ? i0 : 0u];
+                const double a1 = a.window[i1 < (unsigned)a.nwin ? i1 : 0u];
+                w0[m] = i0 < (unsigned)a.nwin ? a0 : 0.0;
+                w1[m] = i1 < (unsigned)a.nwin ? a1 : 0.0;
             }
-            z[j] = v;
+#pragma unroll
+            for (int m = 0; m < kBatch; ++m) {
+                const int j = tt + NT * (h + m);
+                const int i0 = 2 * j, i1 = 2 * j + 1;
+                if (j < M) {
+                    C2 v = z[j];
+                    if (LINEAR) {
+                        v.re = (v.re - mean - slope * (i0 - mid)) * w0[m];
+                        v.im = (v.im - mean - slope * (i1 - mid)) * w1[m];
+                    } else {
+                        v.re = (v.re - mean) * w0[m];
+                        v.im = (v.im - mean) * w1[m];
+                    }
+                    z[j] = v;
+                }
+            }
         }
         // ---- M-point transform, in place
         int B = M;
@@ -217,7 +276,8 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
             const int r = a.radix[p];
             const int S = B / r;
             const int tstep = N / B;
-            if (r == 4) pass<4, NT>(z, t, M, S, tstep, a.tw);
+            if (r == 10) pass<10, NT>(z, t, M, S, tstep, a.tw);
+            else if (r == 4) pass<4, NT>(z, t, M, S, tstep, a.tw);
             else if (r == 5) pass<5, NT>(z, t, M, S, tstep, a.tw);
             else if (r == 2) pass<2, NT>(z, t, M, S, tstep, a.tw);
             else pass<3, NT>(z, t, M, S, tstep, a.tw);
@@ -226,7 +286,6 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
         __syncthreads();
         // ---- bins 0 ... M of the real transform (opaque thread index: hoisted out
         // of the segment loop, the table addresses of all kAcc bins would spill)
-        int tt = t;
         asm volatile("" : "+v"(tt));
 #pragma unroll
         for (int m = 0; m < kAcc; ++m) {
