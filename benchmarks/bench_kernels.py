@@ -256,6 +256,37 @@ def main():
         out.append({"workload": f"host-fed oaconvolve 16 ch x 2^23, 256 taps, chunksize {cs}",
                     "seconds": dt, "Msamples_s": xl.size / dt / 1e6,
                     "pcie_GBps_each_way": 8 * xl.size / dt / 1e9})
+    # the same stream through sosfiltfilt (6 sections) and through the FIR -> sosfiltfilt
+    # chain of cfg-3, host in / host out
+    sos6 = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    from functools import partial
+    from openseize_amd.core.producer import producer as mkpro
+    for name, run in (
+        ("host-fed sosfiltfilt (6 sections)",
+         lambda: nm.sosfiltfilt(producer(xl, 1 << 18, -1), sos6, -1)),
+        ("host-fed FIR(256) -> sosfiltfilt(6) chain",
+         lambda: nm.sosfiltfilt(
+             mkpro(partial(nm.oaconvolve, window=hh, axis=-1, mode="same"), 1 << 18, -1,
+                   shape=xl.shape, pro=producer(xl, 1 << 18, -1)), sos6, -1))):
+        def fed2():
+            return sum(piece.shape[-1] for piece in run())
+        fed2()
+        t0 = time.perf_counter()
+        got = fed2()
+        dt = time.perf_counter() - t0
+        assert got == xl.shape[-1], (name, got)
+        out.append({"workload": f"{name} 16 ch x 2^23, chunksize 262144",
+                    "seconds": dt, "Msamples_s": xl.size / dt / 1e6,
+                    "pcie_GBps_each_way": 8 * xl.size / dt / 1e9})
+    # host-fed Welch PSD at the reference's default resolution, fs = 5 kHz (nfft 10 000)
+    from openseize_amd.spectra.estimators import psd
+    psd(xl, fs=5000.0, axis=-1)
+    t0 = time.perf_counter()
+    cnt, _, _ = psd(xl, fs=5000.0, axis=-1)
+    dt = time.perf_counter() - t0
+    out.append({"workload": f"host-fed psd 16 ch x 2^23, fs 5000 (nfft 10000), {cnt} segments",
+                "seconds": dt, "Msamples_s": xl.size / dt / 1e6,
+                "pcie_GBps_up": 8 * xl.size / dt / 1e9})
     for o in out:
         print(json.dumps(o))
 

@@ -163,6 +163,48 @@ def _threaded_copy(dst, src):
     list(_copy_pool().map(lambda sl: np.copyto(dst[sl], src[sl]), cuts))
 
 
+def gather_along_axis(pieces, counts, axis):
+    """One new array = the first counts[i] samples of pieces[i] along ``axis``,
+    joined (what a FIFO pop needs).  Device tensors: torch.cat of views.  Host
+    arrays: one allocation filled by a few threads, the destination split
+    across the leading rows so every thread writes its own cache lines."""
+    if is_tensor(pieces[0]):
+        return torch.cat([p.narrow(axis, 0, c) for p, c in zip(pieces, counts) if c > 0], dim=axis)
+    first = pieces[0]
+    axis = axis % first.ndim
+    shape = list(first.shape)
+    shape[axis] = int(sum(counts))
+    out = np.empty(shape, dtype=np.result_type(*[p.dtype for p in pieces]))
+    jobs, at = [], 0
+    for p, c in zip(pieces, counts):
+        if c > 0:
+            idx = [slice(None)] * first.ndim
+            idx[axis] = slice(at, at + c)
+            src = [slice(None)] * first.ndim
+            src[axis] = slice(0, c)
+            jobs.append((tuple(idx), p, tuple(src)))
+            at += c
+    if out.size < (1 << 18):
+        for idx, p, src in jobs:
+            out[idx] = p[src]
+        return out
+    # split every job along the longest other axis (or the sample axis itself)
+    tasks = []
+    for idx, p, src in jobs:
+        d, s_ = out[idx], p[src]
+        cut_axis = max(range(d.ndim), key=lambda k: d.shape[k] if k != axis else -1) if d.ndim > 1 else 0
+        if d.ndim == 1 or d.shape[cut_axis] < 4:
+            cut_axis = axis
+        n = d.shape[cut_axis]
+        parts = min(8, n) or 1
+        for q in range(parts):
+            sl = [slice(None)] * d.ndim
+            sl[cut_axis] = slice(q * n // parts, (q + 1) * n // parts)
+            tasks.append((d[tuple(sl)], s_[tuple(sl)]))
+    list(_copy_pool().map(lambda t: np.copyto(t[0], t[1]), tasks))
+    return out
+
+
 class HostPipe:
     """Overlaps the transfers of a host-fed stream with its kernels.  The
     reference's real sources are host ndarrays and EDF files
@@ -209,6 +251,13 @@ class HostPipe:
         slot[1] = ev
         self.slots[k] = slot
         return x, ev
+
+    def feed(self, arr):
+        """``upload`` for consumers that launch on the compute stream right away:
+        the compute stream is made to wait for the transfer, the CPU is not."""
+        x2d, ready = self.upload(arr)
+        self.compute.wait_event(ready)
+        return x2d
 
     def download(self, y2d):
         """Device result -> (pinned host tensor, done event), behind the kernels

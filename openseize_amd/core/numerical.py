@@ -17,6 +17,8 @@ CUDA tensors stay in HBM.
 import math
 from functools import partial
 
+from collections import deque
+
 import numpy as np
 import scipy.signal as sps
 
@@ -283,12 +285,25 @@ def sosfiltfilt(pro, sos, axis):
         first = next(chunks, None)
         if first is None:
             return
-        x2d, host = layout.to2d(first)
+        # host-fed: every chunk goes up through the pinned ring on the H2D stream
+        # while the previous step runs, results leave on the D2H stream and are
+        # handed over two steps later (dev.HostPipe); resident chunks are views
+        pipe = None if dev.is_tensor(first) else dev.HostPipe(layout)
+        flying = deque()
+
+        def put(chunk):
+            if pipe is None or dev.is_tensor(chunk):
+                return layout.to2d(chunk)
+            x2d, ready = pipe.upload(chunk)
+            pipe.compute.wait_event(ready)
+            return x2d, True
+
+        x2d, host = put(first)
         stream.set_state_scaled(x2d, 0)
         fwd, hosts = [stream.forward(x2d)], [host]
         second = next(chunks, None)
         if second is not None:
-            b2d, host_b = layout.to2d(second)
+            b2d, host_b = put(second)
             fwd.append(stream.forward(b2d))
             hosts.append(host_b)
         n = int(np.ceil(pro.shape[axis] / pro.chunksize))
@@ -303,16 +318,27 @@ def sosfiltfilt(pro, sos, axis):
             if nxt is not None:
                 # steady state: forward of chunk idx+2 and backward of chunk
                 # idx share one launch (osz_sosfiltfilt_step)
-                c2d, host_c = layout.to2d(nxt)
+                c2d, host_c = put(nxt)
                 fnew, y = stream.step(c2d, fa, fb)
                 fwd.append(fnew)
                 hosts.append(host_c)
             else:
                 y = stream.backward(fa, fb)
-            yield layout.from2d(y, hosts[0])
+            if pipe is not None and hosts[0]:
+                flying.append(pipe.download(y))
+                while len(flying) > 2:
+                    out, done = flying.popleft()
+                    done.synchronize()
+                    yield pipe.restore(out)
+            else:
+                yield layout.from2d(y, hosts[0])
             fwd.pop(0)
             hosts.pop(0)
             idx += 1
+        while flying:
+            out, done = flying.popleft()
+            done.synchronize()
+            yield pipe.restore(out)
     finally:
         stream.close()
 
@@ -588,9 +614,14 @@ def _spectra_estimatives(pro, fs, nfft, window, overlap, axis, detrend,
     layout = dev.Layout(pro.shape, axis)
     spec = dev.SpecStream(nfft, nfft, stride, coeffs, scale, detrend, mode,
                           layout.nch)
+    pipe = None
     try:
         for arr in _batched(pro, layout.axis, layout.nch):
-            x2d, host = layout.to2d(arr)
+            if dev.is_tensor(arr):
+                x2d, host = layout.to2d(arr)
+            else:
+                pipe = pipe or dev.HostPipe(layout)   # pinned ring + H2D stream
+                x2d, host = pipe.feed(arr), True
             if x2d.shape[1] == 0:
                 continue
             out = spec.push(x2d)               # (nseg, nch, nfreq)

@@ -31,10 +31,16 @@ def psd(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
     layout = dev.Layout(pro.shape, axis_n)
     spec = dev.SpecStream(nfft, nfft, stride, coeffs, scale, detrend,
                           _lib.SPEC_PSD_MEAN, layout.nch)
-    host = True
+    host, pipe = True, None
     try:
         for arr in nm._batched(pro, axis_n, layout.nch):
-            x2d, host = layout.to2d(arr)
+            if dev.is_tensor(arr):
+                x2d, host = layout.to2d(arr)
+            else:
+                # host-fed: the next piece is staged (pinned ring, H2D stream)
+                # while this one's segments are transformed
+                pipe = pipe or dev.HostPipe(layout)
+                x2d, host = pipe.feed(arr), True
             if x2d.shape[1]:
                 spec.push(x2d)
         # device input: the average is taken on the device and stays there
