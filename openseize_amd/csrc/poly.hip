@@ -87,13 +87,21 @@ struct PolyBlockArgs {
 // ONE: L == 1 (decimation), a single class per tile.  NT threads produce
 // NT * kPolyR outputs per class: large M shrinks the tile so that the window
 // (M phase streams) still fits three workgroups' worth of LDS.
-template <bool ONE, int NT>
-__global__ __launch_bounds__(NT, 3) void poly_block_kernel(PolyBlockArgs b) {
+// EG = 2 (decimators whose window leaves room for a 128- or 64-thread tile only:
+// M >= 8 or so): twice the threads on the same tile, the two halves of the
+// workgroup take the lower and the upper half of the M phase streams and their
+// partial sums meet in LDS -- the waves per CU that the large window took away.
+template <bool ONE, int NT, int EG = 1>
+__global__ __launch_bounds__(NT * EG, 3) void poly_block_kernel(PolyBlockArgs b) {
     constexpr int NJ = NT * kPolyR;
+    constexpr int NTH = NT * EG;                    // threads of the workgroup
+    static_assert(EG == 1 || ONE, "phase groups: decimators only");
     extern __shared__ double win[];
     const PolyArgs &a = b.p;
     const int c = blockIdx.y;
-    const int t = threadIdx.x;
+    const int tw = threadIdx.x;                     // staging / store index
+    const int t = EG == 1 ? tw : tw % NT;           // output block
+    const int eg = EG == 1 ? 0 : tw / NT;           // phase group (wave uniform: NT % 64 == 0)
     const double *xr = a.x + (int64_t)c * a.ldx;
     const double *hr = a.hist + (int64_t)c * a.H;
     double *yr = a.y + (int64_t)c * a.ldy;
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(NT, 3) void poly_block_kernel(PolyBlockArgs b) {
     double *outbuf = ONE ? win : win + a.M * b.se;      // L = 1: reuses the window
     const int nstream = NJ + b.apad;               // entries per phase stream
     const int wtot = nstream * a.M;
-    const int dq = NT / a.M, dr = NT - dq * a.M;
+    const int dq = NTH / a.M, dr = NTH - dq * a.M;
     for (int cls = 0; cls < L; ++cls) {
         const int64_t jf = J0 + cls;                    // first output of this class in the tile
         const int r = ONE ? 0 : (int)(jf % L);                  // its residue j mod L
@@ -116,26 +124,26 @@ __global__ __launch_bounds__(NT, 3) void poly_block_kernel(PolyBlockArgs b) {
         const int64_t i0 = itop - (msub - 1);           // window: inputs [i0, i0 + wtot)
         // staging walks w = t, t + NT, ...: (i, e) = (w div M, w mod M) advance by
         // (NT div M, NT mod M) with a carry, no division in the loop
-        int i = t / a.M, e = t - i * a.M;
+        int i = tw / a.M, e = tw - i * a.M;
         if (i0 >= a.nin && i0 + wtot <= a.navail) {
             // the whole window lies in the current chunk: plain coalesced loads,
             // kPolyBatch in flight per thread, issued back to back, then placed
             const double *src = xr + (i0 - a.nin);
-            for (int w = t; w < wtot; w += kPolyBatch * NT) {
+            for (int w = tw; w < wtot; w += kPolyBatch * NTH) {
                 double v[kPolyBatch];
 #pragma unroll
                 for (int u = 0; u < kPolyBatch; ++u)
-                    v[u] = (w + NT * u < wtot) ? src[w + NT * u] : 0.0;
+                    v[u] = (w + NTH * u < wtot) ? src[w + NTH * u] : 0.0;
 #pragma unroll
                 for (int u = 0; u < kPolyBatch; ++u) {
-                    if (w + NT * u < wtot) win[e * b.se + poly_pad(i)] = v[u];
+                    if (w + NTH * u < wtot) win[e * b.se + poly_pad(i)] = v[u];
                     i += dq;
                     e += dr;
                     if (e >= a.M) { e -= a.M; ++i; }
                 }
             }
         } else {
-            for (int w = t; w < wtot; w += NT) {
+            for (int w = tw; w < wtot; w += NTH) {
                 const int64_t g = i0 + w;
                 double v = 0.0;
                 if (g >= 0 && g < a.navail)
@@ -151,7 +159,8 @@ __global__ __launch_bounds__(NT, 3) void poly_block_kernel(PolyBlockArgs b) {
 #pragma unroll
         for (int s = 0; s < kPolyR; ++s) acc[s] = 0.0;
         const double *Gr = b.G + (int64_t)r * a.M * b.apad;
-        for (int ph = 0; ph < a.M; ++ph) {
+        const int ph0 = EG == 1 ? 0 : (eg * a.M) / EG, ph1 = EG == 1 ? a.M : ((eg + 1) * a.M) / EG;
+        for (int ph = ph0; ph < ph1; ++ph) {
             const double *ge = Gr + (int64_t)ph * b.apad;
             const double *xe = win + ph * b.se + 5 * t;     // poly_pad(4 t) = 5 t
             for (int a0 = 0; a0 < b.apad; a0 += kPolyBlk) {
@@ -168,13 +177,24 @@ __global__ __launch_bounds__(NT, 3) void poly_block_kernel(PolyBlockArgs b) {
             }
         }
         __syncthreads();                                // everyone is done with the window
+        if (EG == 1) {
 #pragma unroll
-        for (int s = 0; s < kPolyR; ++s) outbuf[cls + L * (kPolyR * t + s)] = acc[s];
+            for (int s = 0; s < kPolyR; ++s) outbuf[cls + L * (kPolyR * t + s)] = acc[s];
+        } else {
+            // partial sums of phase group eg: outbuf[eg][output]
+#pragma unroll
+            for (int s = 0; s < kPolyR; ++s) outbuf[eg * NJ + kPolyR * t + s] = acc[s];
+        }
     }
     __syncthreads();
     const int64_t left = a.j1 - J0;
     const int ntile = (int)(left < (int64_t)NJ * L ? left : (int64_t)NJ * L);
-    for (int o = t; o < ntile; o += NT) yr[(J0 - a.j0) + o] = outbuf[o];
+    for (int o = tw; o < ntile; o += NTH) {
+        double v = outbuf[o];
+#pragma unroll
+        for (int g = 1; g < EG; ++g) v += outbuf[g * NJ + o];
+        yr[(J0 - a.j0) + o] = v;
+    }
 }
 
 // newhist = last H samples of (hist ++ x[0:n])
@@ -365,13 +385,25 @@ int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n, int fin
             static const kern_t kerns[2][3] = {
                 {poly_block_kernel<false, 256>, poly_block_kernel<false, 128>, poly_block_kernel<false, 64>},
                 {poly_block_kernel<true, 256>, poly_block_kernel<true, 128>, poly_block_kernel<true, 64>}};
-            const kern_t kern = kerns[h->L == 1 ? 1 : 0][h->nt == 256 ? 0 : h->nt == 128 ? 1 : 2];
+            // decimators on a 128- or 64-thread tile: two phase groups (OSZ_POLY_EG=1: off)
+            static const kern_t kerns2[2][2] = {
+                {poly_block_kernel<true, 128, 2>, poly_block_kernel<true, 64, 2>},
+                {poly_block_kernel<true, 128, 4>, poly_block_kernel<true, 64, 4>}};
+            static int eg_on = -1;
+            if (eg_on < 0) {
+                const char *e = getenv("OSZ_POLY_EG");
+                eg_on = e ? atoi(e) : 2;
+            }
+            const int eg = (h->L == 1 && h->nt <= 128) ? (eg_on >= 4 && h->M >= 4 ? 4 : eg_on >= 2 && h->M >= 2 ? 2 : 1) : 1;
+            const bool split = eg > 1;
+            const kern_t kern = split ? kerns2[eg == 4 ? 1 : 0][h->nt == 128 ? 0 : 1]
+                                      : kerns[h->L == 1 ? 1 : 0][h->nt == 256 ? 0 : h->nt == 128 ? 1 : 2];
             OSZ_DYN_LDS(kern, 64 * 1024);
             const int64_t per = (int64_t)h->nt * kPolyR * h->L;
             const int64_t bx = (cnt + per - 1) / per;
             KernelTimer kt("poly_block", st);
             hipLaunchKernelGGL(kern,
-                               dim3((unsigned)bx, h->nch), dim3(h->nt), blds, st, b);
+                               dim3((unsigned)bx, h->nch), dim3(eg * h->nt), blds, st, b);
         } else {   // very large M: the window of even a 64-thread tile exceeds LDS
             int64_t bx = (cnt + 255) / 256;
             if (bx > 4096) bx = 4096;

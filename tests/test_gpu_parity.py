@@ -311,6 +311,29 @@ def test_resample_wrappers(osz, golden):
         downsample(x[:, :5], 5, 5000, chunksize=1000)
 
 
+def test_downsample_every_tile_shape(osz):
+    """Decimators from M = 2 to M = 40: the window of M phase streams picks the
+    256-, 128- or 64-thread tile and, on the two smaller ones, the kernel with
+    two phase groups per workgroup -- all against whole-array
+    scipy.signal.resample_poly with the same filter (what the reference calls
+    per chunk, core/numerical.py:610)."""
+    import scipy.signal as sps
+    from oracle import oracle as orc
+    from openseize_amd.filtering.fir import Kaiser
+    from openseize_amd.resampling.resampling import downsample
+    rng = np.random.default_rng(41)
+    fs = 20480.0
+    x = rng.standard_normal((3, 300007))
+    for M in (2, 3, 7, 8, 10, 13, 16, 25, 40):
+        cutoff = fs / (2 * M)
+        h = Kaiser(cutoff - cutoff / 10, cutoff + cutoff / 10, fs, gpass=0.1, gstop=40).coeffs
+        want = orc.polyphase_resample(x, 1, M, h)
+        assert rel_err(want, sps.resample_poly(x, 1, M, axis=-1, window=h)) < RTOL
+        for cs in (300007, 65536 + 11):
+            y = downsample(x, M, fs, chunksize=cs, axis=-1)
+            assert rel_err(y, want) < RTOL, (M, cs, len(h))
+
+
 # ------------------------------------------------------------------ spectra
 def test_periodogram_golden(osz, golden):
     g = golden("g6_periodogram.npz")
