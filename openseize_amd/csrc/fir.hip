@@ -30,6 +30,7 @@
 #include "common.h"
 #include "fft4096.h"
 #include "fir_pair.h"
+#include "fir_pf_table.h"
 #include "handles.h"
 
 namespace osz {
@@ -39,7 +40,7 @@ namespace osz {
 // and the hot loop then issues no table load at all (-3.5 % time against
 // loading 14 of them per pair before the second barrier, HPRE = 14; HPRE = 0
 // loads them where they are used).
-template <int NR, int HPRE = -1, bool PF = false>
+template <int NR, int HPRE = -1, int PF = 0>
 __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     extern __shared__ fft::cube::C2 cube_lds[];
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     for (int q = 0; q < 12; ++q) P.stamp_acc[q] = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.stamp_last)::"memory");
 #endif
-    if (PF) {
+    if (PF != 0) {
         // the last whole pair of the run requests itself again (unused, in bounds)
         if (blk < P.blk1 && P.whole(blk)) {
             P.next_blk = (blk + 2 < P.blk1 && P.whole(blk + 2)) ? blk + 2 : blk;
@@ -369,18 +370,29 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
         static const kern_t kerns0[8] = {fir_oa_kernel<8>,  fir_oa_kernel<9>,  fir_oa_kernel<10>,
                                          fir_oa_kernel<11>, fir_oa_kernel<12>, fir_oa_kernel<13>,
                                          fir_oa_kernel<14>, fir_oa_kernel<15>};
-        // next pair's samples requested behind the spectrum multiply (see FirPair::nx)
+        // 1: next pair's samples requested behind the spectrum multiply (FirPair::nx);
+        // 2: and the next pair's spectrum ahead of this pair's stores (FirPair::Hn)
         static const kern_t kerns1[8] = {
-            fir_oa_kernel<8, 16, true>,  fir_oa_kernel<9, 16, true>,  fir_oa_kernel<10, 16, true>,
-            fir_oa_kernel<11, 16, true>, fir_oa_kernel<12, 16, true>, fir_oa_kernel<13, 16, true>,
-            fir_oa_kernel<14, 16, true>, fir_oa_kernel<15, 16, true>};
-        static int pf = -1;
-        if (pf < 0) {
+            fir_oa_kernel<8, 16, 1>,  fir_oa_kernel<9, 16, 1>,  fir_oa_kernel<10, 16, 1>,
+            fir_oa_kernel<11, 16, 1>, fir_oa_kernel<12, 16, 1>, fir_oa_kernel<13, 16, 1>,
+            fir_oa_kernel<14, 16, 1>, fir_oa_kernel<15, 16, 1>};
+        static const kern_t kerns2[8] = {
+            fir_oa_kernel<8, 16, 2>,  fir_oa_kernel<9, 16, 2>,  fir_oa_kernel<10, 16, 2>,
+            fir_oa_kernel<11, 16, 2>, fir_oa_kernel<12, 16, 2>, fir_oa_kernel<13, 16, 2>,
+            fir_oa_kernel<14, 16, 2>, fir_oa_kernel<15, 16, 2>};
+        // Which variant a block height runs by default: the deepest one whose
+        // registers with a load in flight the compiler neither spills nor reloads
+        // (benchmarks/check_async_regions.py on the assembly of THIS build;
+        // tests/test_fir_async.py fails when the table and the assembly disagree).
+        static const int kDefaultPf[8] = OSZ_FIR_PF_TABLE;
+        static int pf_env = -2;
+        if (pf_env == -2) {
             const char *e = getenv("OSZ_FIR_PF");
-            pf = e ? atoi(e) : 1;   // measured: 1.086 -> 1.049 ms on the BASELINE chunk
+            pf_env = e ? atoi(e) : -1;
         }
-        const kern_t *kerns = pf ? kerns1 : kerns0;
         const int nr = pt.step / 256;
+        const int pf = pf_env >= 0 ? pf_env : kDefaultPf[nr - 8];
+        const kern_t *kerns = pf == 2 ? kerns2 : pf == 1 ? kerns1 : kerns0;
         size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS;
         if (const char *e = getenv("OSZ_FIR_LDS_PAD")) lds += (size_t)atoi(e) * 1024;   // occupancy experiments
         OSZ_DYN_LDS(kerns[nr - 8], lds);

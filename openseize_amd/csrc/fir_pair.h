@@ -75,8 +75,9 @@ __host__ __device__ __forceinline__ int64_t fir_run_start(int64_t r, int64_t nbl
 // registers, -3.4 % --, twiddles loaded from the tables per pass (+13 %),
 // running the FIR of chunk k+1 beside the IIR step of chunk k on a second
 // stream (+5 %, benchmarks/overlap_probe.py).
-template <int NR, int HPRE, bool PF = false>
+template <int NR, int HPRE, int PF = 0>
 struct FirPair {
+    static constexpr bool PF2 = PF == 2;   // PF = 1: samples ahead only; 2: spectrum ahead as well
     using C2 = fft::cube::C2;
     static constexpr int NT_ = 16 - NR;   // register rows of the tail (wm1 <= 256 NT_)
 
@@ -97,6 +98,24 @@ struct FirPair {
     // the next pair does not wait for those stores (one vmcnt on gfx950).
     double nx[PF ? 2 * NR : 1];
     int64_t next_blk = 0;
+    // PF, whole pairs: the filter spectrum of the NEXT pair, requested after
+    // inverse pass 1 and BEFORE this pair's stores -- requested behind them (as
+    // the per-pair spectrum of HPRE does) it cannot be seen to land before they
+    // have drained: one in-order counter (benchmarks/fir_stamps: 2800 ticks of
+    // a 20 000-tick pair).  Same values every pair; the point is WHEN they
+    // occupy registers: not during the inverse passes, where nx lives.
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    d2_t Hn[PF2 ? 16 : 1];
+
+    __device__ __forceinline__ void request_spectrum() {
+        int tt = t;
+        asm volatile("" : "+v"(tt));   // per pair: hoisted, 16 addresses would spill
+#pragma unroll
+        for (int r = 0; r < (PF2 ? 16 : 0); ++r) {
+            const double *ph = a.H + 2 * (tt + 256 * fft::dr(r));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Hn[PF2 ? r : 0]) : "v"(ph) : "memory");
+        }
+    }
 
     // The requests are inline assembly, outside the compiler's vmcnt bookkeeping:
     // at the loop top it would otherwise wait vmcnt(0..3), i.e. also for the
@@ -123,6 +142,8 @@ struct FirPair {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NR) : "memory");
 #pragma unroll
         for (int j = 0; j < (PF ? 2 * NR : 0); ++j) asm volatile("" : "+v"(nx[PF ? j : 0]));
+#pragma unroll
+        for (int r = 0; r < (PF2 ? 16 : 0); ++r) asm volatile("" : "+v"(Hn[PF2 ? r : 0]));
     }
 #ifdef OSZ_FIR_STAMPS
     unsigned long long stamp_acc[12], stamp_last;
@@ -149,7 +170,7 @@ struct FirPair {
         // HPRE > 0: that many filter-spectrum bins are requested before the barrier
         double hr[HPRE > 0 ? HPRE : 1], hi[HPRE > 0 ? HPRE : 1];
 #pragma unroll
-        for (int r = 0; r < (HPRE > 0 ? HPRE : 0); ++r) {
+        for (int r = 0; r < ((HPRE > 0 && !(PF2 && REQ)) ? HPRE : 0); ++r) {
             const int k = t + 256 * fft::dr(r);
             hr[r] = a.H[2 * k];
             hi[r] = a.H[2 * k + 1];
@@ -162,7 +183,8 @@ struct FirPair {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = t + 256 * fft::dr(r);
-            if (HPRE < 0) fft::cube::cmul(re[r], im[r], Hr[HPRE < 0 ? r : 0], Hi[HPRE < 0 ? r : 0]);
+            if (PF2 && REQ) fft::cube::cmul(re[r], im[r], Hn[PF2 ? r : 0].x, Hn[PF2 ? r : 0].y);
+            else if (HPRE < 0) fft::cube::cmul(re[r], im[r], Hr[HPRE < 0 ? r : 0], Hi[HPRE < 0 ? r : 0]);
             else if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
             else fft::cube::cmul(re[r], im[r], a.H[2 * k], a.H[2 * k + 1]);
         }
@@ -189,6 +211,9 @@ struct FirPair {
         const int64_t start_a = blk * a.step;
         double re[16], im[16];
         const double *pa = xr + start_a + t;
+        // first whole pair of the run: its spectrum goes out ahead of its (compiler
+        // tracked) sample loads -- older than them, landed when they have
+        if (PF2 && !FROM_NX) request_spectrum();
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (PF && FROM_NX) {
@@ -198,6 +223,12 @@ struct FirPair {
                 re[j] = j < NR ? pa[256 * j] : 0.0;
                 im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
             }
+        }
+        if (PF2 && !FROM_NX) {
+            // first whole pair: everything requested so far has landed before pass 1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < (PF2 ? 16 : 0); ++r) asm volatile("" : "+v"(Hn[PF2 ? r : 0]));
         }
         OSZ_FSTAMP(0);   // sample loads issued (and the previous pair's stores)
         transform<true>(re, im);
@@ -211,6 +242,7 @@ struct FirPair {
                 cr[j] = im[j + NR];
             }
         }
+        if (PF2) request_spectrum();   // the next pair's, ahead of the stores
         double *qa = yr + (start_a - a.skip) + t;
         if (a.accum) {   // a piece of a partitioned filter adds into the work row
 #pragma unroll
@@ -225,8 +257,8 @@ struct FirPair {
                 qa[256 * (j + NR)] = im[j];
             }
         }
-        wait_next();
         OSZ_FSTAMP(11);  // inverse pass 1 + overlap add + stores issued
+        wait_next();     // (the stamped build books this wait under the next pair's slot 0)
     }
 
     // any pair: ragged lengths, left cut, accumulate
