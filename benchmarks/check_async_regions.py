@@ -4,8 +4,9 @@ assembly hipcc emits for fir.hip:
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only -o fir.s openseize_amd/csrc/fir.hip
     python benchmarks/check_async_regions.py fir.s
 
-Those kernels request global loads by inline assembly and wait for them with a
-hand-placed `s_waitcnt vmcnt(2 NR)` (or `vmcnt(0)`) much later; the compiler
+Those kernels request global loads by inline assembly (tagged `; osz:nx`, the
+next pair's samples, or `; osz:hn`, its filter spectrum) and wait for them with
+hand-placed `s_waitcnt vmcnt(N) ; osz:<tag>` much later; the compiler
 believes the destination registers hold their values from the moment of the
 request.  That is only safe while it leaves them alone: between a request and
 its wait no instruction may write a destination register (a reload, a move, a
@@ -38,6 +39,7 @@ def parse(lines, nr):
     """-> blocks: list of dict(label, ins=[(lineno, kind, regs, text)], succ=[labels or 'next'])"""
     blocks = [{"label": None, "ins": [], "succ": None}]
     in_asm = False
+    del nr   # the waits name what they complete; the counts are the kernel's business
     for no, line in lines:
         m = LABEL.match(line)
         if m:
@@ -52,6 +54,7 @@ def parse(lines, nr):
             in_asm = False
             continue
         body = line.split(";")[0].strip()
+        tags = frozenset(re.findall(r"osz:(\w+)", line))
         if not body or body.endswith(":") or body.startswith("."):
             continue
         ops = body.split(None, 1)
@@ -62,9 +65,9 @@ def parse(lines, nr):
             blocks.append({"label": None, "ins": [], "succ": None})
             cur = blocks[-1]
         if in_asm and op.startswith("global_load"):
-            cur["ins"].append((no, "request", regs(args[0]), body))
-        elif in_asm and op == "s_waitcnt" and (f"vmcnt({2 * nr})" in body or "vmcnt(0)" in body):
-            cur["ins"].append((no, "wait", frozenset(), body))
+            cur["ins"].append((no, "request", frozenset((r, t) for r in regs(args[0]) for t in tags), body))
+        elif in_asm and op == "s_waitcnt":
+            cur["ins"].append((no, "wait", tags, body))
         elif in_asm:
             continue
         elif op == "s_branch":
@@ -104,11 +107,11 @@ def analyse(blocks):
             if kind == "request":
                 flying = flying | rg
             elif kind == "wait":
-                flying = frozenset()
+                flying = frozenset(f for f in flying if f[1] not in rg)
             elif kind == "end":
                 if flying and report is not None:
                     report.append(f"line {no}: loads still in flight at s_endpgm")
-            elif rg & flying and report is not None:
+            elif rg & {f[0] for f in flying} and report is not None:
                 what = "spill of" if kind == "read" else "write to"
                 report.append(f"line {no}: {what} a register with a load in flight: {text}")
         return flying

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
             P.next_blk = (blk + 2 < P.blk1 && P.whole(blk + 2)) ? blk + 2 : blk;
             P.template fast_pair<true>(blk);
         }
+        P.drain_spectrum();
     } else {
         for (; blk < P.blk1 && P.whole(blk); blk += 2) P.fast_pair(blk);
     }

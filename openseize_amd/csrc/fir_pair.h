@@ -113,7 +113,7 @@ struct FirPair {
 #pragma unroll
         for (int r = 0; r < (PF2 ? 16 : 0); ++r) {
             const double *ph = a.H + 2 * (tt + 256 * fft::dr(r));
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Hn[PF2 ? r : 0]) : "v"(ph) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off ; osz:hn" : "=v"(Hn[PF2 ? r : 0]) : "v"(ph) : "memory");
         }
     }
 
@@ -124,6 +124,9 @@ struct FirPair {
     // operations (this pair's stores; with accum also its 2 NR loads of y) are
     // outstanding: wait_next() after the stores.  Untracked OLDER operations
     // only make the compiler's own waits more conservative, never too short.
+    // (Spreading the requests of a pair over the three inverse passes instead of
+    // one burst behind the multiply -- a burst holds the wave at the issue port
+    // for ~120 cycles per load, benchmarks/fir_stamps -- measured 2 % SLOWER.)
     __device__ __forceinline__ void request_next(int64_t blk) {
         int64_t off = blk * a.step + t;
         asm volatile("" : "+v"(off));   // per pair: hoisted, 2 NR addresses would spill
@@ -131,17 +134,33 @@ struct FirPair {
 #pragma unroll
         for (int j = 0; j < (PF ? 2 * NR : 0); j += 2) {
             const double *pj = pa + 256 * j;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nx[PF ? j : 0]) : "v"(pj) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off ; osz:nx" : "=v"(nx[PF ? j : 0]) : "v"(pj) : "memory");
             if (j + 1 < 2 * NR)
-                asm volatile("global_load_dwordx2 %0, %1, off offset:2048"
+                asm volatile("global_load_dwordx2 %0, %1, off offset:2048 ; osz:nx"
                              : "=v"(nx[PF ? j + 1 : 0]) : "v"(pj) : "memory");
         }
     }
+    // after the pair's stores: younger than nx are those 2 NR stores and, in
+    // variant 2, the 16 spectrum requests issued just before them
     __device__ __forceinline__ void wait_next() {
         if (!PF) return;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NR) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) ; osz:nx" ::"n"(2 * NR + (PF2 ? 16 : 0)) : "memory");
 #pragma unroll
         for (int j = 0; j < (PF ? 2 * NR : 0); ++j) asm volatile("" : "+v"(nx[PF ? j : 0]));
+    }
+    // variant 2, after the last whole pair of the run: its request for a next
+    // pair's spectrum has no taker
+    __device__ __forceinline__ void drain_spectrum() {
+        if (!PF2) return;
+        asm volatile("s_waitcnt vmcnt(0) ; osz:hn osz:nx" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < (PF2 ? 16 : 0); ++r) asm volatile("" : "+v"(Hn[PF2 ? r : 0]));
+    }
+    // variant 2, before the spectrum multiply: younger than the spectrum requests
+    // are the previous pair's 2 NR stores (nothing else is issued in between)
+    __device__ __forceinline__ void wait_spectrum() {
+        if (!PF2) return;
+        asm volatile("s_waitcnt vmcnt(%0) ; osz:hn" ::"n"(2 * NR) : "memory");
 #pragma unroll
         for (int r = 0; r < (PF2 ? 16 : 0); ++r) asm volatile("" : "+v"(Hn[PF2 ? r : 0]));
     }
@@ -180,6 +199,7 @@ struct FirPair {
         OSZ_FSTAMP(4);   // barrier 2
         fft::cube::f3(t, re, im, L);
         OSZ_FSTAMP(5);   // pass 3
+        if (PF2 && REQ) wait_spectrum();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = t + 256 * fft::dr(r);
@@ -188,7 +208,8 @@ struct FirPair {
             else if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
             else fft::cube::cmul(re[r], im[r], a.H[2 * k], a.H[2 * k + 1]);
         }
-        if (PF && REQ) request_next(next_blk);   // unconditional: nx must be dead above this line
+        // unconditional requests: nx must be dead above this line
+        if (PF && REQ) request_next(next_blk);
         OSZ_FSTAMP(6);   // filter spectrum: loads + multiply
         fft::cube::i3(t, re, im, L);
         OSZ_FSTAMP(7);   // inverse pass 3
@@ -226,7 +247,7 @@ struct FirPair {
         }
         if (PF2 && !FROM_NX) {
             // first whole pair: everything requested so far has landed before pass 1
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) ; osz:hn" ::: "memory");
 #pragma unroll
             for (int r = 0; r < (PF2 ? 16 : 0); ++r) asm volatile("" : "+v"(Hn[PF2 ? r : 0]));
         }

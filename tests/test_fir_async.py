@@ -53,8 +53,8 @@ def test_checker_sees_a_planted_violation(tmp_path):
     finally:
         sys.path.pop(0)
     head = "_ZN3osz13fir_oa_kernelILi8ELi16ELi1EEEvNS_7FirArgsE:\n"
-    load = "\t;;#ASMSTART\n\tglobal_load_dwordx2 v[10:11], v[2:3], off\n\t;;#ASMEND\n"
-    wait = "\t;;#ASMSTART\n\ts_waitcnt vmcnt(16)\n\t;;#ASMEND\n"
+    load = "\t;;#ASMSTART\n\tglobal_load_dwordx2 v[10:11], v[2:3], off ; osz:nx\n\t;;#ASMEND\n"
+    wait = "\t;;#ASMSTART\n\ts_waitcnt vmcnt(16) ; osz:nx\n\t;;#ASMEND\n"
     tail = "\ts_endpgm\n.Lfunc_end0:\n"
     bad = head + load + "\ts_cbranch_vccnz .LBB0_2\n\tv_mov_b32_e32 v1, 0\n.LBB0_2:\n\tv_add_f64 v[10:11], v[4:5], v[6:7]\n" + wait + tail
     good = head + load + "\ts_cbranch_vccnz .LBB0_2\n\tv_mov_b32_e32 v1, 0\n.LBB0_2:\n" + wait + "\tv_add_f64 v[10:11], v[4:5], v[6:7]\n" + tail
