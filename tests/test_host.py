@@ -124,6 +124,38 @@ def test_fifo_semantics():
     assert np.array_equal(fifo.queue, (a + 10)[:, 1:])
 
 
+def test_fifo_random_puts_match_concatenate_split():
+    """Any sequence of puts (empty ones, pieces larger than chunksize, any axis,
+    large enough for the threaded copy) pops exactly what the reference's
+    concatenate-then-split queue pops (core/queues.py:46-70), and the pops own
+    their memory."""
+    rng = np.random.default_rng(12)
+    for axis, base in ((0, [1, 3, 4]), (1, [3, 1, 2]), (-1, [2, 3, 1]), (-1, [16, 1])):
+        for chunksize, top in ((7, 12), (40000, 70000)):
+            if top > 100 and len(base) == 3:
+                continue
+            fifo = FIFOArray(chunksize, axis)
+            ref, got, want = None, [], []
+            for _ in range(25):
+                shape = list(base)
+                shape[axis] = int(rng.integers(0, top))
+                x = rng.standard_normal(shape)
+                fifo.put(x)
+                if x.size:
+                    ref = x if ref is None or ref.size == 0 else np.concatenate([ref, x], axis)
+                while fifo.full():
+                    got.append(fifo.get())
+                    head, ref = np.split(ref, [chunksize], axis=axis)
+                    want.append(head)
+                assert fifo.qsize() == (0 if ref is None else ref.shape[axis])
+            assert len(got) == len(want) and len(got) > 3
+            assert all(np.array_equal(a, b) for a, b in zip(got, want))
+            if fifo.qsize():
+                assert np.array_equal(fifo.queue, ref)
+            got[0][...] = 0.0                                  # a pop is not a view of a later one
+            assert all(np.array_equal(a, b) for a, b in zip(got[1:], want[1:]))
+
+
 def test_arraytools():
     x = np.arange(24.0).reshape(2, 3, 4)
     assert arraytools.normalize_axis(-1, 3) == 2
