@@ -44,6 +44,11 @@ struct Args {
     int64_t ldx, nseg;
     int stride, nwin, nch, nruns, N, M, npass;
     int radix[kMaxPass];
+    // per pass: how butterflies map to lanes (host: the cheaper of the two under the
+    // ds_read_b128 bank model) and the divisor of that map with its 2^32 reciprocal
+    int blkfast[kMaxPass];      // 0: consecutive lanes walk a block (inner fastest); 1: walk the blocks
+    int div[kMaxPass];          // inner fastest: S; blocks fastest: M / B
+    unsigned inv[kMaxPass];     // ceil(2^32 / div), 0 when div == 1
     double scale;
 };
 
@@ -126,19 +131,17 @@ __device__ __forceinline__ void dft<10>(C2 *v) {
 // One in-place DIF pass of radix R over the M points: blocks of B = R S points,
 // butterfly (blk, inner) on the slots blk B + inner + q S, output q times W_B^(inner q).
 template <int R, int NT>
-__device__ __forceinline__ void pass(C2 *z, int t, int M, int S, int tstep, const double *tw) {
+__device__ __forceinline__ void pass(C2 *z, int t, int M, int S, int tstep, const double *tw,
+                                     int blkfast, int div, unsigned inv) {
     const int nb = M / R;
     const int B = R * S;
 #pragma unroll 1
     for (int b = t; b < nb; b += NT) {
-        int blk, inner;
-        if (S == 1) {
-            blk = b;
-            inner = 0;
-        } else {
-            blk = b / S;
-            inner = b - blk * S;
-        }
+        // b = hi * div + lo by multiplication with ceil(2^32 / div) (exact: b, div < 2^16)
+        const int hi = div == 1 ? b : (int)__umulhi((unsigned)b, inv);
+        const int lo = b - hi * div;
+        const int blk = blkfast ? lo : hi;
+        const int inner = blkfast ? hi : lo;
         C2 *p = z + blk * B + inner;
         C2 v[R];
 #pragma unroll
@@ -276,42 +279,54 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
             const int r = a.radix[p];
             const int S = B / r;
             const int tstep = N / B;
-            if (r == 10) pass<10, NT>(z, t, M, S, tstep, a.tw);
-            else if (r == 4) pass<4, NT>(z, t, M, S, tstep, a.tw);
-            else if (r == 5) pass<5, NT>(z, t, M, S, tstep, a.tw);
-            else if (r == 2) pass<2, NT>(z, t, M, S, tstep, a.tw);
-            else pass<3, NT>(z, t, M, S, tstep, a.tw);
+            if (r == 10) pass<10, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
+            else if (r == 4) pass<4, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
+            else if (r == 5) pass<5, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
+            else if (r == 2) pass<2, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
+            else pass<3, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
             B = S;
         }
         __syncthreads();
-        // ---- bins 0 ... M of the real transform (opaque thread index: hoisted out
-        // of the segment loop, the table addresses of all kAcc bins would spill)
+        // ---- bins of the real transform, two per thread and trip: k and M - k come
+        // out of the same two slots, X[k] = E + W^k O and X[M-k] = conj(E - W^k O)
+        // (k = 0: DC and Nyquist out of Z[0]).  Opaque thread index: hoisted out of
+        // the segment loop, the table addresses of all trips would spill.
         asm volatile("" : "+v"(tt));
 #pragma unroll
-        for (int m = 0; m < kAcc; ++m) {
+        for (int m = 0; m < kAcc / 2; ++m) {
             const int k = tt + NT * m;
-            asm volatile("" ::: "memory");   // one bin at a time: hoisted, the loads of all kAcc bins spill
-            if (k <= M) {
-                const int ka = k == M ? 0 : k;
-                const int kb = (k == 0 || k == M) ? 0 : M - k;
-                const C2 za = z[a.pos[ka]], zb = z[a.pos[kb]];
+            asm volatile("" ::: "memory");   // one pair at a time: hoisted, the loads of all trips spill
+            if (2 * k <= M) {
+                const int kb = k == 0 ? 0 : M - k;
+                const C2 za = z[a.pos[k]], zb = z[a.pos[kb]];
                 const double er = 0.5 * (za.re + zb.re), ei = 0.5 * (za.im - zb.im);
                 const double dr = 0.5 * (za.re - zb.re), di = 0.5 * (za.im + zb.im);
                 const double orr = di, oi = -dr;                    // O = -i D
                 const double wr = a.tw[2 * k], wi = a.tw[2 * k + 1];
-                const double xr_ = er + (wr * orr - wi * oi);
-                const double xi_ = ei + (wr * oi + wi * orr);
+                const double pr = wr * orr - wi * oi, pi = wr * oi + wi * orr;   // W^k O
+                const double xr_ = er + pr, xi_ = ei + pi;          // X[k]
+                const double yr_ = er - pr, yi_ = -(ei - pi);       // X[M - k]
+                const int k2 = M - k;                               // second bin (== k when 2 k == M)
                 if (MODE == OSZ_SPEC_DFT_SEGMENTS) {
-                    double *o = (double *)a.out + ((s * a.nch + c) * (int64_t)NF + k) * 2;
-                    o[0] = xr_ * a.scale;
-                    o[1] = xi_ * a.scale;
+                    double *o = (double *)a.out + ((s * a.nch + c) * (int64_t)NF) * 2;
+                    o[2 * k] = xr_ * a.scale;
+                    o[2 * k + 1] = xi_ * a.scale;
+                    if (k2 != k) {
+                        o[2 * k2] = yr_ * a.scale;
+                        o[2 * k2 + 1] = yi_ * a.scale;
+                    }
                 } else {
-                    const bool dbl = (k != 0) && (k != M);
-                    const double pw = (xr_ * xr_ + xi_ * xi_) * (dbl ? 2.0 * s2 : s2);
-                    if (MODE == OSZ_SPEC_PSD_SEGMENTS)
-                        ((double *)a.out)[(s * a.nch + c) * (int64_t)NF + k] = pw;
-                    else
-                        acc[m] += pw;
+                    const double f = k != 0 ? 2.0 * s2 : s2;        // DC and Nyquist (k = 0) are not doubled
+                    const double pw = (xr_ * xr_ + xi_ * xi_) * f;
+                    const double qw = k2 != k ? (yr_ * yr_ + yi_ * yi_) * f : 0.0;
+                    if (MODE == OSZ_SPEC_PSD_SEGMENTS) {
+                        double *o = (double *)a.out + (s * a.nch + c) * (int64_t)NF;
+                        o[k] = pw;
+                        if (k2 != k) o[k2] = qw;
+                    } else {
+                        acc[2 * m] += pw;
+                        acc[2 * m + 1] += qw;
+                    }
                 }
             }
         }
@@ -319,9 +334,12 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
     if (MODE == OSZ_SPEC_PSD_MEAN) {
         double *o = a.partial + ((int64_t)c * a.nruns + run) * NF;
 #pragma unroll
-        for (int m = 0; m < kAcc; ++m) {
+        for (int m = 0; m < kAcc / 2; ++m) {
             const int k = t + NT * m;
-            if (k <= M) o[k] = acc[m];
+            if (2 * k <= M) {
+                o[k] = acc[2 * m];
+                if (M - k != k) o[M - k] = acc[2 * m + 1];
+            }
         }
     }
 }
