@@ -65,6 +65,13 @@ def main():
                 traffic["fir_oa"] = hbm
             elif "sos_kernel" in name and "false, false" in name and hbm > 1e9:
                 traffic["sos_fwd"] = hbm
+            elif "chain_kernel" in name and hbm > 1e9:
+                traffic["chain_fwd"] = hbm
+            elif "sos_split2_kernel<32, 4, true" in name and hbm > 1e9:
+                traffic["sos_bwd_split"] = hbm
+    if "chain_fwd" in traffic and "sos_bwd_split" in traffic:
+        # one osz_chain_step = the fused forward kernel and the backward pass, side by side
+        traffic["chain_step"] = traffic["chain_fwd"] + traffic["sos_bwd_split"]
     traffic["_note"] = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                         "(separate passes), (2*FETCH_SIZE + WRITE_SIZE)*1024; see "
                         f"{tag}_pmc_hbm_traffic.csv and profiles/README.md for the calibration.")

@@ -177,6 +177,31 @@ int osz_fir_flush(osz_fir_t h, double *y, int64_t ldy, int64_t skip,
 int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,
                       int64_t n, double *f, int64_t ldf, void *stream);
 
+/*
+ * One steady-state step of the FIR -> sosfiltfilt chain: osz_chain_forward of the
+ * incoming chunk x -> f on `stream` and, BESIDE it on a stream of the SOS handle's
+ * own, osz_sosfiltfilt_chunk of an earlier forward chunk fa (warmed up over fb, or
+ * NULL) -> y.  The backward pass starts behind everything queued on `stream` before
+ * the call.  f must not alias fa or fb.
+ *   flags = 0: `stream` is ordered behind the backward pass when the call returns --
+ *     one stream-ordered operation for the caller.
+ *   flags = OSZ_CHAIN_DEFER: the backward pass is left running: y, and the right to
+ *     overwrite fa / fb, are the caller's only after the NEXT osz_chain_step or an
+ *     osz_chain_wait on this handle has been queued on `stream`.  The next step
+ *     waits for the pass only if its f overlaps fa or fb (a ring of four forward
+ *     buffers never does).
+ * Replaces, for a FIR producer feeding sosfiltfilt, core/numerical.py:158-298 +
+ * :374-411 of the reference.
+ */
+#define OSZ_CHAIN_DEFER 1
+int osz_chain_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,
+                   int64_t n, double *f, int64_t ldf, const double *fa,
+                   int64_t ldfa, int64_t na, const double *fb, int64_t ldfb,
+                   int64_t nb, double *y, int64_t ldy, int flags, void *stream);
+
+/* `stream` is ordered behind the deferred backward pass of the last osz_chain_step. */
+int osz_chain_wait(osz_sos_t sos, void *stream);
+
 /* ---- K4: polyphase rational resampler --------------------------------- */
 /*
  * Replaces scipy.signal.resample_poly(padded, L, M, window=h) as called at

@@ -460,6 +460,32 @@ def chain_forward(fir, sos, x2d, out=None):
     return f
 
 
+def chain_step(fir, sos, x2d, fa, fb=None, f_out=None, y_out=None, defer=False):
+    """One steady-state step of FIR -> sosfiltfilt (C ABI: osz_chain_step): the
+    fused forward half of chunk ``x2d`` -> f, and beside it, on the SOS
+    handle's own stream, the backward sweep of the earlier forward chunk
+    ``fa`` (warmed up over ``fb``) -> y.  Stream-ordered for the caller; with
+    ``defer`` y (and the right to overwrite fa / fb) is the caller's only after
+    the next ``chain_step`` / ``chain_wait`` on these handles."""
+    n = x2d.shape[1]
+    f = f_out if f_out is not None else torch.empty((fir.nch, n), dtype=torch.float64,
+                                                     device=x2d.device)
+    y = torch.empty_like(fa) if y_out is None else y_out
+    _lib.check(fir.lib.osz_chain_step(
+        fir.h, sos.h, ptr(x2d), x2d.stride(0), n, ptr(f), max(f.stride(0), 1),
+        ptr(fa), fa.stride(0), fa.shape[1],
+        ptr(fb) if fb is not None else None,
+        fb.stride(0) if fb is not None else 0,
+        fb.shape[1] if fb is not None else 0,
+        ptr(y), y.stride(0), _lib.CHAIN_DEFER if defer else 0, stream_ptr()))
+    return f, y
+
+
+def chain_wait(sos):
+    """The current stream is ordered behind a deferred backward pass (osz_chain_wait)."""
+    _lib.check(sos.lib.osz_chain_wait(sos.h, stream_ptr()))
+
+
 class PolyStream(_Handle):
     """One iterator's polyphase resampler state (C ABI: osz_poly_*)."""
     _destroy = "osz_poly_destroy"

@@ -35,6 +35,8 @@ c_i64 = ctypes.c_int64
 c_vp = ctypes.c_void_p
 
 # name -> (restype, argtypes); mirrors include/osz_hip.h one to one
+CHAIN_DEFER = 1
+
 SIGNATURES = {
     "osz_version": (ctypes.c_int, []),
     "osz_last_error": (ctypes.c_char_p, []),
@@ -74,6 +76,10 @@ SIGNATURES = {
                                             c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                                             c_vp, c_i64, c_vp]),
     "osz_chain_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    "osz_chain_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64,
+                                      c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64,
+                                      ctypes.c_int, c_vp]),
+    "osz_chain_wait": (ctypes.c_int, [c_vp, c_vp]),
     "osz_fir_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_dp, ctypes.c_int,
                                       ctypes.c_int]),
     "osz_fir_destroy": (ctypes.c_int, [c_vp]),

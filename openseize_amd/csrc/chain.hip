@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <functional>
+
 #include "common.h"
 #include "fft4096.h"
 #include "fir_pair.h"
@@ -164,18 +166,35 @@ using namespace osz;
 
 extern "C" {
 
-int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, int64_t n,
-                      double *f, int64_t ldf, void *stream) {
+// `between` runs after the head launches and before the fused kernel is queued
+// (osz_chain_step starts the backward pass on its side stream there)
+static int chain_forward_impl(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, int64_t n,
+                              double *f, int64_t ldf, void *stream,
+                              const std::function<int()> &between) {
     OSZ_REQUIRE(fir && sos && x && f, "osz_chain_forward: null argument");
     OSZ_REQUIRE(fir->nch == sos->nch, "osz_chain_forward: %d FIR channels, %d SOS channels",
                 fir->nch, sos->nch);
     OSZ_REQUIRE(n >= 0 && ldx >= n && ldf >= n, "osz_chain_forward: n=%lld ldx=%lld ldf=%lld",
                 (long long)n, (long long)ldx, (long long)ldf);
-    if (n == 0) return OSZ_OK;
+    if (n == 0) return between();
     OSZ_SAME_DEVICE(fir, "osz_chain_forward");
     OSZ_SAME_DEVICE(sos, "osz_chain_forward");
     hipStream_t st = as_stream(stream);
-    int64_t whole = 0;   // samples that go through the fused kernel
+    // The samples that are not whole block pairs go FIRST, through the plain kernels
+    // (FIR into the output rows, then the cascade in place): as the head of the chunk
+    // they are queued before the fused kernel and, in osz_chain_step, before the
+    // backward pass on the other stream.  (Three small launches behind two kernels
+    // that fill the chip wait for a CU with 64 KB of LDS to spare: 0.46 ms instead of
+    // 0.02 ms at 256 x 2^20.  With OSZ_CHAIN_DEFER the previous step's backward pass
+    // may still hold that LDS, so the order alone does not buy the time back.)
+    auto plain = [&](int64_t lo, int64_t hi) -> int {
+        // (osz_sos_forward runs one workgroup per channel when y aliases x: every
+        // tile is read before it is written)
+        int rc = osz_fir_push(fir, x + lo, ldx, hi - lo, f + lo, ldf, 0, stream);
+        if (rc) return rc;
+        return osz_sos_forward(sos, f + lo, ldf, f + lo, ldf, hi - lo, stream);
+    };
+    int64_t whole = 0, head = 0;   // [head, head + whole): the fused kernel's samples
     if (fir->parts.size() == 1 && fir->ntaps >= 2) {
         FirPart &pt = fir->parts[0];
         const int nr = pt.step / 256;
@@ -196,9 +215,20 @@ int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
                 rc = sos_lane_table_for(sos, 2 * nr, &ltab);
                 if (rc) return rc;
             }
+            // an even head keeps the 16-byte alignment of the rows
+            head = n - npairs * pair;
+            if (head & 1) head = 0;
+            if (head > 0) {
+                int rc2 = plain(0, head);
+                if (rc2) return rc2;
+            }
+            {
+                int rc2 = between();
+                if (rc2) return rc2;
+            }
             ChainArgs g{};
-            g.f.x = x;
-            g.f.y = f;
+            g.f.x = x + head;
+            g.f.y = f + head;
             g.f.ldx = ldx;
             g.f.ldy = ldf;
             g.f.n = npairs * pair;
@@ -241,15 +271,109 @@ int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
             whole = npairs * pair;
         }
     }
-    if (whole < n) {
-        // the ragged end (or everything, for shapes the fused kernel does not take):
-        // FIR into the output rows, then the cascade in place (osz_sos_forward runs
-        // one workgroup per channel when y aliases x: every tile is read before it
-        // is written)
-        int rc = osz_fir_push(fir, x + whole, ldx, n - whole, f + whole, ldf, 0, stream);
+    if (whole == 0) {
+        int rc = between();
         if (rc) return rc;
-        rc = osz_sos_forward(sos, f + whole, ldf, f + whole, ldf, n - whole, stream);
+    }
+    if (head + whole < n) {
+        // the ragged end left by an odd head (or everything, for shapes the fused
+        // kernel does not take)
+        int rc = plain(head + whole, n);
         if (rc) return rc;
+    }
+    return OSZ_OK;
+}
+
+int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, int64_t n,
+                      double *f, int64_t ldf, void *stream) {
+    return chain_forward_impl(fir, sos, x, ldx, n, f, ldf, stream, [] { return OSZ_OK; });
+}
+
+// One steady-state step of FIR -> sosfiltfilt.  The fused forward kernel is bound by
+// arithmetic and latency (two waves per SIMD, 2.2 TB/s), the backward pass of an earlier
+// chunk by memory: side by side they fill each other's gaps (2.65-2.70 ms against 2.83 ms
+// for either order on one stream, 256 x 2^20).  The backward pass runs on a stream of the
+// SOS handle's own, behind everything queued on `stream` so far (its inputs fa, fb come
+// from earlier steps).
+//   flags = 0: `stream` is ordered behind the backward pass again before the call
+//     returns -- one stream-ordered operation for the caller, f and y both ready for
+//     whatever it queues next.
+//   flags = OSZ_CHAIN_DEFER: the backward pass is left running; y (and the right to
+//     overwrite fa / fb) belongs to the caller only after the NEXT osz_chain_step or
+//     osz_chain_wait on this handle has been queued.  That next step waits for it only
+//     if it has to: when its forward output f overlaps the chunks the pass reads --
+//     with a ring of four forward buffers it never does, and the backward pass of step
+//     k may finish under the forward kernel of step k + 1.
+int osz_chain_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, int64_t n, double *f,
+                   int64_t ldf, const double *fa, int64_t ldfa, int64_t na, const double *fb,
+                   int64_t ldfb, int64_t nb, double *y, int64_t ldy, int flags, void *stream) {
+    OSZ_REQUIRE(fir && sos && x && f && fa && y, "osz_chain_step: null argument");
+    OSZ_REQUIRE(na >= 1 && ldfa >= na && ldy >= na, "osz_chain_step: bad chunk a");
+    OSZ_REQUIRE(!fb || (nb >= 1 && ldfb >= nb), "osz_chain_step: bad chunk b");
+    OSZ_REQUIRE(n >= 0 && ldf >= n, "osz_chain_step: n=%lld ldf=%lld", (long long)n, (long long)ldf);
+    OSZ_REQUIRE((flags & ~OSZ_CHAIN_DEFER) == 0, "osz_chain_step: unknown flags %d", flags);
+    OSZ_SAME_DEVICE(fir, "osz_chain_step");
+    OSZ_SAME_DEVICE(sos, "osz_chain_step");
+    hipStream_t st = as_stream(stream);
+    if (!sos->side) {
+        const size_t sb = sizeof(double) * (size_t)sos->nsec * sos->nch * 2;
+        OSZ_HIP(hipStreamCreateWithFlags(&sos->side, hipStreamNonBlocking));
+        OSZ_HIP(hipEventCreateWithFlags(&sos->side_go, hipEventDisableTiming));
+        OSZ_HIP(hipEventCreateWithFlags(&sos->side_done[0], hipEventDisableTiming));
+        OSZ_HIP(hipEventCreateWithFlags(&sos->side_done[1], hipEventDisableTiming));
+        OSZ_HIP(hipMalloc(&sos->dtmp_side, sb));
+        OSZ_HIP(hipMalloc(&sos->dcarry_side, sb));
+    }
+    const bool pending = sos->side_busy;          // the deferred pass of the previous step
+    const int prev = sos->side_cur, cur = prev ^ 1;
+    bool waited = false;
+    if (pending) {
+        // before the forward kernel only if its output would land in a chunk that pass reads
+        const double *f0 = f, *f1 = f + ((size_t)(sos->nch - 1) * ldf + n);
+        bool clash = false;
+        for (int q = 0; q < 2; ++q)
+            clash = clash || (sos->side_in[q][0] && f0 < sos->side_in[q][1] && sos->side_in[q][0] < f1);
+        if (clash) {
+            OSZ_HIP(hipStreamWaitEvent(st, sos->side_done[prev], 0));
+            waited = true;
+        }
+        sos->side_busy = false;
+    }
+    int rc;
+    {
+        KernelTimer whole("chain_step", st);
+        // head of the chunk (plain kernels) -> backward pass on the side stream, behind
+        // everything queued on `stream` so far -> fused kernel on `stream`
+        rc = chain_forward_impl(fir, sos, x, ldx, n, f, ldf, stream, [&]() -> int {
+            OSZ_HIP(hipEventRecord(sos->side_go, st));
+            OSZ_HIP(hipStreamWaitEvent(sos->side, sos->side_go, 0));
+            return sosfiltfilt_chunk_on(sos, fa, ldfa, na, fb, ldfb, nb, y, ldy, sos->dtmp_side,
+                                        sos->dcarry_side, sos->side);
+        });
+        OSZ_HIP(hipEventRecord(sos->side_done[cur], sos->side));
+        sos->side_cur = cur;
+        // the previous step's y is the caller's from here on (behind this step's forward kernel)
+        if (pending && !waited) OSZ_HIP(hipStreamWaitEvent(st, sos->side_done[prev], 0));
+        if (rc == OSZ_OK && (flags & OSZ_CHAIN_DEFER)) {
+            sos->side_busy = true;
+            sos->side_in[0][0] = fa;
+            sos->side_in[0][1] = fa + ((size_t)(sos->nch - 1) * ldfa + na);
+            sos->side_in[1][0] = fb;
+            sos->side_in[1][1] = fb ? fb + ((size_t)(sos->nch - 1) * ldfb + nb) : nullptr;
+        } else {
+            // also on failure: the side stream must not run ahead of the caller's
+            OSZ_HIP(hipStreamWaitEvent(st, sos->side_done[cur], 0));
+        }
+    }
+    return rc;
+}
+
+// `stream` is ordered behind the deferred backward pass of the last osz_chain_step.
+int osz_chain_wait(osz_sos_t sos, void *stream) {
+    OSZ_REQUIRE(sos, "osz_chain_wait: null handle");
+    if (sos->side_busy) {
+        OSZ_HIP(hipStreamWaitEvent(as_stream(stream), sos->side_done[sos->side_cur], 0));
+        sos->side_busy = false;
     }
     return OSZ_OK;
 }

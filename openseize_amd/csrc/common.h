@@ -62,16 +62,17 @@ int rccl_allreduce_sum(void *buf, size_t count, bool is_f64, void *comm, hipStre
 // (osz_profile_enable / osz_profile_query): bench.py uses it to get each
 // kernel's average duration live, inside the timed region.
 bool profile_on();
-void profile_begin(const char *name, hipStream_t st);
-void profile_end(hipStream_t st);
+int profile_begin(const char *name, hipStream_t st);
+void profile_end(int rec, hipStream_t st);
 struct KernelTimer {
     hipStream_t st;
     bool on;
+    int rec = -1;
     KernelTimer(const char *name, hipStream_t s) : st(s), on(profile_on()) {
-        if (on) profile_begin(name, st);
+        if (on) rec = profile_begin(name, st);
     }
     ~KernelTimer() {
-        if (on) profile_end(st);
+        if (on) profile_end(rec, st);
     }
 };
 

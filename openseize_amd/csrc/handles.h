@@ -48,6 +48,14 @@ struct osz_sos_s {
     double *dzi;        // device (nsec, 2): sosfilt_zi of this cascade
     int touch;          // tuning knob OSZ_SOS_TOUCH: touch-prefetch of the next tile
     double *dtab2;      // device [nsec][4][66]: A^(T k) per section for sos_body2, or null
+    // osz_chain_step: the backward pass runs beside the fused forward kernel on a
+    // stream of the handle's own, with scratch of its own (created on first use)
+    hipStream_t side;
+    hipEvent_t side_go, side_done[2];     // done: ping-pong, side_cur names the last recorded
+    int side_cur;
+    double *dtmp_side, *dcarry_side;
+    bool side_busy;                       // a deferred backward pass may still be running
+    const double *side_in[2][2];          // [fa, fb][begin, end): what it reads
 };
 
 namespace osz {
@@ -60,4 +68,10 @@ int sos_tables_for(osz_sos_s *h, int T, const SosSection **dsec);
 // lane (sos_tile_full2), built on first use and owned by the handle; *dtab = null
 // when the cascade has more sections than the LDS table holds
 int sos_lane_table_for(osz_sos_s *h, int T, const double **dtab);
+// osz_sosfiltfilt_chunk with the warm-up state and the main/remainder carry in
+// caller-named scratch ((nsec, nch, 2) doubles each): two of them may be in flight
+// on two streams (sos.hip)
+int sosfiltfilt_chunk_on(osz_sos_s *h, const double *fa, int64_t ldfa, int64_t na, const double *fb,
+                         int64_t ldfb, int64_t nb, double *y, int64_t ldy, double *tmp, double *carry,
+                         hipStream_t st);
 }  // namespace osz

@@ -49,7 +49,7 @@ void prof_collect() {
 
 bool profile_on() { return g_prof; }
 
-void profile_begin(const char *name, hipStream_t st) {
+int profile_begin(const char *name, hipStream_t st) {
     int id = -1;
     for (size_t i = 0; i < g_names.size(); ++i)
         if (g_names[i] == name) id = (int)i;
@@ -60,10 +60,13 @@ void profile_begin(const char *name, hipStream_t st) {
     ProfRec r{id, prof_event(), prof_event()};
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
+    return (int)g_recs.size() - 1;
 }
 
-void profile_end(hipStream_t st) {
-    if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, st);
+// rec: what profile_begin returned (timers nest: osz_chain_step brackets two launches
+// that carry timers of their own, on two streams)
+void profile_end(int rec, hipStream_t st) {
+    if (rec >= 0 && rec < (int)g_recs.size()) (void)hipEventRecord(g_recs[rec].b, st);
 }
 
 int current_device(int *dev) {

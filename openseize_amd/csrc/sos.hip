@@ -1098,9 +1098,8 @@ static bool sos_lean() {
 
 // whole-tile pass, cut into time segments when there are too few channels to
 // fill the chip (see sos_split_kernel)
-template <int T, int NW, bool REV>
-static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
-    const int64_t tile = (int64_t)NW * 64 * T;
+// time segments a whole-tile pass of `a` is cut into (1: one workgroup per channel)
+static int64_t sos_plan_segments(const SosArgs &a, int64_t tile, int64_t warm_len) {
     const int64_t ntiles = a.n / tile, pre_tiles = warm_len / tile;
     int64_t nseg = 1;
     static int target_wgs = 0;   // tuning knob OSZ_SOS_WGS (default: 2 or, lean, 3 workgroups per CU)
@@ -1117,6 +1116,14 @@ static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
         const int64_t max_seg = ntiles / (4 * pre_tiles);    // pre-roll <= 25 % extra work
         if (nseg > max_seg) nseg = max_seg;
     }
+    return nseg;
+}
+
+template <int T, int NW, bool REV>
+static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
+    const int64_t tile = (int64_t)NW * 64 * T;
+    const int64_t ntiles = a.n / tile;
+    int64_t nseg = sos_plan_segments(a, tile, warm_len);
     if (nseg <= 1) return sos_launch_one<T, NW, REV, false>(a, st);
     const int64_t seg_tiles = (ntiles + nseg - 1) / nseg;
     nseg = (ntiles + seg_tiles - 1) / seg_tiles;
@@ -1172,6 +1179,7 @@ static int sos_launch_tn(const SosArgs &a0, double *carry, int64_t warm_len, hip
     }
     m.state_out = carry;
     r.state_in = carry;
+    r.prex = nullptr;   // a pre-roll belongs to the launch that runs first
     int rc = sos_launch_main<T, NW, REV>(m, warm_len, st);
     if (rc) return rc;
     return sos_launch_one<T, NW, REV, true>(r, st);
@@ -1200,6 +1208,63 @@ static int sos_launch_dual(const SosArgs &f, const SosArgs &b, hipStream_t st) {
     OSZ_HIP(hipGetLastError());
     return OSZ_OK;
 }
+
+namespace osz {
+int sosfiltfilt_chunk_on(osz_sos_s *h, const double *fa, int64_t ldfa, int64_t na, const double *fb,
+                         int64_t ldfb, int64_t nb, double *y, int64_t ldy, double *tmp, double *carry,
+                         hipStream_t st) {
+    SosArgs a{};
+    a.sec = h->dsec;
+    a.nsec = h->nsec;
+    a.nch = h->nch;
+    a.zi_unit = h->dzi;
+    a.tab2 = h->dtab2;
+    a.touch = h->touch;
+    // The warm-up rides the backward launch as a pre-roll of its first time segment
+    // (sos_body2) when that launch is the trimmed split kernel on whole tiles; a
+    // launch of its own otherwise.  (Beside a kernel that fills the chip --
+    // osz_chain_step -- a tiny separate launch waits a millisecond for a free CU.)
+    const int64_t tile = (int64_t)h->NW * 64 * h->T;
+    bool preroll = false;
+    if (fb && h->T == 32 && h->NW == 4 && sos_lean() && h->dtab2 && !sos_pf() && h->warm_len == tile &&
+        nb >= h->warm_len && na >= 8 * tile) {
+        SosArgs m{};
+        m.nch = h->nch;
+        m.n = (na / tile) * tile;
+        m.x = fa;
+        m.y = y;
+        preroll = sos_plan_segments(m, tile, h->warm_len) >= 2;
+    }
+    if (preroll) {
+        a.prex = fb;
+        a.ldprex = ldfb;
+        a.npre = h->warm_len;
+        a.state_in = nullptr;
+    } else if (fb) {
+        // warm-up over the next chunk: state only (numerical.py:397-399)
+        // only the warm_len samples next to chunk a can influence the state
+        a.x = fb;
+        a.ldx = ldfb;
+        a.n = nb < h->warm_len ? nb : h->warm_len;
+        a.y = nullptr;
+        a.ldy = 0;
+        a.state_in = nullptr;
+        a.state_out = tmp;
+        int rc = sos_launch<true>(a, carry, h->T, h->NW, h->warm_len, st);
+        if (rc) return rc;
+        a.state_in = tmp;
+    } else {
+        a.state_in = nullptr;  // zi_unit * fa[:, na-1]  (numerical.py:408-410)
+    }
+    a.x = fa;
+    a.ldx = ldfa;
+    a.n = na;
+    a.y = y;
+    a.ldy = ldy;
+    a.state_out = nullptr;
+    return sos_launch<true>(a, carry, h->T, h->NW, h->warm_len, st);
+}
+}  // namespace osz
 
 extern "C" {
 
@@ -1237,6 +1302,11 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     OSZ_HIP(hipMemcpy(p->dsec, secs.data(), sizeof(SosSection) * nsec, hipMemcpyHostToDevice));
     OSZ_HIP(hipMemset(p->dstate, 0, sb));
     p->dtab2 = nullptr;
+    p->side = nullptr;
+    p->side_go = p->side_done[0] = p->side_done[1] = nullptr;
+    p->side_cur = 0;
+    p->dtmp_side = p->dcarry_side = nullptr;
+    p->side_busy = false;
     p->touch = 0;
     if (const char *e = getenv("OSZ_SOS_TOUCH")) p->touch = atoi(e);
     {
@@ -1299,6 +1369,12 @@ int osz_sos_destroy(osz_sos_t h) {
     (void)hipFree(h->dcarry);
     (void)hipFree(h->dzi);
     (void)hipFree(h->dtab2);
+    (void)hipFree(h->dtmp_side);
+    (void)hipFree(h->dcarry_side);
+    if (h->side_go) (void)hipEventDestroy(h->side_go);
+    for (int q = 0; q < 2; ++q)
+        if (h->side_done[q]) (void)hipEventDestroy(h->side_done[q]);
+    if (h->side) (void)hipStreamDestroy(h->side);
     delete h;
     return OSZ_OK;
 }
@@ -1490,37 +1566,8 @@ int osz_sosfiltfilt_chunk(osz_sos_t h, const double *fa, int64_t ldfa, int64_t n
     OSZ_REQUIRE(na >= 1 && ldfa >= na && ldy >= na, "osz_sosfiltfilt_chunk: bad chunk a");
     OSZ_REQUIRE(!fb || (nb >= 1 && ldfb >= nb), "osz_sosfiltfilt_chunk: bad chunk b");
     OSZ_SAME_DEVICE(h, "osz_sosfiltfilt_chunk");
-    hipStream_t st = as_stream(stream);
-    SosArgs a{};
-    a.sec = h->dsec;
-    a.nsec = h->nsec;
-    a.nch = h->nch;
-    a.zi_unit = h->dzi;
-    a.tab2 = h->dtab2;
-    a.touch = h->touch;
-    if (fb) {
-        // warm-up over the next chunk: state only (numerical.py:397-399)
-        // only the warm_len samples next to chunk a can influence the state
-        a.x = fb;
-        a.ldx = ldfb;
-        a.n = nb < h->warm_len ? nb : h->warm_len;
-        a.y = nullptr;
-        a.ldy = 0;
-        a.state_in = nullptr;
-        a.state_out = h->dtmp;
-        int rc = sos_launch<true>(a, h->dcarry, h->T, h->NW, h->warm_len, st);
-        if (rc) return rc;
-        a.state_in = h->dtmp;
-    } else {
-        a.state_in = nullptr;  // zi_unit * fa[:, na-1]  (numerical.py:408-410)
-    }
-    a.x = fa;
-    a.ldx = ldfa;
-    a.n = na;
-    a.y = y;
-    a.ldy = ldy;
-    a.state_out = nullptr;
-    return sos_launch<true>(a, h->dcarry, h->T, h->NW, h->warm_len, st);
+    return sosfiltfilt_chunk_on(h, fa, ldfa, na, fb, ldfb, nb, y, ldy, h->dtmp, h->dcarry,
+                                as_stream(stream));
 }
 
 }  // extern "C"

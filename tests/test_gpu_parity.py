@@ -956,3 +956,82 @@ def test_chain_forward_fused(osz):
             assert err < 1e-12, (taps, C, n, k, err)
         assert np.allclose(iir.get_state(), zref, rtol=1e-10, atol=1e-12)
         fir.close(); iir.close()
+
+
+def test_chain_step_overlapped(osz):
+    """osz_chain_step (fused forward half on the caller's stream, backward pass of an
+    earlier chunk beside it on the handle's own) against the single-stream kernel
+    sequence osz_fir_push + osz_sosfiltfilt_step and against the CPU oracle, over a
+    stream of chunks with a three-buffer ring (the next step's forward kernel
+    reuses the buffer the previous backward pass read), ragged last chunk, few and
+    many channels; carried states equal at the end."""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    for taps, C, cs, nchunks, last in ((1024, 256, 6144 * 24, 7, 6144 * 9 + 321),
+                                       (300, 5, 200000, 6, 200000), (2049, 3, 120000, 5, 777)):
+        h = sps.firwin(taps, 0.2)
+        lens = [cs] * (nchunks - 1) + [last]
+        xs, n0 = [], 0
+        for n in lens:
+            xs.append(dev.synth_normal(C, n, seed=31, n0=n0))
+            n0 += n
+        first = (xs[0][:, :1] * float(h[0])).contiguous()     # first sample of the FIR stream
+
+        def run(mode):
+            """'plain': fir.push + iir.step; 'step': osz_chain_step, stream ordered, ring of 3;
+            'defer': osz_chain_step with OSZ_CHAIN_DEFER, ring of 3 (every step clashes with
+            the pass in flight) and of 4 (none does); y taken one step late."""
+            nring = 4 if mode == "defer4" else 3
+            fir, iir = dev.FirStream(h, C), dev.SosStream(sos, C)
+            iir.set_state_scaled(first, 0)
+            ring = [torch.empty((C, cs), dtype=torch.float64, device="cuda") for _ in range(nring)]
+            ys = [torch.empty((C, cs), dtype=torch.float64, device="cuda") for _ in range(2)]
+            fwd, outs, late = [], [], None
+            for k, x in enumerate(xs):
+                buf = ring[k % nring][:, :x.shape[1]]
+                if k < 2:
+                    f = iir.forward(fir.push(x, 0), out=buf) if mode == "plain" else \
+                        dev.chain_forward(fir, iir, x, out=buf)
+                elif mode == "plain":
+                    f, y = iir.step(fir.push(x, 0), fwd[k - 2], fwd[k - 1], f_out=buf)
+                    outs.append(y.clone())
+                elif mode == "step":
+                    f, y = dev.chain_step(fir, iir, x, fwd[k - 2], fwd[k - 1], f_out=buf)
+                    outs.append(y.clone())
+                else:
+                    yb = ys[k % 2][:, :fwd[k - 2].shape[1]]
+                    f, y = dev.chain_step(fir, iir, x, fwd[k - 2], fwd[k - 1], f_out=buf, y_out=yb,
+                                          defer=True)
+                    if late is not None:
+                        outs.append(late.clone())        # the previous step's y: ours now
+                    late = y
+                fwd.append(f)
+            if late is not None:
+                dev.chain_wait(iir)
+                outs.append(late.clone())
+            outs.append(iir.backward(fwd[-2], fwd[-1]).clone())
+            outs.append(iir.backward(fwd[-1], None).clone())
+            state = iir.get_state()
+            fir.close()
+            iir.close()
+            return outs, state
+
+        ref, zr = run("plain")
+        for mode in ("step", "defer3", "defer4"):
+            got, zg = run(mode)
+            assert len(got) == len(ref) == len(xs)
+            for k, (a, b) in enumerate(zip(got, ref)):
+                err = float((a - b).abs().max()) / float(b.abs().max())
+                assert err < 1e-11, (mode, taps, C, k, err)
+            assert np.allclose(zg, zr, rtol=1e-10, atol=1e-12)
+        # three channels against the oracle: the FIR stream (full mode, first N
+        # samples), then the reference's chunk-local forward-backward filter
+        pick = [0, C // 2, C - 1]
+        xh = np.concatenate([x[pick].cpu().numpy() for x in xs], -1)
+        fh = sps.oaconvolve(xh, h[None], axes=-1)[:, :xh.shape[1]]
+        want = orc.sosfiltfilt(fh, sos, cs)
+        gh = np.concatenate([g[pick].cpu().numpy() for g in got], -1)
+        assert rel_err(gh, want) < RTOL, (taps, C)
