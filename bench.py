@@ -281,7 +281,7 @@ def run_chain(args, R, h, sos):
         # k-2 (warmed up over forward chunk k-1); OSZ_CHAIN_DEFER + four forward buffers:
         # the pass may finish under the next step's forward kernel, y is taken one step late
         dev.chain_step(fir, iir, ring[k % len(ring)], fwd[(k - 2) % nf], fwd[(k - 1) % nf],
-                       f_out=fwd[k % nf], y_out=y_out, defer=True)
+                       f_out=fwd[k % nf], y_out=y_out, defer=not args.ordered)
 
     # start of the stream: steady-state init as sosfiltfilt does, then warm up
     iir.set_state_scaled(ring[0], 0)
@@ -459,6 +459,8 @@ def main():
                     help="chain: FIR + forward SOS as one kernel (osz_chain_forward), then the "
                          "backward pass, on ONE stream (the default runs them side by side: "
                          "osz_chain_step)")
+    ap.add_argument("--ordered", action="store_true",
+                    help="chain: osz_chain_step without OSZ_CHAIN_DEFER (every step stream-ordered)")
     ap.add_argument("--unfused", action="store_true",
                     help="chain: the three-launch sequence fir_oa, fir_seam, sos_dual "
                          "(48 B per sample through HBM; the round-1 step)")

@@ -47,7 +47,9 @@ def main():
             dst.write(src.read())
     fetch = counter_means(find(os.path.join(root, "fetch"), "*counter_collection.csv"), "FETCH_SIZE")
     write = counter_means(find(os.path.join(root, "write"), "*counter_collection.csv"), "WRITE_SIZE")
-    traffic = {}
+    # keys measured by an earlier run of another step variant (bench.py --unfused) stay
+    tpath = os.path.join(out, "traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     with open(os.path.join(out, f"{tag}_pmc_hbm_traffic.csv"), "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel", "launches_fetch", "FETCH_SIZE_KB_mean", "launches_write",

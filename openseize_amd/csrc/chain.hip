@@ -203,6 +203,7 @@ static int chain_forward_impl(osz_fir_t fir, osz_sos_t sos, const double *x, int
         const int64_t npairs = n / pair;
         const int64_t pre = (sos->warm_len + wm1 + pair - 1) / pair;
         int64_t nruns = 512 / fir->nch;
+        if (const char *e = getenv("OSZ_CHAIN_WGS")) nruns = atoi(e) / fir->nch;   // tuning knob
         if (nruns < 1) nruns = 1;
         if (pre > 0 && nruns > npairs / (4 * pre)) nruns = npairs / (4 * pre);
         if (nruns < 1) nruns = 1;
