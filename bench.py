@@ -320,7 +320,7 @@ def full_stream_leg(R, ring, h, sos):
     96 chunks (95 x 2^20 + 385 280 samples = 1e8 per channel) of 256 channels
     from the resident synth ring -> FIR(1024, 'same') producer -> sosfiltfilt
     generator, outputs consumed and dropped.  Secondary number: `value` stays
-    the steady-state kernel sequence above."""
+    the steady-state step above."""
     from functools import partial
     from openseize_amd import producer
     from openseize_amd.core import numerical as nm
@@ -345,7 +345,9 @@ def full_stream_leg(R, ring, h, sos):
     assert got == total, (got, total)
     return {"chunks": len(lengths), "samples_per_channel": total, "channels": C,
             "seconds": secs, "Msamples_s": C * total / secs / 1e6,
-            "path": "producer(gen) -> oaconvolve('same') -> GenProducer -> sosfiltfilt, "
+            "path": "producer(gen) -> oaconvolve('same') -> GenProducer -> sosfiltfilt (the public "
+                    "generators; sosfiltfilt recognises the FIR producer and runs one "
+                    "osz_chain_step per chunk, OSZ_CHAIN_API=0: the two generators apart), "
                     "device-resident ring of 3 synthesised chunks"}
 
 

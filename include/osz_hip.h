@@ -111,6 +111,12 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y,
  * y (nch, na) receives the result in natural sample order. The handle's
  * carried forward state is not touched.
  */
+/* Samples of forward chunk i+1 (counted from its start) that the chunk-local
+ * backward warm-up of chunk i reads: beyond them the state has forgotten its start
+ * to below 1e-16 (1 << 62: the whole chunk).  fb / nb of the calls below may be cut
+ * to this length. */
+int64_t osz_sos_warm_len(osz_sos_t h);
+
 /* The warm-up over fb stops once further samples cannot change a float64
  * state: after warmup_len samples, the smallest multiple of the kernel tile
  * with ||M^len||_inf < 1e-18 (M: state-transition matrix of the cascade).

@@ -388,6 +388,11 @@ class SosStream(_Handle):
             x2d.shape[1], stream_ptr()))
         return y
 
+    @property
+    def warm_len(self):
+        """Samples of the next chunk the backward warm-up reads (osz_sos_warm_len)."""
+        return int(self.lib.osz_sos_warm_len(self.h))
+
     def backward(self, fa, fb=None, out=None):
         """Chunk-local backward sweep (osz_sosfiltfilt_chunk)."""
         y = torch.empty_like(fa) if out is None else out

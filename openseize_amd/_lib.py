@@ -80,6 +80,7 @@ SIGNATURES = {
                                       c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64,
                                       ctypes.c_int, c_vp]),
     "osz_chain_wait": (ctypes.c_int, [c_vp, c_vp]),
+    "osz_sos_warm_len": (c_i64, [c_vp]),
     "osz_fir_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_dp, ctypes.c_int,
                                       ctypes.c_int]),
     "osz_fir_destroy": (ctypes.c_int, [c_vp]),

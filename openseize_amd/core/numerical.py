@@ -263,6 +263,161 @@ def sosfilt(pro, sos, axis, zi=None):
         stream.close()
 
 
+def _fir_feeding(pro, axis):
+    """(source producer, taps) when ``pro`` is what ``FIR.__call__`` /
+    ``producer(partial(oaconvolve, source, taps, axis, 'same'), ...)`` builds: a
+    generating producer over ``oaconvolve`` in mode 'same' along the same axis
+    with the source's chunksize; None otherwise."""
+    import os
+    from openseize_amd.core.producer import GenProducer, Producer
+    if os.environ.get("OSZ_CHAIN_API") == "0":     # A/B and tests: the two generators apart
+        return None
+    if not isinstance(pro, GenProducer) or pro.kwargs:
+        return None
+    gen = pro.data
+    if not isinstance(gen, partial) or gen.func is not oaconvolve or gen.keywords:
+        return None
+    if len(gen.args) != 4:
+        return None
+    source, taps, fir_axis, mode = gen.args
+    if not isinstance(source, Producer) or mode != "same":
+        return None
+    ndim = len(pro.shape)
+    if normalize_axis(fir_axis, ndim) != normalize_axis(axis, ndim):
+        return None
+    taps = np.asarray(taps, dtype=np.float64)
+    if taps.ndim != 1 or not 2 <= len(taps) <= 2049 or tuple(source.shape) != tuple(pro.shape):
+        return None
+    if int(source.chunksize) != int(pro.chunksize):
+        return None
+    return source, taps
+
+
+def _sosfiltfilt_after_fir(pro, source, taps, sos):
+    """``sosfiltfilt(oaconvolve(source, taps, 'same'))`` for a device-resident
+    source, chunk for chunk what the two generators yield one after the other
+    (reference core/numerical.py:158-298 feeding :338-411), on the steady-state
+    step of the C ABI: ``osz_chain_step`` -- the fused FIR + forward-cascade kernel
+    of input chunk k with the backward pass of output chunk k-2 beside it.
+
+    The forward stream goes into a ring of four chunks per channel.  'same' drops
+    the first ``lcut = (taps-1)//2`` outputs, so the piece input chunk k produces
+    is output samples [k cs - lcut, (k+1) cs - lcut): pieces are written slot by
+    slot (never across the ring's end), output chunk j is the view ``lcut``
+    columns further on, and the ``lcut`` columns by which the last slot's chunk
+    reaches past the ring are copied behind it when slot 0 is rewritten.
+    Returns None (the caller falls back to the two separate generators) for
+    host-fed sources, short streams, ragged inner chunks."""
+    import torch
+    axis = pro.axis
+    cs, total = int(pro.chunksize), int(pro.shape[axis])
+    wlen = len(taps)
+    lcut, rcut = _oa_cuts(wlen, "same")
+    nchunks = -(-total // cs)
+    if nchunks < 5 or cs < 65536 or total < wlen:
+        return None
+    chunks = iter(source)
+    first = next(chunks, None)
+    if first is None or not (dev.is_tensor(first) and first.is_cuda) or first.shape[axis] != cs:
+        return None
+
+    def run():
+        layout = dev.Layout(pro.shape, axis)
+        C, R = layout.nch, 4
+        fir, iir = dev.FirStream(taps, C), dev.SosStream(sos, C)
+        try:
+            warm = iir.warm_len
+            if warm > cs - lcut:                       # the warm-up would need samples not yet there
+                yield None
+                return
+            yield True
+            shift = lcut + (lcut & 1)                  # even: chunk views keep 16-byte alignment
+            span = R * cs
+            off = shift - lcut                         # piece k starts at column (k % R) cs + off
+            ring = torch.empty((C, span + shift + 2), dtype=torch.float64, device=first.device)
+            # Output sample s lives at column (s + shift) mod span; the columns
+            # [span, span + shift) repeat [0, shift) for the chunk of the last slot.  A
+            # piece written by the kernel into the last slot with off = 1 puts its last
+            # sample at column `span` itself (column 0 is then never read).
+
+            def chunk(j, n):                           # first n samples of output chunk j
+                c0 = (j % R) * cs + shift
+                return ring[:, c0:c0 + n]
+
+            def mend(j):
+                # chunk j in the last slot reaches `shift` columns past the ring
+                if j % R == R - 1 and shift > off:
+                    ring[:, span + off:span + shift].copy_(ring[:, off:shift])
+
+            def store(s0, data):                       # host-placed samples (the overhang)
+                n, c0 = data.shape[1], (s0 + shift) % span
+                part = min(n, span - c0)
+                ring[:, c0:c0 + part].copy_(data[:, :part])
+                if part < n:
+                    ring[:, :n - part].copy_(data[:, part:])
+                    if off:
+                        ring[:, span:span + 1].copy_(data[:, part:part + 1])
+
+            # ---- input chunk 0 on the plain kernels: the left cut, the forward state
+            x0, _ = layout.to2d(first)
+            head = fir.push(x0, lcut)
+            iir.set_state_scaled(head, 0)
+            iir.forward(head, out=ring[:, shift:shift + cs - lcut])
+            produced = cs - lcut                       # output samples in the ring
+            late, k = None, 1
+            for arr in chunks:
+                x2d, _ = layout.to2d(arr)
+                m = x2d.shape[1]
+                if m == 0:
+                    continue
+                if produced + lcut != k * cs or m > cs:
+                    raise RuntimeError("sosfiltfilt after oaconvolve: an inner chunk of the source "
+                                       f"is not chunksize = {cs} long")
+                dst = ring[:, (k % R) * cs + off:(k % R) * cs + off + m]
+                j = k - 2
+                if j >= 0:
+                    mend(j)
+                    y = torch.empty((C, cs), dtype=torch.float64, device=first.device)
+                    dev.chain_step(fir, iir, x2d, chunk(j, cs), chunk(j + 1, cs - lcut), f_out=dst,
+                                   y_out=y, defer=True)
+                    if late is not None:
+                        yield layout.from2d(late, False)   # the previous step's: ours now
+                    late = y
+                else:
+                    dev.chain_forward(fir, iir, x2d, out=dst)
+                produced += m
+                k += 1
+            # ---- the overhang of the convolution: plain kernels, behind the last piece
+            cnt = max(wlen - 1 - rcut, 0)
+            if cnt > 0:
+                store(produced, iir.forward(fir.flush(first.device, skip=0, drop=rcut)))
+                produced += cnt
+            if produced != total:
+                raise RuntimeError(f"sosfiltfilt after oaconvolve: {produced} of {total} samples")
+            dev.chain_wait(iir)
+            if late is not None:
+                yield layout.from2d(late, False)
+            # ---- the chunks the steady state has not reached: plain backward passes
+            for j in range(max(k - 2, 0), nchunks):
+                n = min(cs, total - j * cs)
+                mend(j)
+                fb = None
+                if j + 1 < nchunks:
+                    mend(j + 1)
+                    fb = chunk(j + 1, min(cs, total - (j + 1) * cs))
+                yield layout.from2d(iir.backward(chunk(j, n), fb), False)
+        finally:
+            fir.close()
+            iir.close()
+
+    gen = run()
+    ok = next(gen)                                     # handles exist, the plan holds?
+    if ok is None:
+        gen.close()
+        return None
+    return gen
+
+
 def sosfiltfilt(pro, sos, axis):
     """Forward-backward (zero-phase) cascaded-biquad filter
     (core/numerical.py:338-411) on the device (K2 + K3).
@@ -277,6 +432,13 @@ def sosfiltfilt(pro, sos, axis):
     twice, quirk Q11).
     """
     sos = np.atleast_2d(np.asarray(sos, dtype=np.float64))
+    fused = _fir_feeding(pro, axis)
+    if fused is not None:
+        # a resident FIR producer feeding this filter: the fused steady-state step
+        gen = _sosfiltfilt_after_fir(pro, *fused, sos)
+        if gen is not None:
+            yield from gen
+            return
     layout = dev.Layout(pro.shape, axis)
     stream = dev.SosStream(sos, layout.nch)
     try:

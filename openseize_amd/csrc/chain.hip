@@ -290,6 +290,20 @@ int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
     return chain_forward_impl(fir, sos, x, ldx, n, f, ldf, stream, [] { return OSZ_OK; });
 }
 
+// Do two (nch, n) views, rows ld apart, share an element?  Views of one parent
+// buffer (equal pitch) are compared column-wise -- the chunks of a ring buffer
+// interleave in memory without touching; anything else by its address range.
+static bool views_clash(const double *p, int64_t ldp, int64_t np, const double *q, int64_t ldq,
+                        int64_t nq, int nch) {
+    if (!p || !q || np <= 0 || nq <= 0) return false;
+    const double *p1 = p + ((int64_t)(nch - 1) * ldp + np), *q1 = q + ((int64_t)(nch - 1) * ldq + nq);
+    if (!(p < q1 && q < p1)) return false;
+    if (ldp != ldq || np > ldp || nq > ldq) return true;
+    int64_t e = (q - p) % ldp;                  // q's first column relative to p's, in [0, ld)
+    if (e < 0) e += ldp;
+    return e < np || e + nq > ldp;
+}
+
 // One steady-state step of FIR -> sosfiltfilt.  The fused forward kernel is bound by
 // arithmetic and latency (two waves per SIMD, 2.2 TB/s), the backward pass of an earlier
 // chunk by memory: side by side they fill each other's gaps (2.65-2.70 ms against 2.83 ms
@@ -330,10 +344,10 @@ int osz_chain_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, i
     bool waited = false;
     if (pending) {
         // before the forward kernel only if its output would land in a chunk that pass reads
-        const double *f0 = f, *f1 = f + ((size_t)(sos->nch - 1) * ldf + n);
         bool clash = false;
         for (int q = 0; q < 2; ++q)
-            clash = clash || (sos->side_in[q][0] && f0 < sos->side_in[q][1] && sos->side_in[q][0] < f1);
+            clash = clash || views_clash(sos->side_in[q], sos->side_ld[q], sos->side_n[q], f, ldf, n,
+                                         sos->nch);
         if (clash) {
             OSZ_HIP(hipStreamWaitEvent(st, sos->side_done[prev], 0));
             waited = true;
@@ -357,10 +371,12 @@ int osz_chain_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, i
         if (pending && !waited) OSZ_HIP(hipStreamWaitEvent(st, sos->side_done[prev], 0));
         if (rc == OSZ_OK && (flags & OSZ_CHAIN_DEFER)) {
             sos->side_busy = true;
-            sos->side_in[0][0] = fa;
-            sos->side_in[0][1] = fa + ((size_t)(sos->nch - 1) * ldfa + na);
-            sos->side_in[1][0] = fb;
-            sos->side_in[1][1] = fb ? fb + ((size_t)(sos->nch - 1) * ldfb + nb) : nullptr;
+            sos->side_in[0] = fa;
+            sos->side_ld[0] = ldfa;
+            sos->side_n[0] = na;
+            sos->side_in[1] = fb;
+            sos->side_ld[1] = ldfb;
+            sos->side_n[1] = fb ? nb : 0;
         } else {
             // also on failure: the side stream must not run ahead of the caller's
             OSZ_HIP(hipStreamWaitEvent(st, sos->side_done[cur], 0));

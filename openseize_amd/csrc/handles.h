@@ -55,7 +55,8 @@ struct osz_sos_s {
     int side_cur;
     double *dtmp_side, *dcarry_side;
     bool side_busy;                       // a deferred backward pass may still be running
-    const double *side_in[2][2];          // [fa, fb][begin, end): what it reads
+    const double *side_in[2];             // fa, fb of that pass: (nch, n) views with row pitch ld
+    int64_t side_ld[2], side_n[2];
 };
 
 namespace osz {

@@ -1358,6 +1358,9 @@ int osz_sos_set_zi_unit(osz_sos_t h, const double *zi_unit) {
     return OSZ_OK;
 }
 
+/* samples of the next chunk the chunk-local backward warm-up reads (1 << 62: all of it) */
+int64_t osz_sos_warm_len(osz_sos_t h) { return h ? h->warm_len : -1; }
+
 int osz_sos_destroy(osz_sos_t h) {
     if (!h) return OSZ_OK;
     (void)hipFree(h->dsec);

@@ -1035,3 +1035,63 @@ def test_chain_step_overlapped(osz):
         want = orc.sosfiltfilt(fh, sos, cs)
         gh = np.concatenate([g[pick].cpu().numpy() for g in got], -1)
         assert rel_err(gh, want) < RTOL, (taps, C)
+
+
+
+def test_fir_then_sosfiltfilt_through_the_api_fused(osz):
+    """FIR.__call__ feeding IIR.__call__ (dephase) on device-resident data takes the
+    fused steady-state step (numerical._sosfiltfilt_after_fir) -- chunk for chunk
+    the same as the two generators apart (OSZ_CHAIN_API=0), and the oracle's
+    oaconvolve('same') -> chunk-local sosfiltfilt on three channels; odd and even
+    left cuts, ragged last chunk, a stream ending exactly on a chunk, the ring's
+    wrap (more than four chunks), few and many channels, sample axis first."""
+    import os
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    from openseize_amd.core import numerical as nm
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+
+    def chain(x, taps, cs, axis):
+        src = producer(x, cs, axis)
+        fir = producer(partial(nm.oaconvolve, src, taps, axis, "same"), cs, axis, shape=src.shape)
+        return [c for c in nm.sosfiltfilt(fir, sos, axis)]
+
+    from functools import partial
+    for taps_n, C, cs, total in ((1024, 256, 6144 * 24, 6144 * 24 * 6 + 6144 * 9 + 321),
+                                 (301, 5, 100000, 100000 * 9), (2049, 3, 131072, 131072 * 5 + 777),
+                                 (64, 4, 70001, 70001 * 7 + 5)):
+        taps = sps.firwin(taps_n, 0.2)
+        x = dev.synth_normal(C, total, seed=44)
+        steps, plain_step = [], dev.chain_step
+        dev.chain_step = lambda *a, **k: (steps.append(1), plain_step(*a, **k))[1]
+        try:
+            got = chain(x, taps, cs, -1)
+        finally:
+            dev.chain_step = plain_step
+        assert len(steps) == -(-total // cs) - 2, (taps_n, len(steps))   # the fused path DID run
+        os.environ["OSZ_CHAIN_API"] = "0"
+        try:
+            ref = chain(x, taps, cs, -1)
+        finally:
+            del os.environ["OSZ_CHAIN_API"]
+        assert [g.shape for g in got] == [r.shape for r in ref], (taps_n, C)
+        for k, (a, b) in enumerate(zip(got, ref)):
+            err = float((a - b).abs().max()) / float(b.abs().max())
+            assert err < 1e-11, (taps_n, C, k, err)
+        pick = [0, C // 2, C - 1]
+        xh = x[pick].cpu().numpy()
+        want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, cs)
+        gh = torch.cat(got, -1)[pick].cpu().numpy()
+        assert rel_err(gh, want) < RTOL, (taps_n, C)
+    # sample axis first: (samples, channels)
+    taps = sps.firwin(301, 0.2)
+    xt = dev.synth_normal(6, 100000 * 6 + 31, seed=45).T.contiguous()
+    got = torch.cat(chain(xt, taps, 100000, 0), 0)
+    os.environ["OSZ_CHAIN_API"] = "0"
+    try:
+        ref = torch.cat(chain(xt, taps, 100000, 0), 0)
+    finally:
+        del os.environ["OSZ_CHAIN_API"]
+    assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-11 * float(ref.abs().max())
