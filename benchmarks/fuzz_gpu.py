@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 10
+        kind = it % 11
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -165,6 +165,29 @@ def main():
                 fir.close(); iir.close()
                 e = max(rel(g_.cpu().numpy(), r_.cpu().numpy()) for g_, r_ in zip(got, ref))
                 what = f"chain taps={taps} C={C} n={n}"
+            elif kind == 10:   # FIR producer -> sosfiltfilt through the API: fused step vs the two generators
+                import os
+                from functools import partial
+                taps = int(rng.choice([2, 64, 301, 512, 1024, 1025, 2049]))
+                C = int(rng.integers(1, 6))
+                cs = int(rng.integers(65536, 140000))
+                nch_ = int(rng.integers(5, 9))
+                total = cs * (nch_ - 1) + int(rng.integers(1, cs + 1))
+                h = rng.standard_normal(taps) / np.sqrt(taps)
+                sos = designs[int(rng.integers(0, len(designs)))]
+                xdev = torch.from_numpy(rng.standard_normal((C, total))).cuda()
+
+                def through():
+                    src = producer(xdev, cs, -1)
+                    fir_ = producer(partial(nm.oaconvolve, src, h, -1, "same"), cs, -1, shape=src.shape)
+                    return torch.cat(list(nm.sosfiltfilt(fir_, sos, -1)), -1).cpu().numpy()
+                got_ = through()
+                os.environ["OSZ_CHAIN_API"] = "0"
+                try:
+                    ref_ = through()
+                finally:
+                    del os.environ["OSZ_CHAIN_API"]
+                e, what = rel(got_, ref_) * 100, f"api chain taps={taps} C={C} cs={cs} total={total}"
             elif kind == 4:    # psd
                 fs = float(rng.choice([250, 500, 1000, 4096]))
                 res = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
