@@ -329,20 +329,26 @@ def full_stream_leg(R, ring, h, sos):
     lengths = [CHUNK] * 95 + [RAGGED]
     total = sum(lengths)
 
-    def source():
-        for k, m in enumerate(lengths):
-            yield ring[k % len(ring)][:, :m]
+    def through_the_api(lens):
+        n = sum(lens)
 
-    src = producer(source, CHUNK, -1, shape=(C, total))
-    fir = producer(partial(nm.oaconvolve, src, h, -1, "same"), CHUNK, -1, shape=(C, total))
+        def source():
+            for k, m in enumerate(lens):
+                yield ring[k % len(ring)][:, :m]
+
+        src = producer(source, CHUNK, -1, shape=(C, n))
+        fir = producer(partial(nm.oaconvolve, src, h, -1, "same"), CHUNK, -1, shape=(C, n))
+        got = 0
+        for out in nm.sosfiltfilt(fir, sos, -1):
+            got += out.shape[-1]
+        torch.cuda.synchronize()
+        assert got == n, (got, n)
+
+    through_the_api([CHUNK] * 6 + [RAGGED])      # untimed: handles, allocator, first-call costs
     R.barrier()
     t0 = time.perf_counter()
-    got = 0
-    for out in nm.sosfiltfilt(fir, sos, -1):
-        got += out.shape[-1]
-    torch.cuda.synchronize()
+    through_the_api(lengths)
     secs = time.perf_counter() - t0
-    assert got == total, (got, total)
     return {"chunks": len(lengths), "samples_per_channel": total, "channels": C,
             "seconds": secs, "Msamples_s": C * total / secs / 1e6,
             "path": "producer(gen) -> oaconvolve('same') -> GenProducer -> sosfiltfilt (the public "
