@@ -1363,6 +1363,7 @@ int64_t osz_sos_warm_len(osz_sos_t h) { return h ? h->warm_len : -1; }
 
 int osz_sos_destroy(osz_sos_t h) {
     if (!h) return OSZ_OK;
+    if (h->side) (void)hipStreamSynchronize(h->side);   // a deferred backward pass of osz_chain_step
     (void)hipFree(h->dsec);
     for (int i = 0; i < 33; ++i) (void)hipFree(h->dsec_t[i]);
     for (int i = 0; i < 33; ++i) (void)hipFree(h->dtab2_t[i]);
