@@ -1,5 +1,6 @@
-"""Static check of the fir_oa_kernel<NR, 16, PF> variants (PF = 1, 2) in the
-assembly hipcc emits for fir.hip:
+"""Static check of the kernels that manage loads by hand -- fir_oa_kernel<NR, 16, PF>
+(PF = 1, 2) of fir.hip; any kernel with tagged requests is picked up -- in the assembly
+hipcc emits:
 
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only -o fir.s openseize_amd/csrc/fir.hip
     python benchmarks/check_async_regions.py fir.s
@@ -131,28 +132,40 @@ def analyse(blocks):
     return problems
 
 
-def table(path):
-    ok, why = {}, {}
-    key, nr, body = None, None, []
+def kernels(path):
+    """{mangled kernel name: [problems]} for every kernel of the assembly file that
+    requests loads by tagged inline assembly."""
+    out = {}
+    name, body = None, []
     for no, line in enumerate(open(path), 1):
-        m = KERNEL.match(line)
-        if m:
-            key, nr, body = (int(m.group(1)), int(m.group(2))), int(m.group(1)), []
+        m = re.match(r"^(_Z\w+):", line)
+        if m and name is None:
+            name, body = m.group(1), []
             continue
-        if key is None:
+        if name is None:
             continue
         body.append((no, line))
         if line.startswith(".Lfunc_end"):
-            problems = analyse(parse(body, nr))
+            if any("osz:" in text and "global_load" in text for _, text in body):
+                out[name] = analyse(parse(body, 0))
+            name = None
+    return out
+
+
+def table(path):
+    """fir_oa_kernel<NR, 16, PF>: {(nr, pf): clean?}, {(nr, pf): [problems]}"""
+    ok, why = {}, {}
+    for name, problems in kernels(path).items():
+        m = KERNEL.match(name + ":")
+        if m:
+            key = (int(m.group(1)), int(m.group(2)))
             ok[key], why[key] = not problems, problems
-            key = None
     return ok, why
 
 
 if __name__ == "__main__":
-    ok, why = table(sys.argv[1])
-    for key in sorted(ok):
-        print(f"NR={key[0]:2d} PF={key[1]}: {'clean' if ok[key] else 'NOT SAFE'}")
-        for w in why[key][:6]:
+    for name, problems in sorted(kernels(sys.argv[1]).items()):
+        print(f"{name[:60]}: {'clean' if not problems else 'NOT SAFE'}")
+        for w in problems[:6]:
             print("    " + w)
     sys.exit(0)
