@@ -265,21 +265,26 @@ def sosfilt(pro, sos, axis, zi=None):
 
 def _fir_feeding(pro, axis):
     """(source producer, taps) when ``pro`` is what ``FIR.__call__`` /
-    ``producer(partial(oaconvolve, source, taps, axis, 'same'), ...)`` builds: a
-    generating producer over ``oaconvolve`` in mode 'same' along the same axis
-    with the source's chunksize; None otherwise."""
+    ``producer(partial(oaconvolve, ...), ...)`` builds: a generating producer over
+    ``oaconvolve`` in mode 'same' along the same axis with the source's
+    chunksize; None otherwise."""
     import os
     from openseize_amd.core.producer import GenProducer, Producer
     if os.environ.get("OSZ_CHAIN_API") == "0":     # A/B and tests: the two generators apart
         return None
-    if not isinstance(pro, GenProducer) or pro.kwargs:
+    if not isinstance(pro, GenProducer):
         return None
     gen = pro.data
-    if not isinstance(gen, partial) or gen.func is not oaconvolve or gen.keywords:
+    if not isinstance(gen, partial) or gen.func is not oaconvolve:
         return None
-    if len(gen.args) != 4:
+    # however the call was spelled: positional, keywords of the partial, kwargs of the producer
+    import inspect
+    try:
+        bound = inspect.signature(oaconvolve).bind(*gen.args, **{**(gen.keywords or {}), **pro.kwargs})
+    except TypeError:
         return None
-    source, taps, fir_axis, mode = gen.args
+    source, taps = bound.arguments["pro"], bound.arguments["window"]
+    fir_axis, mode = bound.arguments["axis"], bound.arguments["mode"]
     if not isinstance(source, Producer) or mode != "same":
         return None
     ndim = len(pro.shape)
@@ -306,8 +311,11 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
     slot (never across the ring's end), output chunk j is the view ``lcut``
     columns further on, and the ``lcut`` columns by which the last slot's chunk
     reaches past the ring are copied behind it when slot 0 is rewritten.
-    Returns None (the caller falls back to the two separate generators) for
-    host-fed sources, short streams, ragged inner chunks."""
+    A host-fed source goes up through the pinned ring of ``dev.HostPipe`` while the
+    previous step runs and the results leave on its D2H stream: ONE trip over PCIe
+    each way for the chain, where the two generators apart make two and re-chunk
+    on the host in between.  Returns None (the caller falls back to the two
+    separate generators) for short streams and CPU tensors."""
     import torch
     axis = pro.axis
     cs, total = int(pro.chunksize), int(pro.shape[axis])
@@ -318,7 +326,10 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
         return None
     chunks = iter(source)
     first = next(chunks, None)
-    if first is None or not (dev.is_tensor(first) and first.is_cuda) or first.shape[axis] != cs:
+    if first is None or first.shape[axis] != cs:
+        return None
+    resident = dev.is_tensor(first) and first.is_cuda
+    if dev.is_tensor(first) and not resident:
         return None
 
     def run():
@@ -331,10 +342,29 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
                 yield None
                 return
             yield True
+            device = first.device if resident else "cuda"
+            pipe = None if resident else dev.HostPipe(layout)
+            flying = deque()
+
+            def feed(arr):
+                return layout.to2d(arr)[0] if pipe is None else pipe.feed(arr)
+
+            def emit(y):
+                """Results in order: resident ones as they are, host-bound ones once their
+                transfer (behind the kernels queued so far) has been two steps in flight."""
+                if pipe is None:
+                    yield layout.from2d(y, False)
+                    return
+                flying.append(pipe.download(y))
+                while len(flying) > 2:
+                    out, done = flying.popleft()
+                    done.synchronize()
+                    yield pipe.restore(out)
+
             shift = lcut + (lcut & 1)                  # even: chunk views keep 16-byte alignment
             span = R * cs
             off = shift - lcut                         # piece k starts at column (k % R) cs + off
-            ring = torch.empty((C, span + shift + 2), dtype=torch.float64, device=first.device)
+            ring = torch.empty((C, span + shift + 2), dtype=torch.float64, device=device)
             # Output sample s lives at column (s + shift) mod span; the columns
             # [span, span + shift) repeat [0, shift) for the chunk of the last slot.  A
             # piece written by the kernel into the last slot with off = 1 puts its last
@@ -359,17 +389,17 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
                         ring[:, span:span + 1].copy_(data[:, part:part + 1])
 
             # ---- input chunk 0 on the plain kernels: the left cut, the forward state
-            x0, _ = layout.to2d(first)
+            x0 = feed(first)
             head = fir.push(x0, lcut)
             iir.set_state_scaled(head, 0)
             iir.forward(head, out=ring[:, shift:shift + cs - lcut])
             produced = cs - lcut                       # output samples in the ring
             late, k = None, 1
             for arr in chunks:
-                x2d, _ = layout.to2d(arr)
-                m = x2d.shape[1]
-                if m == 0:
+                if arr.shape[axis] == 0:
                     continue
+                x2d = feed(arr)
+                m = x2d.shape[1]
                 if produced + lcut != k * cs or m > cs:
                     raise RuntimeError("sosfiltfilt after oaconvolve: an inner chunk of the source "
                                        f"is not chunksize = {cs} long")
@@ -377,11 +407,11 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
                 j = k - 2
                 if j >= 0:
                     mend(j)
-                    y = torch.empty((C, cs), dtype=torch.float64, device=first.device)
+                    y = torch.empty((C, cs), dtype=torch.float64, device=device)
                     dev.chain_step(fir, iir, x2d, chunk(j, cs), chunk(j + 1, cs - lcut), f_out=dst,
                                    y_out=y, defer=True)
                     if late is not None:
-                        yield layout.from2d(late, False)   # the previous step's: ours now
+                        yield from emit(late)              # the previous step's: ours now
                     late = y
                 else:
                     dev.chain_forward(fir, iir, x2d, out=dst)
@@ -390,13 +420,13 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
             # ---- the overhang of the convolution: plain kernels, behind the last piece
             cnt = max(wlen - 1 - rcut, 0)
             if cnt > 0:
-                store(produced, iir.forward(fir.flush(first.device, skip=0, drop=rcut)))
+                store(produced, iir.forward(fir.flush(device, skip=0, drop=rcut)))
                 produced += cnt
             if produced != total:
                 raise RuntimeError(f"sosfiltfilt after oaconvolve: {produced} of {total} samples")
             dev.chain_wait(iir)
             if late is not None:
-                yield layout.from2d(late, False)
+                yield from emit(late)
             # ---- the chunks the steady state has not reached: plain backward passes
             for j in range(max(k - 2, 0), nchunks):
                 n = min(cs, total - j * cs)
@@ -405,7 +435,11 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
                 if j + 1 < nchunks:
                     mend(j + 1)
                     fb = chunk(j + 1, min(cs, total - (j + 1) * cs))
-                yield layout.from2d(iir.backward(chunk(j, n), fb), False)
+                yield from emit(iir.backward(chunk(j, n), fb))
+            while flying:
+                out, done = flying.popleft()
+                done.synchronize()
+                yield pipe.restore(out)
         finally:
             fir.close()
             iir.close()

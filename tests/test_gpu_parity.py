@@ -1085,6 +1085,19 @@ def test_fir_then_sosfiltfilt_through_the_api_fused(osz):
         want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, cs)
         gh = torch.cat(got, -1)[pick].cpu().numpy()
         assert rel_err(gh, want) < RTOL, (taps_n, C)
+    # host-fed: ndarray chunks in, ndarray chunks out, one trip over PCIe each way
+    taps = sps.firwin(513, 0.2)
+    xh = np.random.default_rng(46).standard_normal((4, 90000 * 7 + 1234))
+    steps, plain_step = [], dev.chain_step
+    dev.chain_step = lambda *a, **k: (steps.append(1), plain_step(*a, **k))[1]
+    try:
+        got = chain(xh, taps, 90000, -1)
+    finally:
+        dev.chain_step = plain_step
+    assert len(steps) == 8 - 2 and all(isinstance(g, np.ndarray) for g in got)
+    assert [g.shape[-1] for g in got] == [90000] * 7 + [1234]
+    want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, 90000)
+    assert rel_err(np.concatenate(got, -1), want) < RTOL
     # sample axis first: (samples, channels)
     taps = sps.firwin(301, 0.2)
     xt = dev.synth_normal(6, 100000 * 6 + 31, seed=45).T.contiguous()
