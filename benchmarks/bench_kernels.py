@@ -278,6 +278,32 @@ def main():
         out.append({"workload": f"{name} 16 ch x 2^23, chunksize 262144",
                     "seconds": dt, "Msamples_s": xl.size / dt / 1e6,
                     "pcie_GBps_each_way": 8 * xl.size / dt / 1e9})
+    # a three-stage host chain: sosfilt(4 sections) -> FIR(256) -> downsample by 5, every stage
+    # a producer; the stages hand CUDA tensors on (dev.chain_aware), OSZ_HOST_CHAIN=0: ndarrays
+    from openseize_amd.filtering.fir import Kaiser as _Kaiser
+    sos4 = sps.butter(4, 0.4, output="sos")
+
+    def three_stage():
+        a = producer(xl, 1 << 18, -1)
+        b = mkpro(partial(nm.sosfilt, a, sos4, -1), 1 << 18, -1, shape=a.shape)
+        c = mkpro(partial(nm.oaconvolve, b, hh, -1, "same"), 1 << 18, -1, shape=a.shape)
+        d = mkpro(partial(nm.polyphase_resample, c, 1, 5, 5000.0, _Kaiser, -1), 1 << 18, -1,
+                  shape=(xl.shape[0], -(-xl.shape[1] // 5)))
+        return sum(piece.shape[-1] for piece in d)
+
+    for label, env in (("stages hand CUDA tensors on", None), ("stages hand ndarrays on (OSZ_HOST_CHAIN=0)", "0")):
+        if env is not None:
+            os.environ["OSZ_HOST_CHAIN"] = env
+        try:
+            three_stage()
+            t0 = time.perf_counter()
+            got = three_stage()
+            dt = time.perf_counter() - t0
+        finally:
+            os.environ.pop("OSZ_HOST_CHAIN", None)
+        assert got == -(-xl.shape[1] // 5)
+        out.append({"workload": f"host-fed sosfilt -> FIR -> downsample 5 chain 16 ch x 2^23, {label}",
+                    "seconds": dt, "Msamples_s": xl.size / dt / 1e6})
     # host-fed Welch PSD at the reference's default resolution, fs = 5 kHz (nfft 10 000)
     from openseize_amd.spectra.estimators import psd
     psd(xl, fs=5000.0, axis=-1)

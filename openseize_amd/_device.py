@@ -87,6 +87,147 @@ def host_dp(a):
     return a.ctypes.data_as(_lib.c_dp)
 
 
+# ---------------------------------------------------------------------------
+# chains of this library's generators over HOST data
+# ---------------------------------------------------------------------------
+# The reference's producers hand ndarrays from stage to stage.  Two stages of this
+# library in a row would each cross PCIe: results down, then up again through the
+# next stage's staging ring (a 256-tap FIR into sosfiltfilt from ndarrays: 0.95
+# instead of 5 Gsamples/s).  Instead a generator of this library that is being
+# pulled by ANOTHER generator of this library hands CUDA tensors on, and only the
+# last stage of the chain -- the one the caller iterates -- goes back to the host.
+#   _PULL: "whoever is pulling right now is one of ours" -- set around every next()
+#          a chain-aware generator makes on its source, read by the generators that
+#          start inside it;
+#   _EMIT: "the generator running right now hands CUDA tensors on" -- what the
+#          staging code (HostPipe.run, Layout.from2d) asks.
+import contextvars as _contextvars
+import functools as _functools
+
+_PULL = _contextvars.ContextVar("osz_pull_resident", default=False)
+_EMIT = _contextvars.ContextVar("osz_emit_resident", default=False)
+_END = object()
+
+
+def emit_resident():
+    return _EMIT.get()
+
+
+def _looks_like_producer(obj):
+    return hasattr(obj, "chunksize") and hasattr(obj, "shape") and hasattr(obj, "__iter__") \
+        and not is_arraylike(obj)
+
+
+def origin_is_host(pro):
+    """Does the chain of producers under ``pro`` start at host data (an ndarray, a CPU
+    tensor, a file reader)?  Static walk: array producers by their data, masked producers
+    through their data producer, generating producers through the producer among the
+    arguments of their (partial) function."""
+    for _ in range(64):
+        if not _looks_like_producer(pro):
+            return False
+        data = getattr(pro, "data", None)
+        if isinstance(data, np.ndarray):
+            return True
+        if is_tensor(data):
+            return not data.is_cuda
+        if type(pro).__name__ == "ReaderProducer":
+            # decoded on the device when asked to (file_io/edf.py: device=True)
+            return not (getattr(pro, "kwargs", None) or {}).get("device", False)
+        if _looks_like_producer(data):
+            pro = data
+            continue
+        cands = list(getattr(data, "args", ()) or ())
+        cands += list((getattr(data, "keywords", None) or {}).values())
+        cands += list((getattr(pro, "kwargs", None) or {}).values())
+        pro = next((c for c in cands if _looks_like_producer(c)), None)
+    return False
+
+
+def pull_resident(iterable):
+    """Iterate ``iterable`` as a consumer that takes CUDA tensors (the estimators and
+    other non-generator consumers of a producer chain)."""
+    it = iter(iterable)
+    while True:
+        token = _PULL.set(True)
+        try:
+            item = next(it, _END)
+        finally:
+            _PULL.reset(token)
+        if item is _END:
+            return
+        yield item
+
+
+def to_host_async(t):
+    """CUDA tensor -> (pinned host tensor, event): the copy runs on a stream of its own
+    behind everything queued on the current stream."""
+    cur = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    side = _d2h_stream()
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        out = torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=True)
+        out.copy_(t, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(side)
+    t.record_stream(side)
+    return out, done
+
+
+_D2H = None
+
+
+def _d2h_stream():
+    global _D2H
+    if _D2H is None:
+        _D2H = torch.cuda.Stream()
+    return _D2H
+
+
+def chain_aware(fn):
+    """Decorator for the generator functions ``fn(pro, ...)`` of core/numerical.py: see
+    the note above.  Resident chains pass through untouched."""
+    from collections import deque
+
+    @_functools.wraps(fn)
+    def wrapper(pro, *args, **kwargs):          # a generator function itself (producer() asks)
+        outer = _PULL.get()                     # does whoever pulls me take CUDA tensors?
+        import os
+        if not origin_is_host(pro) or os.environ.get("OSZ_HOST_CHAIN") == "0":   # (A/B knob)
+            yield from fn(pro, *args, **kwargs)
+            return
+        it = fn(pro, *args, **kwargs)
+        flying = deque()
+        try:
+            while True:
+                t1, t2 = _PULL.set(True), _EMIT.set(outer)
+                try:
+                    item = next(it, _END)
+                finally:
+                    _EMIT.reset(t2)
+                    _PULL.reset(t1)
+                if item is _END:
+                    break
+                if outer or not (is_tensor(item) and item.is_cuda):
+                    yield item
+                    continue
+                # the caller's stage: back to the host, two transfers in flight
+                flying.append(to_host_async(item))
+                while len(flying) > 2:
+                    out, done = flying.popleft()
+                    done.synchronize()
+                    yield out.numpy()
+            while flying:
+                out, done = flying.popleft()
+                done.synchronize()
+                yield out.numpy()
+        finally:
+            it.close()
+    return wrapper
+
+
 class Layout:
     """Maps an N-D chunk with a sample axis to the (channels, samples)
     row-major layout of the C ABI and back.  (The reference's functions take
@@ -128,7 +269,7 @@ class Layout:
         m = t.shape[-1]
         out = t.reshape(self.other + (m,))
         out = torch.movedim(out, -1, self.axis)
-        if host:
+        if host and not _EMIT.get():
             return out.cpu().numpy()
         return out.contiguous()
 
@@ -297,6 +438,10 @@ class HostPipe:
             self.compute.wait_event(ready)
             y2d = op(x2d, staged is None) if tell_last else op(x2d)
             if y2d is not None and y2d.shape[-1] > 0:
+                if _EMIT.get():
+                    # pulled by another generator of this library: the result stays in HBM
+                    yield self.layout.from2d(y2d, False)
+                    continue
                 flying.append(self.download(y2d))
             while len(flying) > lookahead:
                 out, ev = flying.popleft()

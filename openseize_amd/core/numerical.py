@@ -92,6 +92,7 @@ def _oa_cuts(wlen, mode):
     raise KeyError(mode)
 
 
+@dev.chain_aware
 def oaconvolve(pro, window, axis, mode, nfft_factor=32):
     """Streaming overlap-add convolution of a producer with a 1-D window
     (core/numerical.py:158-298) on the device (K1, ``osz_fir_*``).
@@ -233,6 +234,7 @@ def _zi_to_2d(zi, nsec, layout):
     return np.ascontiguousarray(zi.reshape(nsec, layout.nch, 2))
 
 
+@dev.chain_aware
 def sosfilt(pro, sos, axis, zi=None):
     """Forward cascaded-biquad filter with the state carried from chunk to
     chunk (core/numerical.py:301-335) on the device (K2,
@@ -352,7 +354,7 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
             def emit(y):
                 """Results in order: resident ones as they are, host-bound ones once their
                 transfer (behind the kernels queued so far) has been two steps in flight."""
-                if pipe is None:
+                if pipe is None or dev.emit_resident():
                     yield layout.from2d(y, False)
                     return
                 flying.append(pipe.download(y))
@@ -452,6 +454,7 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
     return gen
 
 
+@dev.chain_aware
 def sosfiltfilt(pro, sos, axis):
     """Forward-backward (zero-phase) cascaded-biquad filter
     (core/numerical.py:338-411) on the device (K2 + K3).
@@ -520,7 +523,7 @@ def sosfiltfilt(pro, sos, axis):
                 hosts.append(host_c)
             else:
                 y = stream.backward(fa, fb)
-            if pipe is not None and hosts[0]:
+            if pipe is not None and hosts[0] and not dev.emit_resident():
                 flying.append(pipe.download(y))
                 while len(flying) > 2:
                     out, done = flying.popleft()
@@ -631,6 +634,7 @@ def filtfilt(pro, coeffs, axis):
 # ---------------------------------------------------------------------------
 # polyphase resampling (reference core/numerical.py:523-632)
 # ---------------------------------------------------------------------------
+@dev.chain_aware
 def polyphase_resample(pro, L, M, fs, fir, axis, **kwargs):
     """Rational L/M resampling of a producer (core/numerical.py:523-632) on
     the device (K4, ``osz_poly_*``).
@@ -795,6 +799,7 @@ def _batched(pro, axis, nch):
         yield buf[0] if len(buf) == 1 else dev.concatenate(buf, axis)
 
 
+@dev.chain_aware
 def _spectra_estimatives(pro, fs, nfft, window, overlap, axis, detrend,
                          scaling, func, **kwargs):
     """One estimate per nfft-sample segment, ``stride = nfft - int(nfft *

@@ -33,7 +33,7 @@ def psd(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
                           _lib.SPEC_PSD_MEAN, layout.nch)
     host, pipe = True, None
     try:
-        for arr in nm._batched(pro, axis_n, layout.nch):
+        for arr in dev.pull_resident(nm._batched(pro, axis_n, layout.nch)):
             if dev.is_tensor(arr):
                 x2d, host = layout.to2d(arr)
             else:
@@ -43,6 +43,9 @@ def psd(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
                 x2d, host = pipe.feed(arr), True
             if x2d.shape[1]:
                 spec.push(x2d)
+        # a chain of this library's producers over host data hands CUDA tensors to
+        # this loop (dev.pull_resident); the estimate still goes back as an ndarray
+        host = host or dev.origin_is_host(pro)
         # device input: the average is taken on the device and stays there
         cnt, mean = spec.mean() if host else spec.mean_device()
     finally:

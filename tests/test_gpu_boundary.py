@@ -123,3 +123,67 @@ def test_psd_device_input_stays_on_device():
     # sample axis first
     c2, _, p2 = psd(x.T.contiguous(), fs=1000, axis=0, resolution=0.5)
     assert tuple(p2.shape) == (len(fd), 6) and np.array_equal(p2.cpu().numpy(), ph.T)
+
+
+def test_host_chain_stays_on_the_device_between_stages():
+    """ndarray -> sosfilt -> FIR -> downsample -> psd, every stage a producer of this
+    library: the stages hand CUDA tensors to each other (one upload, one result
+    down), the caller still gets ndarrays -- and the same numbers as stage-by-stage
+    arrays and as the all-resident chain.  Iterating an intermediate producer
+    directly yields ndarrays as before."""
+    import numpy as np
+    import scipy.signal as sps
+    import torch
+    from functools import partial
+    from openseize_amd import _device as dev
+    from openseize_amd import producer
+    from openseize_amd.core import numerical as nm
+    from openseize_amd.filtering.fir import Kaiser
+    from openseize_amd.spectra.estimators import psd
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((6, 400003))
+    cs, fs = 50000, 5000.0
+    sos = sps.butter(4, 0.4, output="sos")
+    taps = sps.firwin(201, 0.3)
+
+    def chain(data):
+        a = producer(data, cs, -1)
+        b = producer(partial(nm.sosfilt, a, sos, -1), cs, -1, shape=a.shape)
+        c = producer(partial(nm.oaconvolve, b, taps, -1, "same"), cs, -1, shape=a.shape)
+        n5 = -(-x.shape[1] // 5)
+        d = producer(partial(nm.polyphase_resample, c, 1, 5, fs, Kaiser, -1), cs, -1, shape=(6, n5))
+        return a, b, c, d
+
+    uploads, plain_upload = [], dev.HostPipe.upload
+
+    def counting(self, arr):
+        uploads.append(arr.shape)
+        return plain_upload(self, arr)
+
+    dev.HostPipe.upload = counting
+    try:
+        a, b, c, d = chain(x)
+        pieces = list(d)
+    finally:
+        dev.HostPipe.upload = plain_upload
+    assert all(isinstance(p, np.ndarray) for p in pieces)
+    assert len(uploads) == -(-x.shape[1] // cs)          # the source's chunks, once; nothing else went up
+    got = np.concatenate(pieces, -1)
+    # stage by stage through arrays
+    y1 = np.concatenate(list(nm.sosfilt(producer(x, cs, -1), sos, -1)), -1)
+    y2 = np.concatenate(list(nm.oaconvolve(producer(y1, cs, -1), taps, -1, "same")), -1)
+    y3 = np.concatenate(list(nm.polyphase_resample(producer(y2, cs, -1), 1, 5, fs, Kaiser, -1)), -1)
+    assert got.shape == y3.shape and np.max(np.abs(got - y3)) < 1e-12 * np.max(np.abs(y3))
+    # all resident
+    xd = torch.from_numpy(x).cuda()
+    res = torch.cat(list(chain(xd)[3]), -1)
+    assert res.is_cuda and float((res.cpu() - torch.from_numpy(y3)).abs().max()) < 1e-12 * np.max(np.abs(y3))
+    # an intermediate producer iterated by the caller: ndarrays
+    a, b, c, d = chain(x)
+    first = next(iter(c))
+    assert isinstance(first, np.ndarray) and np.allclose(first, y2[:, :cs], rtol=0, atol=1e-12 * np.max(np.abs(y2)))
+    # the estimator at the end of a host chain: pulls resident, returns a host estimate
+    cnt, f, p = psd(chain(x)[2], fs, axis=-1, resolution=1.0)
+    cnt2, f2, p2 = psd(y2, fs, axis=-1, resolution=1.0)
+    assert cnt == cnt2 and isinstance(p, np.ndarray) and np.max(np.abs(p - p2)) < 1e-10 * np.max(p2)
+
