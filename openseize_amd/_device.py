@@ -96,15 +96,20 @@ def host_dp(a):
 # instead of 5 Gsamples/s).  Instead a generator of this library that is being
 # pulled by ANOTHER generator of this library hands CUDA tensors on, and only the
 # last stage of the chain -- the one the caller iterates -- goes back to the host.
-#   _PULL: "whoever is pulling right now is one of ours" -- set around every next()
-#          a chain-aware generator makes on its source, read by the generators that
-#          start inside it;
-#   _EMIT: "the generator running right now hands CUDA tensors on" -- what the
-#          staging code (HostPipe.run, Layout.from2d) asks.
+#   _PULL:  the producer object a generator of this library is iterating right now (set
+#           around every next() it makes on its source);
+#   _GRANT: set by a GenProducer that finds ITSELF in _PULL -- its direct consumer is one
+#           of ours -- to the generating function it is about to resume: that function,
+#           if it is one of ours, hands CUDA tensors on.  (Identity on both hops: a stage
+#           written by the user in between sees ndarrays from its source and is handed
+#           ndarrays' worth of behaviour, whatever runs around it.)
+#   _EMIT:  "the generator running right now hands CUDA tensors on" -- what the staging
+#           code (HostPipe.run, Layout.from2d) asks.
 import contextvars as _contextvars
 import functools as _functools
 
-_PULL = _contextvars.ContextVar("osz_pull_resident", default=False)
+_PULL = _contextvars.ContextVar("osz_pull", default=None)
+_GRANT = _contextvars.ContextVar("osz_grant", default=None)
 _EMIT = _contextvars.ContextVar("osz_emit_resident", default=False)
 _END = object()
 
@@ -144,12 +149,12 @@ def origin_is_host(pro):
     return False
 
 
-def pull_resident(iterable):
-    """Iterate ``iterable`` as a consumer that takes CUDA tensors (the estimators and
-    other non-generator consumers of a producer chain)."""
+def pull_resident(iterable, pro):
+    """Iterate ``iterable`` -- chunks drawn from the producer ``pro`` -- as a consumer that
+    takes CUDA tensors (the estimators and other non-generator consumers of a chain)."""
     it = iter(iterable)
     while True:
-        token = _PULL.set(True)
+        token = _PULL.set(pro)
         try:
             item = next(it, _END)
         finally:
@@ -157,6 +162,33 @@ def pull_resident(iterable):
         if item is _END:
             return
         yield item
+
+
+def run_generating(producer, func, kwargs):
+    """What a GenProducer iterates: ``func(**kwargs)``, resumed with the grant in place
+    when the producer's direct consumer is a generator of this library."""
+    direct = _PULL.get() is producer
+    t1, t2 = _GRANT.set(func if direct else None), _PULL.set(None)
+    try:
+        gen = func(**kwargs)
+    finally:
+        _PULL.reset(t2)
+        _GRANT.reset(t1)
+    try:
+        while True:
+            t1, t2 = _GRANT.set(func if direct else None), _PULL.set(None)
+            try:
+                item = next(gen, _END)
+            finally:
+                _PULL.reset(t2)
+                _GRANT.reset(t1)
+            if item is _END:
+                return
+            yield item
+    finally:
+        close = getattr(gen, "close", None)
+        if close:
+            close()
 
 
 def to_host_async(t):
@@ -193,7 +225,8 @@ def chain_aware(fn):
 
     @_functools.wraps(fn)
     def wrapper(pro, *args, **kwargs):          # a generator function itself (producer() asks)
-        outer = _PULL.get()                     # does whoever pulls me take CUDA tensors?
+        grant = _GRANT.get()                    # does whoever pulls me take CUDA tensors?
+        outer = grant is not None and getattr(grant, "func", grant) is wrapper
         import os
         if not origin_is_host(pro) or os.environ.get("OSZ_HOST_CHAIN") == "0":   # (A/B knob)
             yield from fn(pro, *args, **kwargs)
@@ -202,10 +235,11 @@ def chain_aware(fn):
         flying = deque()
         try:
             while True:
-                t1, t2 = _PULL.set(True), _EMIT.set(outer)
+                t1, t2, t3 = _PULL.set(pro), _EMIT.set(outer), _GRANT.set(None)
                 try:
                     item = next(it, _END)
                 finally:
+                    _GRANT.reset(t3)
                     _EMIT.reset(t2)
                     _PULL.reset(t1)
                 if item is _END:

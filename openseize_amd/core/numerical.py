@@ -326,7 +326,7 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
     nchunks = -(-total // cs)
     if nchunks < 5 or cs < 65536 or total < wlen:
         return None
-    chunks = iter(source)
+    chunks = dev.pull_resident(source, source)         # a source of this library hands CUDA tensors
     first = next(chunks, None)
     if first is None or first.shape[axis] != cs:
         return None

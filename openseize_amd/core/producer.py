@@ -200,7 +200,9 @@ class GenProducer(Producer):
 
     def __iter__(self):
         fifo = FIFOArray(self.chunksize, self.axis)
-        for piece in self.data(**self.kwargs):
+        # (dev.run_generating: a generating function of this library hands CUDA tensors
+        # on when this producer's direct consumer is another one of them)
+        for piece in dev.run_generating(self, self.data, self.kwargs):
             fifo.put(piece)
             while fifo.full():
                 yield fifo.get()

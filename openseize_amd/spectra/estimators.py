@@ -33,7 +33,7 @@ def psd(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
                           _lib.SPEC_PSD_MEAN, layout.nch)
     host, pipe = True, None
     try:
-        for arr in dev.pull_resident(nm._batched(pro, axis_n, layout.nch)):
+        for arr in dev.pull_resident(nm._batched(pro, axis_n, layout.nch), pro):
             if dev.is_tensor(arr):
                 x2d, host = layout.to2d(arr)
             else:

@@ -182,6 +182,19 @@ def test_host_chain_stays_on_the_device_between_stages():
     a, b, c, d = chain(x)
     first = next(iter(c))
     assert isinstance(first, np.ndarray) and np.allclose(first, y2[:, :cs], rtol=0, atol=1e-12 * np.max(np.abs(y2)))
+    # a stage written by the user in between takes and hands on ndarrays, whatever runs around it
+    def rectify(pro):
+        for chunk in pro:
+            assert isinstance(chunk, np.ndarray)
+            yield np.abs(chunk)
+
+    a = producer(x, cs, -1)
+    b = producer(partial(nm.sosfilt, a, sos, -1), cs, -1, shape=a.shape)
+    u = producer(rectify, cs, -1, shape=a.shape, pro=b)
+    c = producer(partial(nm.oaconvolve, u, taps, -1, "same"), cs, -1, shape=a.shape)
+    got_u = np.concatenate(list(c), -1)
+    want_u = np.concatenate(list(nm.oaconvolve(producer(np.abs(y1), cs, -1), taps, -1, "same")), -1)
+    assert np.max(np.abs(got_u - want_u)) < 1e-12 * np.max(np.abs(want_u))
     # the estimator at the end of a host chain: pulls resident, returns a host estimate
     cnt, f, p = psd(chain(x)[2], fs, axis=-1, resolution=1.0)
     cnt2, f2, p2 = psd(y2, fs, axis=-1, resolution=1.0)
