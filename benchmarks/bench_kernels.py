@@ -304,6 +304,31 @@ def main():
         assert got == -(-xl.shape[1] // 5)
         out.append({"workload": f"host-fed sosfilt -> FIR -> downsample 5 chain 16 ch x 2^23, {label}",
                     "seconds": dt, "Msamples_s": xl.size / dt / 1e6})
+    # the README's pipeline from ndarrays: Kaiser low-pass -> Butterworth band-pass (zero phase)
+    # -> psd, every stage through the class API
+    from openseize_amd.filtering.iir import Butter as _Butter
+    from openseize_amd.spectra.estimators import psd as _psd
+    xr = xl[:, :3_000_000]
+
+    def readme():
+        pro = producer(xr, 1 << 18, -1)
+        lp = _Kaiser(fpass=500, fstop=600, fs=5000)(pro, chunksize=1 << 18, axis=-1)
+        bp = _Butter(fpass=[8, 30], fstop=[3, 60], fs=5000)(lp, chunksize=1 << 18, axis=-1, dephase=True)
+        return _psd(bp, fs=5000, axis=-1)
+
+    for label, envs in (("chain-aware", {}), ("stages apart (OSZ_HOST_CHAIN=0 OSZ_CHAIN_API=0)",
+                                              {"OSZ_HOST_CHAIN": "0", "OSZ_CHAIN_API": "0"})):
+        os.environ.update(envs)
+        try:
+            readme()
+            t0 = time.perf_counter()
+            readme()
+            dt = time.perf_counter() - t0
+        finally:
+            for k_ in envs:
+                os.environ.pop(k_, None)
+        out.append({"workload": f"README pipeline from ndarrays, 16 ch x 3e6: FIR -> zero-phase IIR -> psd, {label}",
+                    "seconds": dt, "Msamples_s": xr.size / dt / 1e6})
     # host-fed Welch PSD at the reference's default resolution, fs = 5 kHz (nfft 10 000)
     from openseize_amd.spectra.estimators import psd
     psd(xl, fs=5000.0, axis=-1)
