@@ -34,6 +34,7 @@ def pad(pro, amt, axis, value=0):
     return producer(func, pro.chunksize, pro.axis, shape=new_shape)
 
 
+@dev.chain_aware
 def _production_axis_padder(pro, amt, axis, value):
     """Only the first and last produced arrays change
     (core/protools.py:229-251)."""
@@ -52,6 +53,7 @@ def _production_axis_padder(pro, amt, axis, value):
     yield dev.zeros_like_kind(ref, right_shape, value)
 
 
+@dev.chain_aware
 def _other_axis_padder(pro, amt, axis, value):
     """Every produced array grows along a non-production axis
     (core/protools.py:254-264)."""
@@ -81,6 +83,7 @@ def squeeze(pro, axis=None):
                     pro.chunksize, new_axis, shape=new_shape)
 
 
+@dev.chain_aware
 def _map_gen(pro, func):
     for arr in pro:
         yield func(arr)
@@ -127,6 +130,7 @@ def _apply(op, arr, axis, a, b=None):
     return layout.from2d(dev.ew(op, x2d, a2, b2, kind), host)
 
 
+@dev.chain_aware
 def _arith_gen(pro, other, op, verb):
     """pro (op) other, chunk by chunk: ``other`` is a number, an array that
     broadcasts against every produced chunk, or a producer of the same shape
@@ -188,6 +192,7 @@ def multiply_along_axis(pro, arr, axis):
     return _same_shape_producer(pro, partial(_scale_gen, pro, arr.astype(np.float64), along))
 
 
+@dev.chain_aware
 def _scale_gen(pro, factors, along):
     laid = [1] * pro.ndim
     if along != pro.axis:
@@ -245,10 +250,12 @@ def _stream_moments(pro, ax, ignore_nan):
     acc = dev.MomentsStream(layout.nch)
     host = True
     try:
-        for arr in pro:
+        # (a chain of this library's producers over host data hands CUDA tensors to this
+        # loop; the statistics still go back as ndarrays)
+        for arr in dev.pull_resident(pro, pro):
             x2d, host = layout.to2d(arr)
             acc.push(x2d, ignore_nan)
-        return layout, acc.finish(), host
+        return layout, acc.finish(), host or dev.origin_is_host(pro)
     finally:
         acc.close()
 
@@ -267,9 +274,10 @@ def _chunk_moments(arr, ax, ignore_nan):
 
 def _per_chunk_stat(pro, ax, ignore_nan, keepdims, which):
     pieces, host = [], True
-    for arr in pro:
+    for arr in dev.pull_resident(pro, pro):
         stats, host = _chunk_moments(arr, ax, ignore_nan)
         pieces.append(stats[which])
+    host = host or dev.origin_is_host(pro)
     result = dev.concatenate(pieces, pro.axis)
     if not keepdims:
         result = result.squeeze(ax)
@@ -315,6 +323,7 @@ def standardize(pro, axis=-1, ignore_nan=True):
     return _same_shape_producer(pro, partial(_standardize_rows, pro, mu, sd))
 
 
+@dev.chain_aware
 def _standardize_rows(pro, mu, sd):
     import torch
     for arr in pro:
@@ -324,6 +333,7 @@ def _standardize_rows(pro, mu, sd):
         yield layout.from2d(dev.ew(_lib.EW_STANDARDIZE, x2d, a, b, _lib.BCAST_ROW), host)
 
 
+@dev.chain_aware
 def _standardize_chunks(pro, ax, ignore_nan):
     for arr in pro:
         (mu, sd), host = _chunk_moments(arr, ax, ignore_nan)

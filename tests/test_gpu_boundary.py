@@ -195,6 +195,19 @@ def test_host_chain_stays_on_the_device_between_stages():
     got_u = np.concatenate(list(c), -1)
     want_u = np.concatenate(list(nm.oaconvolve(producer(np.abs(y1), cs, -1), taps, -1, "same")), -1)
     assert np.max(np.abs(got_u - want_u)) < 1e-12 * np.max(np.abs(want_u))
+    # producer-level arithmetic inside a host chain: tensors through, ndarrays out
+    from openseize_amd.core import protools
+    a = producer(x, cs, -1)
+    b = producer(partial(nm.sosfilt, a, sos, -1), cs, -1, shape=a.shape)
+    z = protools.standardize(b, axis=-1)
+    zc = producer(partial(nm.oaconvolve, z, taps, -1, "same"), cs, -1, shape=a.shape)
+    got_z = np.concatenate(list(zc), -1)
+    y1z = (y1 - y1.mean(-1, keepdims=True)) / y1.std(-1, keepdims=True)
+    want_z = np.concatenate(list(nm.oaconvolve(producer(y1z, cs, -1), taps, -1, "same")), -1)
+    assert np.max(np.abs(got_z - want_z)) < 1e-10 * np.max(np.abs(want_z))
+    m = protools.mean(b, axis=-1)
+    assert isinstance(m, np.ndarray) and np.allclose(m, y1.mean(-1), rtol=0, atol=1e-12)
+    assert all(isinstance(c_, np.ndarray) for c_ in protools.multiply(b, 2.0))
     # the estimator at the end of a host chain: pulls resident, returns a host estimate
     cnt, f, p = psd(chain(x)[2], fs, axis=-1, resolution=1.0)
     cnt2, f2, p2 = psd(y2, fs, axis=-1, resolution=1.0)
