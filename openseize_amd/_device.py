@@ -164,6 +164,15 @@ def pull_resident(iterable, pro):
         yield item
 
 
+def relay_pull(outer, inner):
+    """Iterator over ``inner`` for a producer ``outer`` that merely passes chunks on (a
+    masked producer over its data producer): when ``outer``'s direct consumer is a
+    generator of this library, ``inner`` is named in its place."""
+    if _PULL.get() is outer:
+        return pull_resident(inner, inner)
+    return iter(inner)
+
+
 def run_generating(producer, func, kwargs):
     """What a GenProducer iterates: ``func(**kwargs)``, resumed with the grant in place
     when the producer's direct consumer is a generator of this library."""

@@ -263,7 +263,7 @@ class MaskedProducer(Producer):
         # keep[bounds[k]:bounds[k + 1]] falls into the window of data chunk k
         bounds = np.searchsorted(keep, np.arange(paired + 1) * cs)
         pending = FIFOArray(cs, self.axis)
-        for k, arr in zip(range(paired), self.data):
+        for k, arr in zip(range(paired), dev.relay_pull(self, self.data)):
             local = keep[bounds[k]:bounds[k + 1]] - k * cs
             if local.size == 0:
                 continue

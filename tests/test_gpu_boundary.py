@@ -138,6 +138,7 @@ def test_host_chain_stays_on_the_device_between_stages():
     from openseize_amd import _device as dev
     from openseize_amd import producer
     from openseize_amd.core import numerical as nm
+    from openseize_amd.core import producer as pmod
     from openseize_amd.filtering.fir import Kaiser
     from openseize_amd.spectra.estimators import psd
     rng = np.random.default_rng(8)
@@ -208,6 +209,22 @@ def test_host_chain_stays_on_the_device_between_stages():
     m = protools.mean(b, axis=-1)
     assert isinstance(m, np.ndarray) and np.allclose(m, y1.mean(-1), rtol=0, atol=1e-12)
     assert all(isinstance(c_, np.ndarray) for c_ in protools.multiply(b, 2.0))
+    # a masked producer between two stages passes the grant on: tensors in, tensors out
+    mask = rng.random(x.shape[1]) < 0.7
+    b = producer(partial(nm.sosfilt, producer(x, cs, -1), sos, -1), cs, -1, shape=x.shape)
+    mk = producer(b, cs, -1, mask=mask)
+    kinds = []
+    plain_take = pmod._take_device
+    pmod._take_device = lambda arr, keep_, axis_: (kinds.append(1), plain_take(arr, keep_, axis_))[1]
+    try:
+        mc = producer(partial(nm.oaconvolve, mk, taps, -1, "same"), cs, -1, shape=mk.shape)
+        got_m = np.concatenate(list(mc), -1)
+    finally:
+        pmod._take_device = plain_take
+    assert kinds, "the masked producer saw host chunks inside a chain of this library"
+    want_m = np.concatenate(list(nm.oaconvolve(producer(y1[:, mask], cs, -1), taps, -1, "same")), -1)
+    assert got_m.shape == want_m.shape and np.max(np.abs(got_m - want_m)) < 1e-12 * np.max(np.abs(want_m))
+    assert all(isinstance(c_, np.ndarray) for c_ in producer(b, cs, -1, mask=mask))
     # the estimator at the end of a host chain: pulls resident, returns a host estimate
     cnt, f, p = psd(chain(x)[2], fs, axis=-1, resolution=1.0)
     cnt2, f2, p2 = psd(y2, fs, axis=-1, resolution=1.0)
