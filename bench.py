@@ -212,16 +212,37 @@ def kernel_table(lib, samples_per_step):
     return kernels
 
 
+def kernel_sources_sha():
+    import hashlib
+    csrc = os.path.join(ROOT, "openseize_amd", "csrc")
+    hsh = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            hsh.update(name.encode())
+            hsh.update(open(os.path.join(csrc, name), "rb").read())
+    return hsh.hexdigest()
+
+
 def roofline_of(kernels, samples_per_step):
-    dom = max(kernels, key=lambda nm: kernels[nm]["total_ms"])
-    traffic = None
+    # one osz_chain_step is the unit when the step ran: its members (fused kernel on
+    # the caller's stream, backward pass on the handle's) overlap inside it, and a
+    # member's own bracket may include its wait for the other
+    dom = "chain_step" if "chain_step" in kernels else max(kernels, key=lambda nm: kernels[nm]["total_ms"])
+    # PMC counters cannot be read from inside a timed run: the bytes come from the
+    # committed rocprofv3 --pmc passes, and only while the kernel sources are the ones
+    # those passes ran (fingerprint written by benchmarks/summarise_profiles.py)
+    traffic, traffic_note = None, "profiles/traffic.json missing"
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(dom)
+        tj = json.load(open(tfile))
+        if tj.get("_kernel_sources_sha256") == kernel_sources_sha():
+            traffic, traffic_note = tj.get(dom), "rocprofv3 --pmc passes of these kernel sources"
+        else:
+            traffic_note = "stale: kernel sources changed since the --pmc passes (re-run refresh_profiles.sh)"
     out = {"kernel": dom, "bound": "hbm",
            "achieved": kernels[dom]["achieved_gbps"], "peak": HBM_PEAK_GBPS,
            "unit": "GB/s", "frac": kernels[dom]["achieved_gbps"] / HBM_PEAK_GBPS,
-           "traffic": traffic,
+           "traffic": traffic, "traffic_source": traffic_note,
            "algorithmic_bytes_per_launch": KERNEL_BYTES[dom] * samples_per_step,
            "avg_launch_ms": kernels[dom]["avg_ms"]}
     if dom == "chain_step":

@@ -38,7 +38,27 @@ def counter_means(path, counter):
     return acc
 
 
+def kernel_sources_sha():
+    """Fingerprint of the kernel sources the counters were collected with: bench.py
+    reports the counters as stale (traffic = null) when the sources have changed."""
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "openseize_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()
+
+
 def main():
+    if sys.argv[1:] == ["--stamp"]:
+        # the sources are what the committed counters were collected with: stamp them
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json")
+        traffic = json.load(open(tpath))
+        traffic["_kernel_sources_sha256"] = kernel_sources_sha()
+        json.dump(traffic, open(tpath, "w"), indent=1)
+        return
     root, tag = sys.argv[1], sys.argv[2]
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
     stats = find(os.path.join(root, "stats"), "*kernel_stats.csv")
@@ -77,6 +97,7 @@ def main():
     traffic["_note"] = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                         "(separate passes), (2*FETCH_SIZE + WRITE_SIZE)*1024; see "
                         f"{tag}_pmc_hbm_traffic.csv and profiles/README.md for the calibration.")
+    traffic["_kernel_sources_sha256"] = kernel_sources_sha()
     with open(os.path.join(out, "traffic.json"), "w") as fh:
         json.dump(traffic, fh, indent=1)
     print(json.dumps(traffic, indent=1))

@@ -46,6 +46,8 @@ struct osz_sos_s {
     double *dtmp;       // device (nsec, nch, 2): warm-up state of sosfiltfilt
     double *dcarry;     // device (nsec, nch, 2): state between the main and remainder launches
     double *dzi;        // device (nsec, 2): sosfilt_zi of this cascade
+    int *dsegcnt;       // device (nch): arrival counters of a forward pass's time segments
+                        // (sos_fwd_seal; zero between launches)
     int touch;          // tuning knob OSZ_SOS_TOUCH: touch-prefetch of the next tile
     double *dtab2;      // device [nsec][4][66]: A^(T k) per section for sos_body2, or null
     // osz_chain_step: the backward pass runs beside the fused forward kernel on a
@@ -60,6 +62,8 @@ struct osz_sos_s {
 };
 
 namespace osz {
+// false under OSZ_SOS_NANFIX=0 (A/B knob, sos.hip)
+bool sos_nanfix();
 // process-wide twiddle tables on the device (fir.hip)
 int get_fft_tables(fft::Tables &out);
 // per-section tables of a cascade for a tile of T samples per lane, built on

@@ -49,6 +49,12 @@ struct SosArgs {
     // backward pass instead of a launch of its own; npre a whole number of tiles
     const double *prex;
     int64_t ldprex, npre;
+    // Non-finite samples (see "NaN reach" below).  probe: backward passes, one sample per
+    // channel (row pitch ldprobe) whose being non-finite makes the whole pass NaN;
+    // segcnt: forward passes in time segments, one arrival counter per channel.
+    const double *probe;
+    int64_t ldprobe;
+    int *segcnt;
 };
 
 // In-kernel phase stamps for the diagnostic build only
@@ -75,6 +81,13 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// NaN reach across time segments: see sos_tile.h
+// backward pass: is channel c's pass NaN throughout?  (workgroup-uniform)
+__device__ __forceinline__ bool sos_bwd_poisoned(const SosArgs &a, int c) {
+    return a.probe != nullptr && sos_not_finite(a.probe[(int64_t)c * a.ldprobe]);
+}
+
 
 // GUARD = false: n is a whole number of tiles (the hot kernel: no bounds
 // checks, no predication); GUARD = true handles a ragged remainder.
@@ -767,6 +780,11 @@ __device__ __forceinline__ void sos_body2(const SosArgs &a, const SosSection *__
 template <int T, int NW, bool REV, bool GUARD>
 __global__ __launch_bounds__(NW * 64) void sos_kernel(SosArgs a,
                                                       const SosSection *__restrict__ sec) {
+    if (REV && sos_bwd_poisoned(a, blockIdx.x)) {
+        if (a.y) sos_fill_nan(a.y + (int64_t)blockIdx.x * a.ldy, a.n);
+        sos_state_nan(a.state_out, a.nsec, a.nch, blockIdx.x);
+        return;
+    }
     sos_body<T, NW, REV, GUARD>(a, sec, blockIdx.x);
 }
 
@@ -795,7 +813,15 @@ __device__ __forceinline__ void sos_segment(const SosArgs &a, const SosSection *
         if (a.y) b.y = a.y + begin - p;
     }
     if (s != nseg - 1) b.state_out = nullptr;
+    if (REV && sos_bwd_poisoned(a, c)) {
+        if (a.y) sos_fill_nan(a.y + (int64_t)c * a.ldy + (a.n - begin - len), len);
+        sos_state_nan(b.state_out, a.nsec, a.nch, c);
+        return;
+    }
     sos_body<T, NW, REV, false, LEAN>(b, sec, c, s > 0, p / ((int64_t)NW * 64 * T));
+    if (!REV && a.segcnt)
+        sos_fwd_seal(a.segcnt, a.y + (int64_t)c * a.ldy, a.n, nseg,
+                     [seglen](int q) { return (int64_t)(q + 1) * seglen; }, a.state_out, a.nsec, a.nch, c);
 }
 
 // One pass, grid (nch, nseg): fills the chip when there are few channels.
@@ -834,7 +860,15 @@ __device__ __forceinline__ void sos_segment2(const SosArgs &a, const SosSection 
     }
     if (s != nseg - 1) b.state_out = nullptr;
     if (s != 0) b.prex = nullptr;
+    if (REV && sos_bwd_poisoned(a, c)) {
+        if (a.y) sos_fill_nan(a.y + (int64_t)c * a.ldy + (a.n - begin - len), len);
+        sos_state_nan(b.state_out, a.nsec, a.nch, c);
+        return;
+    }
     sos_body2<T, NW, REV, AL16, PF>(b, sec, gtab, c, s > 0, p / ((int64_t)NW * 64 * T));
+    if (!REV && a.segcnt)
+        sos_fwd_seal(a.segcnt, a.y + (int64_t)c * a.ldy, a.n, nseg,
+                     [seglen](int q) { return (int64_t)(q + 1) * seglen; }, a.state_out, a.nsec, a.nch, c);
 }
 
 template <int T, int NW, bool REV, bool AL16, bool PF>
@@ -868,6 +902,17 @@ static bool sos_pf() {
     return pf == 1;
 }
 
+// OSZ_SOS_NANFIX=0: time segments as they were before the NaN reach was handled
+// (sos_tile.h) -- A/B knob for tests/test_gpu_nonfinite.py, which fails with it
+bool sos_nanfix() {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("OSZ_SOS_NANFIX");
+        on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return on == 1;
+}
+
 static bool sos_rows_aligned16(const SosArgs &a) {
     auto ok = [](const void *p, int64_t ld) {
         return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 1) == 0);
@@ -884,7 +929,10 @@ __global__ __launch_bounds__(NW * 64, 2) void sos_dual_kernel(SosArgs f, SosArgs
                                                              const SosSection *__restrict__ sec) {
     if (blockIdx.y == 0)
         sos_body<T, NW, false, false>(f, sec, blockIdx.x);
-    else
+    else if (sos_bwd_poisoned(b, blockIdx.x)) {
+        if (b.y) sos_fill_nan(b.y + (int64_t)blockIdx.x * b.ldy, b.n);
+        sos_state_nan(b.state_out, b.nsec, b.nch, blockIdx.x);
+    } else
         sos_body<T, NW, true, false>(b, sec, blockIdx.x);
 }
 
@@ -1220,6 +1268,9 @@ int sosfiltfilt_chunk_on(osz_sos_s *h, const double *fa, int64_t ldfa, int64_t n
     a.zi_unit = h->dzi;
     a.tab2 = h->dtab2;
     a.touch = h->touch;
+    // NaN reach of the backward pass: the last sample of what it is initialised from
+    a.probe = !sos_nanfix() ? nullptr : fb ? fb + (nb - 1) : fa + (na - 1);
+    a.ldprobe = fb ? ldfb : ldfa;
     // The warm-up rides the backward launch as a pre-roll of its first time segment
     // (sos_body2) when that launch is the trimmed split kernel on whole tiles; a
     // launch of its own otherwise.  (Beside a kernel that fills the chip --
@@ -1298,6 +1349,8 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     OSZ_HIP(hipMalloc(&p->dstate_alt, sb));
     OSZ_HIP(hipMalloc(&p->dtmp, sb));
     OSZ_HIP(hipMalloc(&p->dcarry, sb));
+    OSZ_HIP(hipMalloc(&p->dsegcnt, sizeof(int) * (size_t)nch));
+    OSZ_HIP(hipMemset(p->dsegcnt, 0, sizeof(int) * (size_t)nch));
     OSZ_HIP(hipMalloc(&p->dzi, sizeof(double) * nsec * 2));
     OSZ_HIP(hipMemcpy(p->dsec, secs.data(), sizeof(SosSection) * nsec, hipMemcpyHostToDevice));
     OSZ_HIP(hipMemset(p->dstate, 0, sb));
@@ -1371,6 +1424,7 @@ int osz_sos_destroy(osz_sos_t h) {
     (void)hipFree(h->dstate_alt);
     (void)hipFree(h->dtmp);
     (void)hipFree(h->dcarry);
+    (void)hipFree(h->dsegcnt);
     (void)hipFree(h->dzi);
     (void)hipFree(h->dtab2);
     (void)hipFree(h->dtmp_side);
@@ -1447,6 +1501,7 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y, int64_
     a.nch = h->nch;
     a.tab2 = h->dtab2;
     a.touch = h->touch;
+    a.segcnt = sos_nanfix() ? h->dsegcnt : nullptr;
     int rc = sos_launch<false>(a, h->dcarry, h->T, h->NW, h->warm_len, as_stream(stream));
     if (rc) return rc;
     std::swap(h->dstate, h->dstate_alt);
@@ -1478,6 +1533,10 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
     w.zi_unit = fw.zi_unit = bw.zi_unit = h->dzi;
     w.tab2 = fw.tab2 = bw.tab2 = h->dtab2;
     w.touch = fw.touch = bw.touch = h->touch;
+    fw.segcnt = sos_nanfix() ? h->dsegcnt : nullptr;
+    // NaN reach of the backward pass: the last sample of what it is initialised from
+    w.probe = bw.probe = !sos_nanfix() ? nullptr : fb ? fb + (nb - 1) : fa + (na - 1);
+    w.ldprobe = bw.ldprobe = fb ? ldfb : ldfa;
     // The chunk-local warm-up (numerical.py:397-399) rides the dual launch as a
     // pre-roll of the backward pass's first segment when it is exactly whole
     // tiles of the trimmed body; otherwise it is a small launch of its own.

@@ -27,6 +27,27 @@ def golden():
     return load_golden
 
 
+def nonfinite_inputs():
+    """The seeded inputs of tests/golden/g15_nonfinite.npz (make_golden.g15_inputs)."""
+    rng = np.random.default_rng(1515)
+    x = rng.standard_normal((3, 600000))
+    x[1, 250123] = np.nan
+    x[2, 590000:] = np.nan
+    xi = x.copy()
+    xi[0, 100] = np.inf
+    return x, xi
+
+
+def nonfinite_runs(arr):
+    """(channel, start, stop) runs of non-finite samples along the last axis."""
+    bad = ~np.isfinite(arr)
+    runs = []
+    for c in range(arr.shape[0]):
+        edges = np.flatnonzero(np.diff(np.concatenate(([0], bad[c].astype(np.int8), [0]))))
+        runs += [(c, a, b) for a, b in zip(edges[::2], edges[1::2])]
+    return np.array(runs, dtype=np.int64).reshape(-1, 3)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built_library():
     """A fresh checkout has no built artefacts (they are git-ignored): compile

@@ -496,6 +496,44 @@ def g14_metrics_analytic():
     save("g14_metrics_analytic.npz", **out)
 
 
+# --------------------------------------------------------------------------
+# G15 non-finite samples through the IIR passes (rows a6, a7): a NaN never
+# leaves a section's state -- forward: NaN to the end of the stream; backward:
+# the chunk that holds it, and the chunk before it (whose warm-up runs over it).
+# Inputs are regenerated from the seed; stored are the non-finite masks as run
+# boundaries and a decimation of the finite values.
+# --------------------------------------------------------------------------
+def g15_inputs():
+    rng = np.random.default_rng(1515)
+    x = rng.standard_normal((3, 600000))
+    x[1, 250123] = np.nan                 # one NaN in the middle of chunk 1
+    x[2, 590000:] = np.nan                # EDF-style NaN padding of the last record
+    xi = x.copy()
+    xi[0, 100] = np.inf                   # an Inf: NaN within a sample or two
+    return x, xi
+
+
+def g15_nonfinite():
+    x, xi = g15_inputs()
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    cs = 200000
+    out = {"sos": sos, "chunksize": np.array(cs)}
+    for tag, data in (("nan", x), ("inf", xi)):
+        y = np.concatenate(list(nm.sosfilt(producer(data, cs, -1), sos, -1)), -1)
+        yy = np.concatenate(list(nm.sosfiltfilt(producer(data, cs, -1), sos, -1)), -1)
+        for name, arr in (("sosfilt", y), ("sosfiltfilt", yy)):
+            bad = ~np.isfinite(arr)
+            # rows of (channel, start, stop) runs of non-finite samples
+            runs = []
+            for c in range(arr.shape[0]):
+                edges = np.flatnonzero(np.diff(np.concatenate(([0], bad[c].astype(np.int8), [0]))))
+                runs += [(c, a, b) for a, b in zip(edges[::2], edges[1::2])]
+            out[f"{name}_{tag}_runs"] = np.array(runs, dtype=np.int64).reshape(-1, 3)
+            out[f"{name}_{tag}_isnan_all"] = np.array(bool(np.all(np.isnan(arr[bad]))))
+            out[f"{name}_{tag}_dec"] = arr[:, ::97]
+    save("g15_nonfinite.npz", **out)
+
+
 if __name__ == "__main__":
     g1_producer()
     g2_fir()
@@ -511,3 +549,4 @@ if __name__ == "__main__":
     g12_protools()
     g13_hilbert()
     g14_metrics_analytic()
+    g15_nonfinite()

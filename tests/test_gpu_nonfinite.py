@@ -1,0 +1,144 @@
+"""GPU parity on non-finite input: a NaN (or Inf) never leaves the state of an IIR
+section, so the reference (scipy.signal.sosfilt behind core/numerical.py:334, :399-410)
+is NaN from that sample to the end of the STREAM in a forward pass and, in
+sosfiltfilt, over the whole chunk that holds it and the chunk before it (whose
+backward warm-up runs over it).  The kernels cut a pass into time segments that start
+from zero states; `sos_fwd_seal` / `probe` (csrc/sos_tile.h) make the segments agree
+with the serial recurrence.  Pinned by tests/golden/g15_nonfinite.npz (reference
+outputs) and, for other geometries, by the oracle (itself pinned by g15)."""
+
+from functools import partial
+
+import numpy as np
+import pytest
+
+from conftest import nonfinite_inputs, nonfinite_runs
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def nm():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from openseize_amd import _lib
+    _lib.load()
+    from openseize_amd.core import numerical
+    return numerical
+
+
+def producer(*a, **k):
+    from openseize_amd import producer as p
+    return p(*a, **k)
+
+
+def same_where_finite(got, want, tol=RTOL):
+    ok = np.isfinite(want)
+    assert np.array_equal(ok, np.isfinite(got))
+    assert np.array_equal(np.isnan(want), np.isnan(got))
+    if ok.any():
+        assert np.max(np.abs(got[ok] - want[ok])) < tol * np.max(np.abs(want[ok]))
+
+
+@pytest.mark.parametrize("tag", ["nan", "inf"])
+def test_golden_nonfinite_reach(nm, golden, tag):
+    """Three channels (every pass cut into time segments, main + ragged remainder
+    launches), chunks of 200 000: the reference's own masks and values."""
+    from oracle import oracle as orc
+    g = golden("g15_nonfinite.npz")
+    sos, cs = g["sos"], int(g["chunksize"])
+    data = nonfinite_inputs()[0 if tag == "nan" else 1]
+    y = np.concatenate(list(nm.sosfilt(producer(data, cs, -1), sos, -1)), -1)
+    yy = np.concatenate(list(nm.sosfiltfilt(producer(data, cs, -1), sos, -1)), -1)
+    for name, arr in (("sosfilt", y), ("sosfiltfilt", yy)):
+        assert np.array_equal(nonfinite_runs(arr), g[f"{name}_{tag}_runs"]), name
+        dec, want = arr[:, ::97], g[f"{name}_{tag}_dec"]
+        ok = np.isfinite(want)
+        assert np.array_equal(ok, np.isfinite(dec))
+        assert np.max(np.abs(dec[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
+    if tag == "nan":
+        same_where_finite(y, orc.sosfilt(data, sos, cs)[0])
+        same_where_finite(yy, orc.sosfiltfilt(data, sos, cs))
+
+
+def test_nonfinite_reach_many_channels_whole_tiles(nm):
+    """128 channels in chunks of 2^17 (whole tiles: sosfiltfilt takes the dual launch,
+    forward of chunk k and backward of chunk k - 2 in time segments), device resident:
+    a NaN in the FIRST tile of a chunk (behind every later segment's pre-roll), one in
+    the last chunk only, a NaN tail, and the carried state across chunks."""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    cs, nchunks, C = 1 << 17, 5, 128
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((C, cs * nchunks))
+    x[5, cs + 17] = np.nan                      # first tile of chunk 1
+    x[40, 4 * cs + 3] = np.nan                  # last chunk only
+    x[77, 3 * cs + 99999:] = np.nan             # tail
+    x[100, 2 * cs - 1] = np.nan                 # last sample of chunk 1
+    pick = [0, 5, 40, 77, 100, 127]
+    xd = torch.from_numpy(x).cuda()
+    y = torch.cat(list(nm.sosfilt(producer(xd, cs, -1), sos, -1)), -1)[pick].cpu().numpy()
+    same_where_finite(y, orc.sosfilt(x[pick], sos, cs)[0])
+    yy = torch.cat(list(nm.sosfiltfilt(producer(xd, cs, -1), sos, -1)), -1)[pick].cpu().numpy()
+    want = orc.sosfiltfilt(x[pick], sos, cs)
+    same_where_finite(yy, want)
+    # what the masks are, spelled out: channel 5 -> chunks 0.. all NaN; channel 40 ->
+    # chunks 3, 4; channel 77 -> chunks 2, 3, 4; channel 100 -> everything
+    nanchunks = [[bool(np.isnan(yy[i, k * cs:(k + 1) * cs]).all()) for k in range(nchunks)]
+                 for i in range(len(pick))]
+    assert nanchunks == [[False] * 5, [True] * 5, [False, False, False, True, True],
+                         [False, False, True, True, True], [True] * 5, [False] * 5]
+
+
+def test_nonfinite_reach_fused_chain(nm):
+    """FIR -> sosfiltfilt on the fused step (chain_kernel: several runs per channel that
+    start from zero states; backward pass beside it): a NaN in the input reaches the
+    end of the stream in the forward half, so from the chunk before the NaN on every
+    output chunk of that channel is NaN; the other channels equal the oracle.  (How
+    far a NaN spreads inside the FIR differs from the reference by construction -- an
+    FFT block is NaN as a whole and the block lengths differ -- which is why the
+    chunks BEFORE are only required to be finite up to one chunk ahead of the NaN.)"""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    taps = sps.firwin(1024, 0.2)
+    C, cs, nchunks = 64, 6144 * 24, 7
+    x = dev.synth_normal(C, cs * nchunks, seed=5)
+    x[9, 3 * cs + 8000] = float("nan")         # inside the first block pair of chunk 3
+    x[30, 5 * cs + cs // 2:] = float("nan")
+    src = producer(x, cs, -1)
+    fir = producer(partial(nm.oaconvolve, src, taps, -1, "same"), cs, -1, shape=src.shape)
+    steps, plain_step = [], dev.chain_step
+    dev.chain_step = lambda *a, **k: (steps.append(1), plain_step(*a, **k))[1]
+    try:
+        got = torch.cat(list(nm.sosfiltfilt(fir, sos, -1)), -1).cpu().numpy()
+    finally:
+        dev.chain_step = plain_step
+    assert steps, "the fused step did not run"
+    nan_chunk = np.array([[bool(np.isnan(got[c, k * cs:(k + 1) * cs]).all()) for k in range(nchunks)]
+                          for c in range(C)])
+    some_nan = np.array([[bool(np.isnan(got[c, k * cs:(k + 1) * cs]).any()) for k in range(nchunks)]
+                         for c in range(C)])
+    assert np.array_equal(nan_chunk, some_nan)            # a chunk is NaN as a whole or not at all
+    assert nan_chunk[9].tolist() == [False, False, True, True, True, True, True]
+    assert nan_chunk[30].tolist() == [False, False, False, False, True, True, True]
+    clean = [c for c in range(C) if c not in (9, 30)]
+    assert not nan_chunk[clean].any()
+    pick = [0, 31, 63]
+    xh = x[pick].cpu().numpy()
+    want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, cs)
+    assert np.max(np.abs(got[pick] - want)) < RTOL * np.max(np.abs(want))
+    # and the finite chunks of the two NaN channels equal the oracle on their finite prefix
+    for c, upto in ((9, 2), (30, 4)):
+        # chunks < upto see the forward output up to chunk `upto`, i.e. the input up to
+        # 511 samples into the next chunk: no NaN there
+        xc = x[c:c + 1, :(upto + 1) * cs + 600].cpu().numpy()
+        assert np.isfinite(xc).all()
+        w = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xc, taps, "same"), -1), sos, cs)
+        assert np.max(np.abs(got[c, :upto * cs] - w[0, :upto * cs])) < RTOL * np.max(np.abs(w))

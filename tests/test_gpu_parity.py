@@ -99,6 +99,36 @@ def test_oaconvolve_edges(osz):
         assert rel_err(y, orc.convolve_direct(xx, h, "full")) < RTOL
 
 
+def test_documented_divergences_are_exactly_these(osz, golden):
+    """DESIGN section 2 lists the inputs on which the product deliberately does NOT
+    follow the reference; this pins which inputs those are and what comes back.
+    Q12: the reference's short-data fallback with an odd nfft raises inside the overlap
+    add (flag recorded by make_golden.py from the reference itself, numerical.py:210-249);
+    the product returns the linear convolution.  Q3: data shorter than the window is a
+    ValueError on both sides.  Q13: FIR.__call__ along axis 0 raises IndexError in the
+    reference (filtering/bases.py:411); here it filters along that axis."""
+    from oracle import oracle as orc
+    from openseize_amd.filtering.fir import Kaiser
+    g = golden("g2_fir.npz")
+    assert bool(g["quirk_odd_fallback_raises"])          # what the reference did
+    x, h = g["x"][:, :5003], g["h1024"]
+    with pytest.raises(ValueError):                      # the oracle follows the reference
+        orc.oaconvolve(x, h, "same")
+    for mode in ("full", "same", "valid"):
+        y = np.concatenate(list(osz.oaconvolve(producer(x, 1000, -1), h, -1, mode)), -1)
+        assert rel_err(y, orc.convolve_direct(x, h, mode)) < RTOL
+    # the even neighbour is NOT a divergence: golden outputs of the reference
+    y = np.concatenate(list(osz.oaconvolve(producer(g["x"], 1000, -1), h, -1, "same")), -1)
+    assert rel_err(y, g["y_t1024_same"]) < RTOL
+    with pytest.raises(ValueError):
+        list(osz.oaconvolve(producer(x[:, :500], 100, -1), h, -1, "same"))
+    kais = Kaiser(fpass=30, fstop=60, fs=500, gpass=1, gstop=40)
+    xt = np.ascontiguousarray(g["x"].T)                  # samples along axis 0
+    y0 = kais(xt, chunksize=1000, axis=0, mode="same")
+    y1 = kais(g["x"], chunksize=1000, axis=-1, mode="same")
+    assert y0.shape == xt.shape and rel_err(y0.T, y1) < RTOL
+
+
 def test_oaconvolve_every_block_height(osz):
     """One filter length per compiled block height (8 ... 15 rows of 256 samples:
     the whole-pair loop of fir_oa_kernel is a separate instantiation for each),

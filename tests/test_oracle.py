@@ -182,3 +182,21 @@ def test_ba_filters(golden, name):
         y, _ = orc.lfilter(x, coeffs, 1000, zi=g["notch_zi"])
         assert close(y, g["notch_lfilter_zi"], 1e-12)
         assert close(orc.filtfilt(x, coeffs, 1500).T, g["notch_axis0"], 1e-12)
+
+
+def test_nonfinite_reach(golden):
+    """G15: where the reference's IIR passes are non-finite after a NaN / an Inf in the
+    input (forward: to the end of the stream; backward: the chunk and the one before)."""
+    from conftest import nonfinite_inputs, nonfinite_runs
+    g = golden("g15_nonfinite.npz")
+    sos, cs = g["sos"], int(g["chunksize"])
+    for tag, data in zip(("nan", "inf"), nonfinite_inputs()):
+        y, _ = orc.sosfilt(data, sos, cs)
+        yy = orc.sosfiltfilt(data, sos, cs)
+        for name, arr in (("sosfilt", y), ("sosfiltfilt", yy)):
+            assert np.array_equal(nonfinite_runs(arr), g[f"{name}_{tag}_runs"])
+            assert bool(np.all(np.isnan(arr[~np.isfinite(arr)]))) == bool(g[f"{name}_{tag}_isnan_all"])
+            dec, want = arr[:, ::97], g[f"{name}_{tag}_dec"]
+            ok = np.isfinite(want)
+            assert np.array_equal(ok, np.isfinite(dec))
+            assert np.max(np.abs(dec[ok] - want[ok])) < 1e-12 * np.max(np.abs(want[ok]))
