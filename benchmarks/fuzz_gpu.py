@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 11
+        kind = it % 12
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -202,6 +202,34 @@ def main():
                 _, pr = sps.welch(x, fs, window=win, nperseg=nfft, noverlap=int(nfft * ov), detrend=det,
                                   scaling=sc, axis=axis)
                 e, what = rel(p, pr), f"psd fs={fs} res={res} n={n} shape={x.shape} axis={axis} ov={ov} {det} {sc} {win}"
+            elif kind == 11:   # non-finite samples: as far as in the serial recurrence (time segments!)
+                n = int(rng.integers(70000, 700000))
+                C = int(rng.choice([1, 2, 3, 5, 40, 130]))
+                if C > 5:
+                    n = min(n, 200000)
+                x = rng.standard_normal((C, n))
+                for _ in range(int(rng.integers(1, 4))):
+                    c, at = int(rng.integers(0, C)), int(rng.integers(0, n))
+                    if rng.random() < 0.4:
+                        x[c, at:] = np.nan                     # EDF-style padding to the end
+                    else:
+                        x[c, at] = np.nan if rng.random() < 0.7 else np.inf
+                sos = designs[int(rng.integers(0, 4))]
+                cs = int(rng.choice([8192 * int(rng.integers(2, 30)), int(rng.integers(20000, n + 100))]))
+                dev_in = rng.random() < 0.5
+                src = torch.from_numpy(x).cuda() if dev_in else x
+                back = (lambda o: o.cpu().numpy()) if dev_in else (lambda o: o)
+                y = np.concatenate([back(o) for o in nm.sosfilt(producer(src, cs, -1), sos, -1)], -1)
+                z = np.concatenate([back(o) for o in nm.sosfiltfilt(producer(src, cs, -1), sos, -1)], -1)
+                ry, rz = orc.sosfilt(x, sos, cs)[0], orc.sosfiltfilt(x, sos, cs)
+                e = 0.0
+                for got, want in ((y, ry), (z, rz)):
+                    ok = np.isfinite(want)
+                    if not np.array_equal(ok, np.isfinite(got)):
+                        e = float("inf")
+                    elif ok.any():
+                        e = max(e, float(np.max(np.abs(got[ok] - want[ok])) / np.max(np.abs(want[ok]))))
+                what = f"nonfinite C={C} n={n} cs={cs} dev={dev_in}"
         except Exception as exc:   # noqa: BLE001 - report and continue
             e, what = float("inf"), f"kind {kind} raised {type(exc).__name__}: {exc}"
         if not e < (1e-8 if kind in (4, 5) else TOL):
