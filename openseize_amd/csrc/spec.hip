@@ -203,9 +203,13 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) win[j] = a.window[256 * j + t];
 
-    double acc[9];
+    // PSD_MEAN: the sum over a pair's two segments needs no separation,
+    //   |A[k]|^2 + |B[k]|^2 = (|Z[k]|^2 + |Z[N-k]|^2) / 2   (Z = A + i B, a and b real),
+    // so a thread sums |Z|^2 of the 16 bins it owns over its whole run and the bins
+    // meet their mirrors ONCE, after the run: no park / barrier / mirror read per pair.
+    double acc[16];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) acc[j] = 0.0;
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0;
     double keep[HALF ? 8 : 1];
     bool have_keep = false;
 
@@ -311,6 +315,11 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
         fft::cube::f2(tt, re, im, tw2, L);
         __syncthreads();
         fft::cube::f3(tt, re, im, L);
+        if (MODE == OSZ_SPEC_PSD_MEAN) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fma(re[r], re[r], fma(im[r], im[r], acc[r]));
+            continue;   // (the next pair's first barrier also ends this pair's cube reads)
+        }
         // ---- separate the two spectra: park Z[k] in this thread's own slots
 #pragma unroll
         for (int r = 0; r < 16; ++r) L[fft::cube::slot_c(tt, fft::dr(r))] = C2{re[r], im[r]};
@@ -346,17 +355,25 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
                     double *o = (double *)a.out;
                     o[(sa * a.nch + c) * (int64_t)kNF + k] = pa;
                     if (has_b) o[(sb * a.nch + c) * (int64_t)kNF + k] = pb;
-                } else {
-                    acc[j] += has_b ? pa + pb : pa;
                 }
             }
         }
     }
     if (MODE == OSZ_SPEC_PSD_MEAN) {
+        // fold bin k with its mirror N - k; one-sided doubling and the scale here
+        double *D = reinterpret_cast<double *>(L);
+        __syncthreads();   // the last pair's cube reads are done
+#pragma unroll
+        for (int r = 0; r < 16; ++r) D[t + 256 * fft::dr(r)] = acc[r];
+        __syncthreads();
         double *o = a.partial + ((int64_t)c * a.nruns + run) * kNF;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[t + 256 * j] = acc[j];
-        if (t == 0) o[2048] = acc[8];
+        for (int j = 0; j < 8; ++j) {
+            const int k = t + 256 * j;
+            const double f = k != 0 ? 2.0 * s2 : s2;
+            o[k] = 0.5 * (D[k] + D[(fft::N - k) & (fft::N - 1)]) * f;
+        }
+        if (t == 0) o[2048] = D[2048] * s2;
     }
 }
 
@@ -438,7 +455,10 @@ __global__ __launch_bounds__(N / 8, 4) void spec8_kernel(Spec8Args a) {
         const double wv = a.window[i < a.nwin ? i : 0];   // clamped address, no branch
         win[r] = i < a.nwin ? wv : 0.0;                   // zero padding up to nfft
     }
-    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    // PSD_MEAN: |A[k]|^2 + |B[k]|^2 = (|Z[k]|^2 + |Z[N-k]|^2) / 2 -- a thread sums |Z|^2 of
+    // its own 8 bins over the run; bins meet their mirrors once, after the run
+    // (see spec_cube_kernel): no natural-order exchange per pair
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     const bool fullwin = a.nwin == N;
     double keep[HALF ? 4 : 1];
     bool have_keep = false;
@@ -556,6 +576,11 @@ __global__ __launch_bounds__(N / 8, 4) void spec8_kernel(Spec8Args a) {
         int tt = t;   // opaque copy: keeps the LDS slot numbers out of loop-invariant registers
         asm volatile("" : "+v"(tt));
         Fwd8<N, 0>::run(tt, re, im, tw, lds8);
+        if (MODE == OSZ_SPEC_PSD_MEAN) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = fma(re[r], re[r], fma(im[r], im[r], acc[r]));
+            continue;   // (the next pair's first barrier also ends this pair's LDS reads)
+        }
         // ---- natural-order exchange: Z[k] of both spectra side by side
         __syncthreads();   // every read of the last stage is done
         asm volatile("" : "+v"(tt));
@@ -591,17 +616,25 @@ __global__ __launch_bounds__(N / 8, 4) void spec8_kernel(Spec8Args a) {
                     double *o = (double *)a.out;
                     o[(sa * a.nch + c) * (int64_t)NF + k] = pa;
                     if (has_b) o[(sb * a.nch + c) * (int64_t)NF + k] = pb;
-                } else {
-                    acc[jj] += has_b ? pa + pb : pa;
                 }
             }
         }
     }
     if (MODE == OSZ_SPEC_PSD_MEAN) {
+        // fold bin k with its mirror N - k; one-sided doubling and the scale here
+        double *D = reinterpret_cast<double *>(lds8);
+        __syncthreads();   // the last pair's LDS reads are done
+#pragma unroll
+        for (int r = 0; r < 8; ++r) D[fft8::revdigits<L>(fft8::idx_of<0>(t, r))] = acc[r];
+        __syncthreads();
         double *o = a.partial + ((int64_t)c * a.nruns + run) * NF;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) o[t + NT * jj] = acc[jj];
-        if (t == 0) o[N / 2] = acc[4];
+        for (int jj = 0; jj < 4; ++jj) {
+            const int k = t + NT * jj;
+            const double f = k != 0 ? 2.0 * s2 : s2;
+            o[k] = 0.5 * (D[k] + D[(N - k) & (N - 1)]) * f;
+        }
+        if (t == 0) o[N / 2] = D[N / 2] * s2;
     }
 }
 
