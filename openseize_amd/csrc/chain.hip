@@ -343,16 +343,7 @@ int osz_chain_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, i
     hipStream_t st = as_stream(stream);
     if (!sos->side) {
         const size_t sb = sizeof(double) * (size_t)sos->nsec * sos->nch * 2;
-        // OSZ_CHAIN_SIDE_PRIO = hi | lo: the backward pass's stream above / below the
-        // caller's in the dispatcher's eyes (A/B knob; default: same priority)
-        const char *pe = getenv("OSZ_CHAIN_SIDE_PRIO");
-        if (pe && (pe[0] == 'h' || pe[0] == 'l')) {
-            int least = 0, greatest = 0;
-            OSZ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            OSZ_HIP(hipStreamCreateWithPriority(&sos->side, hipStreamNonBlocking,
-                                                pe[0] == 'h' ? greatest : least));
-        } else
-            OSZ_HIP(hipStreamCreateWithFlags(&sos->side, hipStreamNonBlocking));
+        OSZ_HIP(hipStreamCreateWithFlags(&sos->side, hipStreamNonBlocking));
         OSZ_HIP(hipEventCreateWithFlags(&sos->side_go, hipEventDisableTiming));
         OSZ_HIP(hipEventCreateWithFlags(&sos->side_done[0], hipEventDisableTiming));
         OSZ_HIP(hipEventCreateWithFlags(&sos->side_done[1], hipEventDisableTiming));
