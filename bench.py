@@ -274,10 +274,12 @@ def run_chain(args, R, h, sos):
     ring = [dev.synth_normal(C, CHUNK, seed=0, ch0=R.rank * C, n0=k * CHUNK) for k in range(3)]
     fir = dev.FirStream(h, C)
     iir = dev.SosStream(sos, C)
-    fir_out = torch.empty((C, CHUNK), dtype=torch.float64, device="cuda")
+    # resident buffers with defined contents (zero-filled, so every page of the ring
+    # has been written once before the first step reads or overwrites it)
+    fir_out = torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda")
     nf = 3 if (args.unfused or args.fused) else 4
-    fwd = [torch.empty_like(fir_out) for _ in range(nf)]
-    y_out = torch.empty_like(fir_out)
+    fwd = [torch.zeros_like(fir_out) for _ in range(nf)]
+    y_out = torch.zeros_like(fir_out)
 
     def step(k):
         if args.unfused:
@@ -486,8 +488,11 @@ def run_welch(args, R):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the two-stream step needs ~8 steps after a cold start to settle into its
+    # steady interleaving (benchmarks/step_trace.py: 3.1, 2.9, 2.8 ... 2.6 ms); 100 steps
+    # of 2.6 ms are a quarter of a second
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=("chain", "welch"), default="chain")
     ap.add_argument("--reduce", choices=("torch", "abi"), default="torch",
                     help="welch: all-reduce through torch.distributed (RCCL) or through "
