@@ -58,7 +58,7 @@ RAGGED = 100_000_000 - 95 * CHUNK     # last chunk of the literal 1e8-sample str
 # the whole 48 B of the chain.  What these launches really move is roofline.traffic.)
 KERNEL_BYTES = {"fir_oa": 16, "sos_dual": 32, "sos_fwd": 16, "sos_bwd": 16, "sos_fwd_split": 16,
                 "sos_bwd_split": 16, "chain_fwd": 32, "chain_step": 48, "sos_warmup": 0,
-                "fir_seam": 0, "spec_fused": 8}
+                "fir_seam": 0, "spec_fused": 8, "poly_block": 9.6}
 CHAIN_BYTES = 48         # FIR 16 + sosfiltfilt 32 (the unfused accounting of the metric)
 METRIC = "Msamples/sec/node (FIR+IIR chain, 256ch f64); HBM GB/s vs roofline at 1/2/4/8 GPU"
 
@@ -84,6 +84,16 @@ def _cpu_welch_worker(args):
     return time.perf_counter() - t0
 
 
+def _cpu_stft_worker(args):
+    ch, n, seed = args
+    from oracle import oracle as orc
+    x = np.random.default_rng(seed).standard_normal((ch, n))
+    t0 = time.perf_counter()
+    y = orc.polyphase_resample(x, 1, 5, orc.resample_filter(1, 5, 20480.0))
+    orc.stft(y, 4096.0, resolution=1.0)
+    return time.perf_counter() - t0
+
+
 def cpu_baseline(workload, h, sos):
     """The CPU oracle (oracle/: NumPy FFT overlap-add + C DF2T loops; NumPy
     windowed rFFT for Welch) on a bounded sample of the same workload: once on
@@ -98,6 +108,9 @@ def cpu_baseline(workload, h, sos):
     if workload == "welch":
         worker, work = _cpu_welch_worker, lambda seed: (ch, n, seed)
         what = "Welch PSD nfft 4096, 50 % overlap"
+    elif workload == "stft":
+        worker, work = _cpu_stft_worker, lambda seed: (ch, n, seed)
+        what = "downsample by 5 (113 taps) -> STFT nfft 4096, 50 % overlap"
     else:
         worker, work = _cpu_worker, lambda seed: (h, sos, ch, n, seed)
         what = "FIR(1024)+sosfiltfilt(6) chain, chunksize 2^20"
@@ -484,6 +497,74 @@ def run_welch(args, R):
     return elapsed, kernels, roofline_of(kernels, C * CHUNK), extra
 
 
+# ------------------------------------------------------------- workload: stft
+STFT_CH = 128            # cfg-5: 1024 channels over 8 GPUs
+
+
+def run_stft(args, R):
+    """cfg-5 (secondary): polyphase downsample 5 -> 1 (default Kaiser anti-alias filter, 113
+    taps) feeding the STFT (nfft 4096, 50 % overlap, complex128 segments), 128 channels per
+    GPU, channels sharded with no collective.  A step = one 2^20-sample input chunk through
+    osz_poly_push and osz_spec_push; the STFT segments go to a fresh buffer per step and are
+    dropped.  14.4 algorithmic bytes per INPUT sample (9.6 + 24 / 5)."""
+    torch = R.torch
+    if R.dry:
+        R.barrier()
+        t0 = time.perf_counter()
+        time.sleep(1e-3 * args.steps)
+        elapsed = R.max_over_ranks(time.perf_counter() - t0)
+        R.barrier()
+        return elapsed, {}, None, None
+    import scipy.signal as sps
+    from openseize_amd import _device as dev
+    from openseize_amd import _lib
+    from openseize_amd.filtering.fir import Kaiser
+    lib = _lib.load()
+    C = STFT_CH
+    cutoff = 20480 / 10
+    hk = Kaiser(cutoff - cutoff / 10, cutoff + cutoff / 10, 20480, gpass=0.1, gstop=40).coeffs
+    w = sps.get_window("hann", NFFT)
+    scale = float(np.sqrt(1 / (4096.0 * np.sum(w ** 2))))
+    ring = [dev.synth_normal(C, CHUNK, seed=0, ch0=R.rank * C, n0=k * CHUNK) for k in range(3)]
+    poly = dev.PolyStream(hk, 1, 5, C)
+    spec = dev.SpecStream(NFFT, NFFT, NFFT // 2, w, scale, "constant", _lib.SPEC_DFT_SEGMENTS, C)
+    nseg = 0
+
+    def step(k):
+        y = poly.push(ring[k % 3], final=False)
+        seg = spec.push(y)
+        return 0 if seg is None else seg.shape[0]
+
+    for k in range(max(args.warmup, 1)):
+        step(k)
+    R.barrier()
+    _lib.check(lib.osz_profile_reset())
+    _lib.check(lib.osz_profile_enable(1))
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        nseg += step(args.warmup + k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.check(lib.osz_profile_enable(0))
+    elapsed = R.max_over_ranks(elapsed)
+    R.barrier()
+    poly.close()
+    spec.close()
+    kernels = kernel_table(lib, C * CHUNK)
+    if "spec_fused" in kernels:       # the STFT kernel sees a fifth of the input samples, 24 B each
+        rec = kernels["spec_fused"]
+        rec["achieved_gbps"] = 24 * C * CHUNK / 5 / (rec["avg_ms"] * 1e-3) / 1e9
+    roof = None
+    if "poly_block" in kernels:
+        rec = kernels["poly_block"]
+        roof = {"kernel": "poly_block (downsample 5 -> 1; the STFT kernel behind it moves half as much)",
+                "bound": "hbm", "achieved": rec["achieved_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": rec["achieved_gbps"] / HBM_PEAK_GBPS, "traffic": None,
+                "traffic_source": "not collected for this workload",
+                "algorithmic_bytes_per_launch": 9.6 * C * CHUNK, "avg_launch_ms": rec["avg_ms"]}
+    return elapsed, kernels, roof, {"stft_segments": nseg, "stft_segments_per_step": nseg / max(args.steps, 1)}
+
+
 # ----------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -493,7 +574,7 @@ def main():
     # of 2.6 ms are a quarter of a second
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=("chain", "welch"), default="chain")
+    ap.add_argument("--workload", choices=("chain", "welch", "stft"), default="chain")
     ap.add_argument("--reduce", choices=("torch", "abi"), default="torch",
                     help="welch: all-reduce through torch.distributed (RCCL) or through "
                          "osz_welch_reduce of the C ABI")
@@ -531,6 +612,13 @@ def main():
             "cfg-4: Welch PSD nperseg 4096, 50 % overlap, hann, 256 ch x 2^20-sample chunks per "
             "GPU, stream split in time across ranks, one all-reduce of (256 x 2049) f64 + count")
         parallelism = f"time-split x{R.world} + all-reduce"
+    elif args.workload == "stft":
+        elapsed, kernels, roofline, extra = run_stft(args, R)
+        metric = "Msamples/sec/node (downsample 5->1 then STFT nfft 4096, 128ch/GPU f64, input samples)"
+        bytes_per_sample, label = 14.4, (
+            "cfg-5: polyphase downsample 5 -> 1 (113-tap Kaiser) -> STFT nfft 4096, 50 % overlap, "
+            "hann, complex128 segments; 128 ch x 2^20-sample input chunks per GPU, channels sharded")
+        parallelism = f"channel-shard x{R.world}"
     else:
         elapsed, kernels, roofline, extra = run_chain(args, R, h, sos)
         metric = METRIC
@@ -542,7 +630,7 @@ def main():
             "cfg-3: 256 ch/GPU x 2^20-sample chunks, FIR overlap-add 1024 taps -> 6-section "
             "Butterworth band-pass sosfiltfilt, steady-state stream; " + how)
         parallelism = f"channel-shard x{R.world}"
-    samples_per_step = C_PER_GPU * CHUNK
+    samples_per_step = (STFT_CH if args.workload == "stft" else C_PER_GPU) * CHUNK
     value = samples_per_step * args.steps * R.world / elapsed / 1e6
     out = {
         "metric": metric, "value": value, "unit": "Msamples/s", "n_gpus": R.world,
@@ -550,7 +638,8 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": label, "channels_per_gpu": C_PER_GPU, "chunksize": CHUNK,
+        "config": {"workload": label,
+                   "channels_per_gpu": STFT_CH if args.workload == "stft" else C_PER_GPU, "chunksize": CHUNK,
                    "fir_taps": NTAPS, "sos_sections": int(sos.shape[0]),
                    "parallelism": parallelism},
         "rccl_ranks": R.ranks_seen(),
