@@ -22,6 +22,10 @@ meet in ONE RCCL all-reduce of (256 x 2049) float64 + the segment count -- the
 "segment-average reduce" of cfg-4, inside the timed region.  A small untimed
 pass then checks the reduced estimate against the single-rank PSD.
 
+Workloads `fir` (configs[1]: 128 channels per GPU through the overlap-add FIR alone, 16 B per
+sample) and `stft` (configs[4]: 128 channels per GPU, polyphase downsample 5 -> 1 then STFT
+nfft 4096 / 50 %, 14.4 B per input sample): channel shards, no collective.
+
 Launching: `python bench.py --gpus N` with N > 1 starts N ranks itself (fresh
 child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before
 anything touches the GPU in the parent); under `torch.distributed.run` the
@@ -108,6 +112,9 @@ def cpu_baseline(workload, h, sos):
     if workload == "welch":
         worker, work = _cpu_welch_worker, lambda seed: (ch, n, seed)
         what = "Welch PSD nfft 4096, 50 % overlap"
+    elif workload == "fir":
+        worker, work = _cpu_fir_worker, lambda seed: (h, ch, n, seed)
+        what = "FIR(1024) overlap-add, mode same"
     elif workload == "stft":
         worker, work = _cpu_stft_worker, lambda seed: (ch, n, seed)
         what = "downsample by 5 (113 taps) -> STFT nfft 4096, 50 % overlap"
@@ -497,6 +504,60 @@ def run_welch(args, R):
     return elapsed, kernels, roofline_of(kernels, C * CHUNK), extra
 
 
+# -------------------------------------------------------------- workload: fir
+FIR_CH = 128             # cfg-2: 128 channels, 1024 taps, chunksize 2^20, one GPU
+
+
+def run_fir(args, R, h):
+    """cfg-2 (secondary): the overlap-add FIR alone, 128 channels per GPU, 1024 taps, a step = one
+    2^20-sample chunk through osz_fir_push (16 algorithmic bytes per sample)."""
+    torch = R.torch
+    if R.dry:
+        R.barrier()
+        t0 = time.perf_counter()
+        time.sleep(1e-3 * args.steps)
+        elapsed = R.max_over_ranks(time.perf_counter() - t0)
+        R.barrier()
+        return elapsed, {}, None, None
+    from openseize_amd import _device as dev
+    from openseize_amd import _lib
+    lib = _lib.load()
+    C = FIR_CH
+    ring = [dev.synth_normal(C, CHUNK, seed=0, ch0=R.rank * C, n0=k * CHUNK) for k in range(3)]
+    fir = dev.FirStream(h, C)
+    out = torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda")
+    for k in range(max(args.warmup, 1)):
+        fir.push(ring[k % 3], 0, out=out)
+    R.barrier()
+    _lib.check(lib.osz_profile_reset())
+    _lib.check(lib.osz_profile_enable(1))
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        fir.push(ring[(args.warmup + k) % 3], 0, out=out)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.check(lib.osz_profile_enable(0))
+    elapsed = R.max_over_ranks(elapsed)
+    R.barrier()
+    bits, fsum = dev.checksum(out)
+    fir.close()
+    kernels = kernel_table(lib, C * CHUNK)
+    roof = roofline_of({k: v for k, v in kernels.items() if k == "fir_oa"}, C * CHUNK) if "fir_oa" in kernels else None
+    if roof is not None and roof.get("traffic"):
+        roof["traffic"] = roof["traffic"] * C / C_PER_GPU      # the counters were collected at 256 channels
+        roof["traffic_source"] += " (scaled from the 256-channel launch)"
+    return elapsed, kernels, roof, {"output_checksum": {"bits": f"{bits:#018x}", "sum": fsum}}
+
+
+def _cpu_fir_worker(args):
+    h, ch, n, seed = args
+    from oracle import oracle as orc
+    x = np.random.default_rng(seed).standard_normal((ch, n))
+    t0 = time.perf_counter()
+    orc.oaconvolve(x, h, "same")
+    return time.perf_counter() - t0
+
+
 # ------------------------------------------------------------- workload: stft
 STFT_CH = 128            # cfg-5: 1024 channels over 8 GPUs
 
@@ -574,7 +635,7 @@ def main():
     # of 2.6 ms are a quarter of a second
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=("chain", "welch", "stft"), default="chain")
+    ap.add_argument("--workload", choices=("chain", "fir", "welch", "stft"), default="chain")
     ap.add_argument("--reduce", choices=("torch", "abi"), default="torch",
                     help="welch: all-reduce through torch.distributed (RCCL) or through "
                          "osz_welch_reduce of the C ABI")
@@ -612,6 +673,12 @@ def main():
             "cfg-4: Welch PSD nperseg 4096, 50 % overlap, hann, 256 ch x 2^20-sample chunks per "
             "GPU, stream split in time across ranks, one all-reduce of (256 x 2049) f64 + count")
         parallelism = f"time-split x{R.world} + all-reduce"
+    elif args.workload == "fir":
+        elapsed, kernels, roofline, extra = run_fir(args, R, h)
+        metric = "Msamples/sec/node (FIR overlap-add 1024 taps, 128ch/GPU f64)"
+        bytes_per_sample, label = 16, (
+            "cfg-2: 128 ch x 2^20-sample chunks per GPU, FIR overlap-add 1024 taps, steady-state stream")
+        parallelism = f"channel-shard x{R.world}"
     elif args.workload == "stft":
         elapsed, kernels, roofline, extra = run_stft(args, R)
         metric = "Msamples/sec/node (downsample 5->1 then STFT nfft 4096, 128ch/GPU f64, input samples)"
@@ -630,7 +697,8 @@ def main():
             "cfg-3: 256 ch/GPU x 2^20-sample chunks, FIR overlap-add 1024 taps -> 6-section "
             "Butterworth band-pass sosfiltfilt, steady-state stream; " + how)
         parallelism = f"channel-shard x{R.world}"
-    samples_per_step = (STFT_CH if args.workload == "stft" else C_PER_GPU) * CHUNK
+    ch_per_gpu = {"stft": STFT_CH, "fir": FIR_CH}.get(args.workload, C_PER_GPU)
+    samples_per_step = ch_per_gpu * CHUNK
     value = samples_per_step * args.steps * R.world / elapsed / 1e6
     out = {
         "metric": metric, "value": value, "unit": "Msamples/s", "n_gpus": R.world,
@@ -639,7 +707,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": label,
-                   "channels_per_gpu": STFT_CH if args.workload == "stft" else C_PER_GPU, "chunksize": CHUNK,
+                   "channels_per_gpu": ch_per_gpu, "chunksize": CHUNK,
                    "fir_taps": NTAPS, "sos_sections": int(sos.shape[0]),
                    "parallelism": parallelism},
         "rccl_ranks": R.ranks_seen(),

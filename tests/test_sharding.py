@@ -111,6 +111,9 @@ def test_bench_launcher_world2_dry():
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
     assert out["welch_check"]["segments"] == 83 and out["welch_check"]["max_rel_err"] < 1e-13
     out = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry",
+                     "--workload", "fir")
+    assert out["n_gpus"] == 2 and out["config"]["channels_per_gpu"] == 128
+    out = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry",
                      "--workload", "stft")
     assert out["n_gpus"] == 2 and out["config"]["channels_per_gpu"] == 128
     assert out["config"]["parallelism"] == "channel-shard x2"
