@@ -534,6 +534,43 @@ def g15_nonfinite():
     save("g15_nonfinite.npz", **out)
 
 
+# --------------------------------------------------------------------------
+# G16 Remez designs (row a13; filtering/fir.py:483-662): taps, tap-count estimate,
+# band type and the derived edges for low / high / band-pass / band-stop /
+# multiband specifications and keyword overrides; one filtered stream through the
+# class API.
+# --------------------------------------------------------------------------
+REMEZ_CASES = [
+    dict(bands=[0, 300, 400, 800, 900, 2500], desired=[0, 1, 0], fs=5000, gpass=.5, gstop=40),
+    dict(bands=[0, 300, 400, 2500], desired=[1, 0], fs=5000),
+    dict(bands=[0, 100, 200, 2500], desired=[0, 1], fs=5000, gpass=1, gstop=60),
+    dict(bands=[0, 200, 300, 600, 700, 2500], desired=[1, 0, 1], fs=5000),
+    dict(bands=[0, 100, 150, 400, 450, 800, 850, 1200, 1250, 2500], desired=[0, 1, 0, 1, 0],
+         fs=5000, gpass=1, gstop=30),
+    dict(bands=[0, 300, 400, 2500], desired=[1, 0], fs=5000, numtaps=101, grid_density=32),
+]
+
+
+def g16_remez():
+    out = {}
+    for i, kw in enumerate(REMEZ_CASES):
+        filt = ref_fir.Remez(**kw)
+        out[f"coeffs{i}"] = filt.coeffs
+        out[f"numtaps{i}"] = np.array(filt.numtaps)
+        out[f"btype{i}"] = np.array(filt.btype)
+        out[f"fpass{i}"], out[f"fstop{i}"] = filt.fpass, filt.fstop
+        out[f"cutoff{i}"], out[f"width{i}"] = filt.cutoff, np.array(filt.width)
+        out[f"delta{i}"] = filt.delta
+    rng = np.random.default_rng(1616)
+    x = rng.standard_normal((3, 30011))
+    out["x"] = x
+    filt = ref_fir.Remez(**REMEZ_CASES[0])
+    out["y0_same"] = filt(x, chunksize=4000, axis=-1, mode="same")
+    res = filt(producer(x, 4000, axis=-1), chunksize=4000, axis=-1, mode="full")
+    out["y0_full_lens"] = lengths(res)
+    save("g16_remez.npz", **out)
+
+
 if __name__ == "__main__":
     g1_producer()
     g2_fir()
@@ -550,3 +587,4 @@ if __name__ == "__main__":
     g13_hilbert()
     g14_metrics_analytic()
     g15_nonfinite()
+    g16_remez()

@@ -76,6 +76,19 @@ def test_fir_class_api(osz, golden):
         assert tuple(res.shape) == tuple(g[f"kaiser_pro_shape_{mode}"])
 
 
+def test_remez_class_api(osz, golden):
+    """A Remez design applied through FIR.__call__ (array in -> array out, producer in ->
+    producer out) against the reference's output (tests/golden/g16_remez.npz)."""
+    from openseize_amd.filtering.fir import Remez
+    g = golden("g16_remez.npz")
+    filt = Remez(bands=[0, 300, 400, 800, 900, 2500], desired=[0, 1, 0], fs=5000, gpass=.5, gstop=40)
+    assert np.array_equal(filt.coeffs, g["coeffs0"])
+    y = filt(g["x"], chunksize=4000, axis=-1, mode="same")
+    assert isinstance(y, np.ndarray) and rel_err(y, g["y0_same"]) < RTOL
+    res = filt(producer(g["x"], 4000, -1), chunksize=4000, axis=-1, mode="full")
+    assert [a.shape[-1] for a in res] == list(g["y0_full_lens"])
+
+
 def test_oaconvolve_edges(osz):
     rng = np.random.default_rng(1)
     from oracle import oracle as orc

@@ -246,6 +246,9 @@ def test_pickleable_pipeline():
         assert q.shape == p.shape and q.chunksize == 1000
     f, wp = nm.welch(pro, 500, 500, "hann", 0.5, -1, "constant", "density")
     assert pickle.loads(pickle.dumps(wp)).shape == wp.shape
+    from openseize_amd.core import resources
+    assert resources.pickleable(wp) and not resources.pickleable(lambda v: v)
+    assert 1 <= resources.allocate(64) <= 64 and resources.allocate(64, 1) == 1
 
 
 def test_no_gpu_fails_loudly():
@@ -424,3 +427,31 @@ def test_pipeline_composition_and_validation():
     pipe2.append(producer, chunksize=4, axis=-1)
     pro = pipe2(np.arange(10.0)[None, :])
     assert [a.shape[-1] for a in pro] == [4, 4, 2]
+
+
+def test_remez_designs_golden():
+    """Remez (filtering/fir.py:483-662): taps, Bellanger tap estimate, band type and
+    derived edges equal the reference's for low / high / band-pass / band-stop /
+    multiband specifications and keyword overrides (tests/golden/g16_remez.npz)."""
+    from conftest import load_golden
+    from openseize_amd.filtering.fir import Remez
+    g = load_golden("g16_remez.npz")
+    cases = [
+        dict(bands=[0, 300, 400, 800, 900, 2500], desired=[0, 1, 0], fs=5000, gpass=.5, gstop=40),
+        dict(bands=[0, 300, 400, 2500], desired=[1, 0], fs=5000),
+        dict(bands=[0, 100, 200, 2500], desired=[0, 1], fs=5000, gpass=1, gstop=60),
+        dict(bands=[0, 200, 300, 600, 700, 2500], desired=[1, 0, 1], fs=5000),
+        dict(bands=[0, 100, 150, 400, 450, 800, 850, 1200, 1250, 2500], desired=[0, 1, 0, 1, 0],
+             fs=5000, gpass=1, gstop=30),
+        dict(bands=[0, 300, 400, 2500], desired=[1, 0], fs=5000, numtaps=101, grid_density=32),
+    ]
+    for i, kw in enumerate(cases):
+        filt = Remez(**kw)
+        assert np.array_equal(filt.coeffs, g[f"coeffs{i}"]), i
+        assert filt.numtaps == int(g[f"numtaps{i}"]) and filt.btype == str(g[f"btype{i}"])
+        assert np.array_equal(filt.fpass, g[f"fpass{i}"]) and np.array_equal(filt.fstop, g[f"fstop{i}"])
+        assert np.allclose(filt.cutoff, g[f"cutoff{i}"], rtol=0, atol=0)
+        assert filt.width == float(g[f"width{i}"]) and np.array_equal(filt.delta, g[f"delta{i}"])
+        assert filt.ftype == "remez"
+    with pytest.raises(ValueError):
+        Remez(bands=[0, 300, 400, 800, 2500], desired=[1, 0], fs=5000)     # odd number of edges
