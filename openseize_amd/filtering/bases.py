@@ -73,6 +73,31 @@ class _Spec:
         """SciPy's name of the design family = the class name in lower case."""
         return self.__class__.__name__.lower()
 
+    # -- design-time inspection (the numeric half of the reference's viewer mixins,
+    # filtering/mixins.py:226-317; its plotting half is out of scope)
+    def _transfer(self, worN):
+        raise NotImplementedError
+
+    def frequency_response(self, scale, worN, rope):
+        """(frequencies in [0, Nyquist), response, scale): the response in decibels with
+        everything below ``rope`` dB clipped to it ('dB'), as magnitude ('abs') or complex
+        ('complex')."""
+        freqs, h = self._transfer(worN)
+        if scale == "dB":
+            gain = 20 * np.log10(np.maximum(np.abs(h), 10 ** (rope / 20)))
+        elif scale == "abs":
+            gain = np.abs(h)
+        elif scale == "complex":
+            gain = h
+        else:
+            raise ValueError(f"scale must be 'dB', 'abs' or 'complex', got {scale!r}")
+        return freqs, gain, scale
+
+    def impulse_response(self):
+        """The response to a unit pulse at sample 0 of a one-second record -- run through
+        the filter's own streaming path (``__call__``), causal."""
+        return self._pulse_response(sps.unit_impulse(int(self.fs)))
+
 
 class IIR(_Spec):
     """Infinite impulse response filters.  A concrete family names its SciPy
@@ -92,6 +117,14 @@ class IIR(_Spec):
     @property
     def btype(self):
         return band_kind(self.fpass, self.fstop)
+
+    def _transfer(self, worN):
+        if self.fmt == "sos":
+            return sps.sosfreqz(self.coeffs, fs=self.fs, worN=worN)
+        return sps.freqz(*self.coeffs, fs=self.fs, worN=worN)
+
+    def _pulse_response(self, pulse):
+        return self(pulse, chunksize=len(pulse), axis=-1, dephase=False)
 
     @property
     def order(self):
@@ -139,6 +172,12 @@ class FIR(_Spec):
     @property
     def btype(self):
         return band_kind(self.fpass, self.fstop, max_edges=2, owner=type(self))
+
+    def _transfer(self, worN):
+        return sps.freqz(self.coeffs, fs=self.fs, worN=worN)
+
+    def _pulse_response(self, pulse):
+        return self(pulse, chunksize=len(pulse), axis=-1, mode="full")
 
     @property
     def pass_attenuation(self):

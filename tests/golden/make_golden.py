@@ -571,6 +571,24 @@ def g16_remez():
     save("g16_remez.npz", **out)
 
 
+# --------------------------------------------------------------------------
+# G17 design-time inspection (filtering/mixins.py:226-317): impulse and frequency
+# responses of an sos IIR, a ba IIR and a FIR.
+# --------------------------------------------------------------------------
+def g17_responses():
+    out = {}
+    filts = {"butter": ref_iir.Butter(fpass=[8, 30], fstop=[3, 60], fs=500, gpass=1, gstop=40),
+             "notch": ref_iir.Notch(60, 8, 500),
+             "kaiser": ref_fir.Kaiser(fpass=200, fstop=400, fs=5000, gpass=0.5, gstop=40)}
+    for name, filt in filts.items():
+        out[f"{name}_impulse"] = filt.impulse_response()
+        for scale in ("dB", "abs", "complex"):
+            freqs, gain, _ = filt.frequency_response(scale, 512, -100)
+            out[f"{name}_freqs"] = freqs
+            out[f"{name}_{scale}"] = gain
+    save("g17_responses.npz", **out)
+
+
 if __name__ == "__main__":
     g1_producer()
     g2_fir()
@@ -588,3 +606,4 @@ if __name__ == "__main__":
     g14_metrics_analytic()
     g15_nonfinite()
     g16_remez()
+    g17_responses()

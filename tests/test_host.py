@@ -455,3 +455,22 @@ def test_remez_designs_golden():
         assert filt.ftype == "remez"
     with pytest.raises(ValueError):
         Remez(bands=[0, 300, 400, 800, 2500], desired=[1, 0], fs=5000)     # odd number of edges
+
+
+def test_frequency_responses_golden():
+    """frequency_response(scale, worN, rope) of an sos IIR, a ba IIR and a FIR equal the
+    reference's (filtering/mixins.py:240-317; tests/golden/g17_responses.npz)."""
+    from conftest import load_golden
+    from openseize_amd.filtering.fir import Kaiser
+    from openseize_amd.filtering.iir import Butter, Notch
+    g = load_golden("g17_responses.npz")
+    filts = {"butter": Butter(fpass=[8, 30], fstop=[3, 60], fs=500, gpass=1, gstop=40),
+             "notch": Notch(60, 8, 500),
+             "kaiser": Kaiser(fpass=200, fstop=400, fs=5000, gpass=0.5, gstop=40)}
+    for name, filt in filts.items():
+        for scale in ("dB", "abs", "complex"):
+            freqs, gain, sc = filt.frequency_response(scale, 512, -100)
+            assert sc == scale and np.array_equal(freqs, g[f"{name}_freqs"])
+            assert np.array_equal(gain, g[f"{name}_{scale}"]), (name, scale)
+    with pytest.raises(ValueError):
+        filts["kaiser"].frequency_response("power", 512, -100)
