@@ -142,3 +142,55 @@ def test_nonfinite_reach_fused_chain(nm):
         assert np.isfinite(xc).all()
         w = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xc, taps, "same"), -1), sos, cs)
         assert np.max(np.abs(got[c, :upto * cs] - w[0, :upto * cs])) < RTOL * np.max(np.abs(w))
+
+
+def test_nonfinite_reach_at_the_headline_geometry(nm):
+    """cfg-3's own geometry (256 channels x 2^20-sample chunks through osz_chain_step, two
+    fused runs and three backward segments per channel): one NaN in one channel of chunk 2
+    leaves every other channel bit-identical to the clean run, and that channel NaN from
+    chunk 1 on (the chunk before the NaN: its backward warm-up runs over it)."""
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    taps = sps.firwin(1024, 0.2)
+    C, cs, nchunks = 256, 1 << 20, 5
+    ring = [dev.synth_normal(C, cs, seed=8, n0=k * cs) for k in range(nchunks)]
+
+    def run(poison):
+        if poison:
+            saved = float(ring[2][77, 400000])
+            ring[2][77, 400000] = float("nan")
+        def chunks():
+            yield from ring
+
+        src = producer(chunks, cs, -1, shape=(C, cs * nchunks))
+        fir = producer(partial(nm.oaconvolve, src, taps, -1, "same"), cs, -1, shape=src.shape)
+        sums, nanmask = [], []
+        plain_step = dev.chain_step
+        dev.chain_step = lambda *a, **k: (steps.append(1), plain_step(*a, **k))[1]
+        outs = nm.sosfiltfilt(fir, sos, -1)
+        for out in outs:
+            bad = torch.isnan(out).any(dim=1)
+            allbad = torch.isnan(out).all(dim=1)
+            assert torch.equal(bad, allbad)            # a channel's chunk is NaN as a whole or not at all
+            nanmask.append(bad.cpu().numpy())
+            sums.append(torch.where(bad[:, None], torch.zeros_like(out), out).view(torch.int64).sum(dim=1).cpu().numpy())
+            del out
+        dev.chain_step = plain_step
+        if poison:
+            ring[2][77, 400000] = saved
+        return np.array(nanmask), np.array(sums)
+
+    steps = []
+    clean_mask, clean_sums = run(False)
+    assert len(steps) == nchunks - 2, "the fused step did not run"
+    assert not clean_mask.any()
+    mask, sums = run(True)
+    want = np.zeros_like(mask)
+    want[1:, 77] = True
+    assert np.array_equal(mask, want)
+    keep = np.ones(C, dtype=bool)
+    keep[77] = False
+    assert np.array_equal(sums[:, keep], clean_sums[:, keep])      # bit patterns, channel by channel
+    assert np.array_equal(sums[0], clean_sums[0])
