@@ -54,6 +54,30 @@ int current_device(int *dev);
 
 constexpr int kWave = 64;  // CDNA wavefront width
 
+// DPP moves with bound_ctrl (lanes without a source read 0) and no `old`
+// operand: nothing to initialise in front of them.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov0(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes of a wave, valid in LANE 63 (the other lanes hold partial
+// sums): four row_shr steps inside the 16-lane rows, then row_bcast:15 (a row takes the
+// total of the row before it) and row_bcast:31 (lanes 32..63 take lane 31) -- vector
+// moves only, where a __shfl_down chain goes through the LDS crossbar (ds_bpermute) and
+// waits for it six times.  (benchmarks/dpp_probe.hip pins what these controls deliver.)
+__device__ __forceinline__ double wave_sum63(double v) {
+    v += dpp_mov0<0x111>(v);
+    v += dpp_mov0<0x112>(v);
+    v += dpp_mov0<0x114>(v);
+    v += dpp_mov0<0x118>(v);
+    v += dpp_mov0<0x142>(v);
+    v += dpp_mov0<0x143>(v);
+    return v;
+}
+
 // rccl.hip: in-place all-reduce(sum) of `count` float64 / int64 elements over
 // the ranks of an ncclComm_t; RCCL is bound at run time (dlopen)
 int rccl_allreduce_sum(void *buf, size_t count, bool is_f64, void *comm, hipStream_t st);

@@ -154,14 +154,7 @@ constexpr int kSos2Tab = 66;                   // A^(T k), k = 0 .. 64, then one
 constexpr int kSos2Zero = 65;
 
 
-// DPP moves with bound_ctrl (lanes without a source read 0) and no `old`
-// operand: nothing to initialise in front of them.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov0(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
+// (dpp_mov0: common.h)
 // lane i <- lane i - D inside its 16-lane row, 0 for the first D lanes
 template <int D>
 __device__ __forceinline__ double dpp_row_shr0(double v) { return dpp_mov0<0x110 + D>(v); }

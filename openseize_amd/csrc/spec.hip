@@ -273,15 +273,13 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
                 lin_b += (i - mid) * im[j];
             }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            sum_a += __shfl_down(sum_a, off, 64);
-            sum_b += __shfl_down(sum_b, off, 64);
-            if (LINEAR) {
-                lin_a += __shfl_down(lin_a, off, 64);
-                lin_b += __shfl_down(lin_b, off, 64);
-            }
+        sum_a = wave_sum63(sum_a);
+        sum_b = wave_sum63(sum_b);
+        if (LINEAR) {
+            lin_a = wave_sum63(lin_a);
+            lin_b = wave_sum63(lin_b);
         }
-        if ((t & 63) == 0) {
+        if ((t & 63) == 63) {
             red[t >> 6][0] = sum_a;
             red[t >> 6][1] = sum_b;
             red[t >> 6][2] = lin_a;
@@ -528,15 +526,13 @@ __global__ __launch_bounds__(N / 8, 4) void spec8_kernel(Spec8Args a) {
                 lin_b += (i - mid) * im[r];
             }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            sum_a += __shfl_down(sum_a, off, 64);
-            sum_b += __shfl_down(sum_b, off, 64);
-            if (LINEAR) {
-                lin_a += __shfl_down(lin_a, off, 64);
-                lin_b += __shfl_down(lin_b, off, 64);
-            }
+        sum_a = wave_sum63(sum_a);
+        sum_b = wave_sum63(sum_b);
+        if (LINEAR) {
+            lin_a = wave_sum63(lin_a);
+            lin_b = wave_sum63(lin_b);
         }
-        if ((t & 63) == 0) {
+        if ((t & 63) == 63) {
             red[t >> 6][0] = sum_a;
             red[t >> 6][1] = sum_b;
             red[t >> 6][2] = lin_a;

@@ -218,11 +218,9 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
                 }
             }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            sum += __shfl_down(sum, off, 64);
-            if (LINEAR) lin += __shfl_down(lin, off, 64);
-        }
-        if ((t & 63) == 0) {
+        sum = wave_sum63(sum);
+        if (LINEAR) lin = wave_sum63(lin);
+        if ((t & 63) == 63) {
             red[t >> 6][0] = sum;
             red[t >> 6][1] = lin;
         }
