@@ -52,3 +52,65 @@ def multiply_along_axis(x, y, axis=-1):
     shape = [1] * x.ndim
     shape[axis] = len(y)
     return x * y.reshape(shape)
+
+
+# ---- host-side utilities off the hot path (core/arraytools.py:85-312), kept so that
+# code importing them from the reference finds them here too
+def expand_along_axis(arr, l, value=0, axis=-1):
+    """Every sample along ``axis`` followed by ``l - 1`` copies of ``value``
+    (zero stuffing for l-fold upsampling)."""
+    moved = np.moveaxis(np.asarray(arr), axis, -1)
+    out = np.full(moved.shape + (l,), value, dtype=np.result_type(moved, type(value)))
+    out[..., 0] = moved
+    return np.moveaxis(out.reshape(moved.shape[:-1] + (-1,)), -1, axis)
+
+
+def filter1D(size, indices):
+    """Boolean mask of length ``size`` that is True at every index or slice in ``indices``."""
+    mask = np.zeros(int(size), dtype=bool)
+    for where in np.atleast_1d(np.array(indices, dtype=object)):
+        mask[where] = True
+    return mask
+
+
+def nearest1D(x, x0):
+    """Index of the element of ``x`` closest to ``x0``."""
+    return np.argmin(np.abs(x - x0))
+
+
+def zero_extend(arr, n, axis=-1):
+    """``n`` zeros on either side along ``axis``."""
+    return pad_along_axis(arr, n, axis=axis)
+
+
+def edge_extend(arr, n, axis=-1):
+    """The first and the last sample repeated ``n`` times on their sides."""
+    pads = [(0, 0)] * np.ndim(arr)
+    pads[axis] = (n, n)
+    return np.pad(arr, pads, mode="edge")
+
+
+def _mirrored_ends(arr, n, axis):
+    """The ``n`` samples next to either end, mirrored (end samples excluded); the
+    reference's length check with SciPy's wording."""
+    limit = arr.shape[axis] - 1
+    if n > limit:
+        raise ValueError("The extension length n ({}) is too big. It must not "
+                         "exceed x.shape[axis] - 1, which is {}.".format(n, limit))
+    head = slice_along_axis(arr, n, 0, -1, axis=axis)
+    tail = slice_along_axis(arr, -2, -(n + 2), -1, axis=axis)
+    return head, tail
+
+
+def even_extend(arr, n, axis=-1):
+    """Mirror images of the ``n`` samples next to either end."""
+    head, tail = _mirrored_ends(arr, n, axis)
+    return np.concatenate((head, arr, tail), axis=axis)
+
+
+def odd_extend(arr, n, axis=-1):
+    """Point reflections about the end samples of the ``n`` samples next to them."""
+    head, tail = _mirrored_ends(arr, n, axis)
+    first = slice_along_axis(arr, 0, 1, axis=axis)
+    last = slice_along_axis(arr, -1, None, axis=axis)
+    return np.concatenate((2 * first - head, arr, 2 * last - tail), axis=axis)
