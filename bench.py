@@ -243,6 +243,18 @@ def kernel_sources_sha():
     return hsh.hexdigest()
 
 
+def committed_traffic(key):
+    """(HBM bytes per launch of `key` from the committed counter passes, where it comes from);
+    None when the kernel sources are not the ones those passes ran."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tfile):
+        return None, "profiles/traffic.json missing"
+    tj = json.load(open(tfile))
+    if tj.get("_kernel_sources_sha256") != kernel_sources_sha():
+        return None, "stale: kernel sources changed since the --pmc passes (re-run refresh_profiles.sh)"
+    return tj.get(key), "rocprofv3 --pmc passes of these kernel sources"
+
+
 def roofline_of(kernels, samples_per_step):
     # one osz_chain_step is the unit when the step ran: its members (fused kernel on
     # the caller's stream, backward pass on the handle's) overlap inside it, and a
@@ -251,14 +263,7 @@ def roofline_of(kernels, samples_per_step):
     # PMC counters cannot be read from inside a timed run: the bytes come from the
     # committed rocprofv3 --pmc passes, and only while the kernel sources are the ones
     # those passes ran (fingerprint written by benchmarks/summarise_profiles.py)
-    traffic, traffic_note = None, "profiles/traffic.json missing"
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
-        tj = json.load(open(tfile))
-        if tj.get("_kernel_sources_sha256") == kernel_sources_sha():
-            traffic, traffic_note = tj.get(dom), "rocprofv3 --pmc passes of these kernel sources"
-        else:
-            traffic_note = "stale: kernel sources changed since the --pmc passes (re-run refresh_profiles.sh)"
+    traffic, traffic_note = committed_traffic(dom)
     out = {"kernel": dom, "bound": "hbm",
            "achieved": kernels[dom]["achieved_gbps"], "peak": HBM_PEAK_GBPS,
            "unit": "GB/s", "frac": kernels[dom]["achieved_gbps"] / HBM_PEAK_GBPS,
@@ -620,9 +625,12 @@ def run_stft(args, R):
         rec = kernels["poly_block"]
         roof = {"kernel": "poly_block (downsample 5 -> 1; the STFT kernel behind it moves half as much)",
                 "bound": "hbm", "achieved": rec["achieved_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": rec["achieved_gbps"] / HBM_PEAK_GBPS, "traffic": None,
-                "traffic_source": "not collected for this workload",
+                "frac": rec["achieved_gbps"] / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                 "algorithmic_bytes_per_launch": 9.6 * C * CHUNK, "avg_launch_ms": rec["avg_ms"]}
+    if roof is not None:
+        tr, note = committed_traffic("poly_block")
+        roof["traffic"] = tr * C / C_PER_GPU if tr else None      # collected at 256 channels
+        roof["traffic_source"] = note + (" (scaled from the 256-channel launch)" if tr else "")
     return elapsed, kernels, roof, {"stft_segments": nseg, "stft_segments_per_step": nseg / max(args.steps, 1)}
 
 

@@ -97,6 +97,15 @@ def main():
     traffic["_note"] = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                         "(separate passes), (2*FETCH_SIZE + WRITE_SIZE)*1024; see "
                         f"{tag}_pmc_hbm_traffic.csv and profiles/README.md for the calibration.")
+    # the secondary workloads' kernels (bench.py --workload welch / stft): bytes per launch
+    # from the counter passes of benchmarks/collect_pmc.sh secondary, when reduced already
+    sec = os.path.join(out, f"{tag}_pmc_sec.json")
+    if os.path.exists(sec):
+        pmc = json.load(open(sec))
+        for key, name in (("spec_fused", "void spec_cube_kernel<0, false, true>"),
+                          ("poly_block", "void poly_block_kernel<true, 256, 1>")):
+            if name in pmc and pmc[name].get("hbm_bytes"):
+                traffic[key] = pmc[name]["hbm_bytes"]
     traffic["_kernel_sources_sha256"] = kernel_sources_sha()
     with open(os.path.join(out, "traffic.json"), "w") as fh:
         json.dump(traffic, fh, indent=1)
