@@ -190,6 +190,16 @@ static int chain_forward_impl(osz_fir_t fir, osz_sos_t sos, const double *x, int
     OSZ_SAME_DEVICE(fir, "osz_chain_forward");
     OSZ_SAME_DEVICE(sos, "osz_chain_forward");
     hipStream_t st = as_stream(stream);
+    {
+        // cascades whose ringing dies within the guard rows of the transform: FIR and
+        // cascade as one multiplication per bin (chain_spec.hip), any chunk length
+        bool taken = false;
+        int rc = spec_try_forward(fir, sos, x, ldx, n, f, ldf, st, between, &taken);
+        if (rc || taken) return rc;
+        // not this time: the kernels below work on the handles' own states
+        rc = spec_touch(sos->spec, st);
+        if (rc) return rc;
+    }
     // The samples that are not whole block pairs go FIRST, through the plain kernels
     // (FIR into the output rows, then the cascade in place): as the head of the chunk
     // they are queued before the fused kernel and, in osz_chain_step, before the

@@ -442,6 +442,8 @@ int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch) {
     p->device = 0;
     (void)hipGetDevice(&p->device);
     p->dtails = p->dD = p->dW = nullptr;
+    p->spec = nullptr;
+    p->htaps.assign(taps, taps + ntaps);
     p->tails_cap = p->w_cap = 0;
     p->dlen = 0;
     int rc = get_fft_tables(p->tb);
@@ -472,6 +474,7 @@ int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch) {
 
 int osz_fir_destroy(osz_fir_t h) {
     if (!h) return OSZ_OK;
+    spec_unlink(h->spec);
     for (auto &pt : h->parts) {
         (void)hipFree(pt.dH);
         (void)hipFree(pt.dstate[0]);
@@ -487,6 +490,10 @@ int osz_fir_destroy(osz_fir_t h) {
 int osz_fir_reset(osz_fir_t h, void *stream) {
     OSZ_REQUIRE(h, "osz_fir_reset: null handle");
     hipStream_t st = as_stream(stream);
+    {
+        int rc = spec_touch(h->spec, st);
+        if (rc) return rc;
+    }
     for (auto &pt : h->parts)
         OSZ_HIP(hipMemsetAsync(pt.dstate[pt.cur], 0,
                                sizeof(double) * (size_t)h->nch * (pt.ntaps > 1 ? pt.ntaps - 1 : 1),
@@ -528,12 +535,20 @@ static int fir_state_copy(osz_fir_t h, double *host, bool to_host, hipStream_t s
 int osz_fir_get_state(osz_fir_t h, double *state, void *stream) {
     OSZ_REQUIRE(h && state, "osz_fir_get_state: null argument");
     OSZ_SAME_DEVICE(h, "osz_fir_get_state");
+    {
+        int rc = spec_settle(h->spec, as_stream(stream));
+        if (rc) return rc;
+    }
     return fir_state_copy(h, state, true, as_stream(stream));
 }
 
 int osz_fir_set_state(osz_fir_t h, const double *state, void *stream) {
     OSZ_REQUIRE(h && state, "osz_fir_set_state: null argument");
     OSZ_SAME_DEVICE(h, "osz_fir_set_state");
+    {
+        int rc = spec_touch(h->spec, as_stream(stream));
+        if (rc) return rc;
+    }
     return fir_state_copy(h, const_cast<double *>(state), false, as_stream(stream));
 }
 
@@ -545,7 +560,17 @@ int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y
     OSZ_REQUIRE(skip == n || (y && ldy >= n - skip), "osz_fir_push: bad output");
     if (n == 0) return OSZ_OK;
     OSZ_SAME_DEVICE(h, "osz_fir_push");
-    hipStream_t st = as_stream(stream);
+    {
+        int rc = spec_touch(h->spec, as_stream(stream));
+        if (rc) return rc;
+    }
+    return fir_push_raw(h, x, ldx, n, y, ldy, skip, as_stream(stream));
+}
+
+}  // extern "C"
+
+int osz::fir_push_raw(osz_fir_s *h, const double *x, int64_t ldx, int64_t n, double *y, int64_t ldy,
+                      int64_t skip, hipStream_t st) {
     if (h->parts.size() == 1)
         return fir_part_push(h, h->parts[0], x, ldx, n, y, ldy, skip, 0, st);
     // partitioned: accumulate every piece into W = [deferred | n new positions]
@@ -577,8 +602,14 @@ int osz_fir_push(osz_fir_t h, const double *x, int64_t ldx, int64_t n, double *y
     return OSZ_OK;
 }
 
+extern "C" {
+
 int osz_fir_flush(osz_fir_t h, double *y, int64_t ldy, int64_t skip, int64_t drop, void *stream) {
     OSZ_REQUIRE(h, "osz_fir_flush: null handle");
+    {
+        int rc = spec_settle(h->spec, as_stream(stream));
+        if (rc) return rc;
+    }
     const int64_t wm1 = h->ntaps - 1;
     OSZ_REQUIRE(skip >= 0 && drop >= 0 && skip + drop <= wm1, "osz_fir_flush: skip=%lld drop=%lld",
                 (long long)skip, (long long)drop);

@@ -3,11 +3,16 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <vector>
 
 #include "fft4096.h"
 #include "sos_tile.h"
+
+namespace osz {
+struct ChainSpec;   // chain_spec.hip: a FIR and a SOS handle that run the spectral kernel together
+}
 
 struct FirPart {
     int ntaps, step;
@@ -27,6 +32,8 @@ struct osz_fir_s {
     double *dW;         // partitioned: work rows
     int64_t w_cap;      // doubles
     osz::fft::Tables tb;
+    std::vector<double> htaps;   // host copy of the taps
+    osz::ChainSpec *spec;        // set while the handle's stream runs in the spectral chain kernel
 };
 
 
@@ -59,6 +66,7 @@ struct osz_sos_s {
     bool side_busy;                       // a deferred backward pass may still be running
     const double *side_in[2];             // fa, fb of that pass: (nch, n) views with row pitch ld
     int64_t side_ld[2], side_n[2];
+    osz::ChainSpec *spec;                 // see osz_fir_s
 };
 
 namespace osz {
@@ -79,4 +87,18 @@ int sos_lane_table_for(osz_sos_s *h, int T, const double **dtab);
 int sosfiltfilt_chunk_on(osz_sos_s *h, const double *fa, int64_t ldfa, int64_t na, const double *fb,
                          int64_t ldfb, int64_t nb, double *y, int64_t ldy, double *tmp, double *carry,
                          hipStream_t st);
+// ---- chain_spec.hip: FIR -> forward cascade in the spectrum.  While a pair of handles
+// runs it, their own states (overlap tail, section states) are not kept up to date:
+// every entry point that reads them calls spec_settle first, every one that changes
+// them spec_touch.
+int spec_try_forward(osz_fir_s *fir, osz_sos_s *sos, const double *x, int64_t ldx, int64_t n, double *f,
+                     int64_t ldf, hipStream_t st, const std::function<int()> &between, bool *taken);
+int spec_settle(ChainSpec *s, hipStream_t st);
+int spec_touch(ChainSpec *s, hipStream_t st);
+void spec_unlink(ChainSpec *s);
+// the entry points osz_fir_push / osz_sos_forward without those calls (fir.hip, sos.hip)
+int fir_push_raw(osz_fir_s *h, const double *x, int64_t ldx, int64_t n, double *y, int64_t ldy,
+                 int64_t skip, hipStream_t st);
+int sos_forward_raw(osz_sos_s *h, const double *x, int64_t ldx, double *y, int64_t ldy, int64_t n,
+                    hipStream_t st);
 }  // namespace osz

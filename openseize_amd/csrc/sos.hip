@@ -1360,6 +1360,7 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     p->side_cur = 0;
     p->dtmp_side = p->dcarry_side = nullptr;
     p->side_busy = false;
+    p->spec = nullptr;
     p->touch = 0;
     if (const char *e = getenv("OSZ_SOS_TOUCH")) p->touch = atoi(e);
     {
@@ -1416,6 +1417,7 @@ int64_t osz_sos_warm_len(osz_sos_t h) { return h ? h->warm_len : -1; }
 
 int osz_sos_destroy(osz_sos_t h) {
     if (!h) return OSZ_OK;
+    spec_unlink(h->spec);
     if (h->side) (void)hipStreamSynchronize(h->side);   // a deferred backward pass of osz_chain_step
     (void)hipFree(h->dsec);
     for (int i = 0; i < 33; ++i) (void)hipFree(h->dsec_t[i]);
@@ -1441,6 +1443,10 @@ int osz_sos_set_state(osz_sos_t h, const double *zi, void *stream) {
     OSZ_REQUIRE(h, "osz_sos_set_state: null handle");
     const size_t sb = sizeof(double) * (size_t)h->nsec * h->nch * 2;
     hipStream_t st = as_stream(stream);
+    {
+        int rc = spec_touch(h->spec, st);
+        if (rc) return rc;
+    }
     if (zi) {
         OSZ_HIP(hipMemcpyAsync(h->dstate, zi, sb, hipMemcpyHostToDevice, st));
     } else {
@@ -1454,6 +1460,10 @@ int osz_sos_get_state(osz_sos_t h, double *zf, void *stream) {
     OSZ_REQUIRE(h && zf, "osz_sos_get_state: null argument");
     const size_t sb = sizeof(double) * (size_t)h->nsec * h->nch * 2;
     hipStream_t st = as_stream(stream);
+    {
+        int rc = spec_settle(h->spec, st);
+        if (rc) return rc;
+    }
     OSZ_HIP(hipMemcpyAsync(zf, h->dstate, sb, hipMemcpyDeviceToHost, st));
     OSZ_HIP(hipStreamSynchronize(st));
     return OSZ_OK;
@@ -1473,6 +1483,10 @@ int osz_sos_set_state_scaled(osz_sos_t h, const double *x, int64_t ldx, int64_t 
                              void *stream) {
     OSZ_REQUIRE(h && x, "osz_sos_set_state_scaled: null argument");
     hipStream_t st = as_stream(stream);
+    {
+        int rc = spec_touch(h->spec, st);
+        if (rc) return rc;
+    }
     const int total = h->nsec * h->nch;
     hipLaunchKernelGGL(sos_scale_state_kernel, dim3((total + 255) / 256), dim3(256), 0, st,
                        h->dstate, h->dzi, x, ldx, col, h->nsec, h->nch);
@@ -1487,6 +1501,18 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y, int64_
                 (long long)n, (long long)ldx, (long long)ldy);
     if (n == 0) return OSZ_OK;
     OSZ_SAME_DEVICE(h, "osz_sos_forward");
+    {
+        int rc = spec_touch(h->spec, as_stream(stream));
+        if (rc) return rc;
+    }
+    return sos_forward_raw(h, x, ldx, y, ldy, n, as_stream(stream));
+}
+
+}  // extern "C"
+
+int osz::sos_forward_raw(osz_sos_s *h, const double *x, int64_t ldx, double *y, int64_t ldy, int64_t n,
+                         hipStream_t st_) {
+    void *stream = st_;
     SosArgs a{};
     a.x = x;
     a.y = y;
@@ -1508,6 +1534,8 @@ int osz_sos_forward(osz_sos_t h, const double *x, int64_t ldx, double *y, int64_
     return OSZ_OK;
 }
 
+extern "C" {
+
 int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, double *f,
                          int64_t ldf, const double *fa, int64_t ldfa, int64_t na,
                          const double *fb, int64_t ldfb, int64_t nb, double *y, int64_t ldy,
@@ -1517,6 +1545,10 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
     OSZ_REQUIRE(na >= 1 && ldfa >= na && ldy >= na, "osz_sosfiltfilt_step: bad chunk a");
     OSZ_REQUIRE(!fb || (nb >= 1 && ldfb >= nb), "osz_sosfiltfilt_step: bad chunk b");
     OSZ_SAME_DEVICE(h, "osz_sosfiltfilt_step");
+    {
+        int rc = spec_touch(h->spec, as_stream(stream));
+        if (rc) return rc;
+    }
     const int64_t tile = (int64_t)h->NW * 64 * h->T;
     const bool fusable = h->T == 32 && h->NW == 4 && nx % tile == 0 && na % tile == 0 &&
                          h->nch >= 96;   // fewer channels: time-split launches fill the chip better

@@ -1,0 +1,284 @@
+// spec_tables.h -- the host-side tables of the spectral FIR -> cascade kernel
+// (chain_spec.hip), in long double, free of HIP so that tests/host/spec_host_check.cpp
+// can build them with g++ and tests/test_spec_host.py can hold them against NumPy
+// and run the block algorithm with them on the CPU.
+//
+// For taps h (wlen of them) and a cascade of biquads (reference layout
+// b0 b1 b2 1 a1 a2, core/numerical.py:301-335):
+//   NR    rows of 256 samples per block: the largest with 256 NR + wlen - 1 <= 3840, so
+//         that row 15 of the 4096-sample window holds nothing but the cascade's ringing
+//   modes lambda_q: one pole per conjugate pair, every real pole (a double pole, a pole
+//         on or outside the unit circle, more than 6 modes: not eligible)
+//   H     [4096][2]  FFT(h) * prod_s B_s / A_s at the 4096 bins, divided by 4096
+//   M     [2 NM][64] mu = M y: y = the first 64 samples of row 15, mu_q = the amplitude of
+//         mode q extrapolated to window sample 4096 (re rows, then im rows); least squares
+//         on the basis Re(lambda^l), -Im(lambda^l) by Householder QR
+//   P     [32][NM][2] lambda^(16 i), i < 16, then lambda^i, i < 16
+//   L     [5][NM][2]  lambda^(256 r)
+//   R     rows of 256 samples over which a burst exceeds 3e-18 of the output scale, from
+//         the tail energy of the composite impulse response
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <vector>
+
+namespace osz {
+namespace spec {
+
+typedef long double ld_t;
+
+constexpr int kFit = 64;      // samples of row 15 the fit reads (one wave)
+constexpr int kRMax = 5;      // burst rows supported
+constexpr int kN = 4096;
+
+struct Tables {
+    bool eligible = false;
+    int NR = 0, NM = 0, nm = 0, R = 0;
+    double fit_ratio = 0.0;                  // min |R_ii| / max |R_ii| of the fit's QR
+    std::vector<double> H, M, P, L;
+};
+
+// FFT of the zero-padded taps, 4096 points, decimation in time
+inline void fir_spectrum(const double *taps, int ntaps, std::vector<ld_t> &fr, std::vector<ld_t> &fi) {
+    const ld_t PI = acosl(-1.0L);
+    std::vector<ld_t> wc(kN / 2), ws(kN / 2);
+    for (int j = 0; j < kN / 2; ++j) {
+        const ld_t ang = -2.0L * PI * (ld_t)j / (ld_t)kN;
+        wc[j] = cosl(ang);
+        ws[j] = sinl(ang);
+    }
+    fr.assign(kN, 0.0L);
+    fi.assign(kN, 0.0L);
+    for (int m = 0; m < ntaps && m < kN; ++m) {           // bit-reversed load
+        unsigned r = 0;
+        for (int b = 0; b < 12; ++b) r |= ((unsigned)(m >> b) & 1u) << (11 - b);
+        fr[r] = (ld_t)taps[m];
+    }
+    for (int len = 2; len <= kN; len <<= 1) {
+        const int half = len >> 1, tstep = kN / len;
+        for (int base = 0; base < kN; base += len)
+            for (int j = 0; j < half; ++j) {
+                const ld_t c = wc[j * tstep], sn = ws[j * tstep];
+                const int u = base + j, v = u + half;
+                const ld_t tr = fr[v] * c - fi[v] * sn, ti = fr[v] * sn + fi[v] * c;
+                fr[v] = fr[u] - tr;
+                fi[v] = fi[u] - ti;
+                fr[u] += tr;
+                fi[u] += ti;
+            }
+    }
+}
+
+// P = pinv(B) by Householder QR; B is m x n (column major), m >= n, P is n x m (row
+// major); returns min |R_ii| / max |R_ii| (0: rank deficient)
+inline ld_t pinv_qr(std::vector<ld_t> B, int m, int n, std::vector<ld_t> &Pinv) {
+    std::vector<ld_t> Qt((size_t)m * m, 0.0L);             // Q^T, accumulated
+    for (int i = 0; i < m; ++i) Qt[(size_t)i * m + i] = 1.0L;
+    auto Bm = [&](int i, int j) -> ld_t & { return B[(size_t)j * m + i]; };
+    for (int k = 0; k < n; ++k) {
+        ld_t nrm = 0.0L;
+        for (int i = k; i < m; ++i) nrm += Bm(i, k) * Bm(i, k);
+        nrm = sqrtl(nrm);
+        if (nrm == 0.0L) return 0.0L;
+        const ld_t alpha = Bm(k, k) > 0 ? -nrm : nrm;
+        std::vector<ld_t> v(m, 0.0L);
+        for (int i = k; i < m; ++i) v[i] = Bm(i, k);
+        v[k] -= alpha;
+        ld_t vv = 0.0L;
+        for (int i = k; i < m; ++i) vv += v[i] * v[i];
+        if (vv == 0.0L) continue;
+        for (int j = k; j < n; ++j) {
+            ld_t d = 0.0L;
+            for (int i = k; i < m; ++i) d += v[i] * Bm(i, j);
+            d = 2.0L * d / vv;
+            for (int i = k; i < m; ++i) Bm(i, j) -= d * v[i];
+        }
+        for (int j = 0; j < m; ++j) {
+            ld_t d = 0.0L;
+            for (int i = k; i < m; ++i) d += v[i] * Qt[(size_t)i * m + j];
+            d = 2.0L * d / vv;
+            for (int i = k; i < m; ++i) Qt[(size_t)i * m + j] -= d * v[i];
+        }
+    }
+    ld_t rmin = fabsl(Bm(0, 0)), rmax = rmin;
+    for (int k = 1; k < n; ++k) {
+        rmin = std::min(rmin, fabsl(Bm(k, k)));
+        rmax = std::max(rmax, fabsl(Bm(k, k)));
+    }
+    if (rmin == 0.0L) return 0.0L;
+    Pinv.assign((size_t)n * m, 0.0L);                      // R^-1 (Q^T)[0:n, :]
+    for (int j = 0; j < m; ++j)
+        for (int i = n - 1; i >= 0; --i) {
+            ld_t acc = Qt[(size_t)i * m + j];
+            for (int k = i + 1; k < n; ++k) acc -= Bm(i, k) * Pinv[(size_t)k * m + j];
+            Pinv[(size_t)i * m + j] = acc / Bm(i, i);
+        }
+    return rmin / rmax;
+}
+
+struct Mode {
+    ld_t re, im;
+    bool real;
+};
+
+inline void mode_pow(const Mode &m, int e, ld_t &pr, ld_t &pi) {
+    ld_t br = m.re, bi = m.im;
+    pr = 1.0L;
+    pi = 0.0L;
+    for (; e > 0; e >>= 1) {
+        if (e & 1) {
+            const ld_t x = pr * br - pi * bi, y = pr * bi + pi * br;
+            pr = x;
+            pi = y;
+        }
+        const ld_t x = br * br - bi * bi, y = 2.0L * br * bi;
+        br = x;
+        bi = y;
+    }
+}
+
+// sos: nsec rows of (b0 b1 b2 a0 a1 a2), a0 == 1; forgets: the cascade's memory is
+// bounded (osz_sos_s::warm_len is a finite number of samples)
+inline Tables build(const double *taps, int wlen, const double *sos, int nsec, bool forgets) {
+    Tables T;
+    if (wlen < 2 || !forgets) return T;
+    int NR = (3841 - wlen) / 256;
+    if (NR > 15) NR = 15;
+    if (NR < 8) return T;
+    const int S = 256 * NR, D = 16 - NR;
+    std::vector<Mode> modes;
+    for (int q = 0; q < nsec; ++q) {
+        const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+        if (a1 == 0.0L && a2 == 0.0L) continue;
+        if (a2 == 0.0L) {
+            modes.push_back({-a1, 0.0L, true});
+            continue;
+        }
+        const ld_t disc = a1 * a1 - 4.0L * a2;
+        if (disc < 0.0L) {
+            modes.push_back({-a1 / 2, sqrtl(-disc) / 2, false});
+        } else if (disc > 0.0L) {
+            modes.push_back({(-a1 + sqrtl(disc)) / 2, 0.0L, true});
+            modes.push_back({(-a1 - sqrtl(disc)) / 2, 0.0L, true});
+        } else {
+            return T;                                      // a double pole: n lambda^n is not in the basis
+        }
+    }
+    const int nm = (int)modes.size();
+    if (nm < 1 || nm > 6) return T;       // the tables of 8 modes do not fit beside two cubes per CU
+    for (auto &m : modes)
+        if (!(m.re * m.re + m.im * m.im < 1.0L)) return T;
+    const int NM = (nm + 1) & ~1;                          // instantiated: 2, 4, 6
+    // least squares on the first 64 samples of row 15:
+    //   hom[l] = sum_q Re(gamma_q lambda_q^l) = sum_q a_q Re(lambda^l) - b_q Im(lambda^l)
+    std::vector<int> col_mode, col_im;
+    for (int q = 0; q < nm; ++q) {
+        col_mode.push_back(q);
+        col_im.push_back(0);
+        if (!modes[q].real) {
+            col_mode.push_back(q);
+            col_im.push_back(1);
+        }
+    }
+    const int nd = (int)col_mode.size();
+    std::vector<ld_t> B((size_t)kFit * nd);
+    for (int j = 0; j < nd; ++j)
+        for (int l = 0; l < kFit; ++l) {
+            ld_t pr, pi;
+            mode_pow(modes[col_mode[j]], l, pr, pi);
+            B[(size_t)j * kFit + l] = col_im[j] ? -pi : pr;
+        }
+    std::vector<ld_t> Pinv;
+    const ld_t ratio = pinv_qr(B, kFit, nd, Pinv);
+    T.fit_ratio = (double)ratio;
+    if (!(ratio > 1e-9L)) return T;                        // modes too close to tell apart
+    // mu = gamma lambda^256
+    T.M.assign((size_t)2 * NM * kFit, 0.0);
+    for (int q = 0; q < nm; ++q) {
+        int ja = -1, jb = -1;
+        for (int j = 0; j < nd; ++j)
+            if (col_mode[j] == q) (col_im[j] ? jb : ja) = j;
+        ld_t cr, ci;
+        mode_pow(modes[q], 256, cr, ci);
+        for (int l = 0; l < kFit; ++l) {
+            const ld_t av = Pinv[(size_t)ja * kFit + l];
+            const ld_t bv = jb >= 0 ? Pinv[(size_t)jb * kFit + l] : 0.0L;
+            T.M[(size_t)q * kFit + l] = (double)(cr * av - ci * bv);
+            T.M[(size_t)(NM + q) * kFit + l] = (double)(ci * av + cr * bv);
+        }
+    }
+    // composite impulse response (the taps, then the cascade): how far a burst reaches
+    const int glen = kN + 256 * 17;
+    std::vector<ld_t> g(glen, 0.0L);
+    for (int i = 0; i < wlen && i < glen; ++i) g[i] = taps[i];
+    for (int q = 0; q < nsec; ++q) {
+        const ld_t b0 = sos[6 * q], b1 = sos[6 * q + 1], b2 = sos[6 * q + 2];
+        const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+        ld_t z0 = 0.0L, z1 = 0.0L;
+        for (int i = 0; i < glen; ++i) {
+            const ld_t xin = g[i], y = b0 * xin + z0;
+            z0 = b1 * xin - a1 * y + z1;
+            z1 = b2 * xin - a2 * y;
+            g[i] = y;
+        }
+    }
+    std::vector<ld_t> tail2(glen + 1, 0.0L);
+    for (int i = glen - 1; i >= 0; --i) tail2[i] = tail2[i + 1] + g[i] * g[i];
+    int R = 1;
+    while (R <= 16 && kN + 256 * R - S < glen && sqrtl(tail2[kN + 256 * R - S]) > 3e-18L * sqrtl(tail2[0]))
+        ++R;
+    // the +mu burst of a block must end inside the next block (D + R <= NR) and the closing
+    // pair's accumulator holds 8192 samples (NR + R <= 16)
+    if (R > kRMax || R > D || R > 2 * NR - 16) return T;
+    // composite spectrum, divided by 4096 (the inverse transform is unnormalised)
+    std::vector<ld_t> fr, fi;
+    fir_spectrum(taps, wlen, fr, fi);
+    const ld_t PI = acosl(-1.0L);
+    T.H.assign(2 * kN, 0.0);
+    for (int k = 0; k < kN; ++k) {
+        const ld_t ang = -2.0L * PI * (ld_t)k / (ld_t)kN;
+        const ld_t zr = cosl(ang), zi = sinl(ang);          // z^-1 at bin k
+        const ld_t z2r = zr * zr - zi * zi, z2i = 2.0L * zr * zi;
+        ld_t hr = fr[k] / kN, hi = fi[k] / kN;
+        for (int q = 0; q < nsec; ++q) {
+            const ld_t b0 = sos[6 * q], b1 = sos[6 * q + 1], b2 = sos[6 * q + 2];
+            const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+            const ld_t nr = b0 + b1 * zr + b2 * z2r, ni = b1 * zi + b2 * z2i;
+            const ld_t dr = 1.0L + a1 * zr + a2 * z2r, di = a1 * zi + a2 * z2i;
+            const ld_t den = dr * dr + di * di;
+            const ld_t qr = (nr * dr + ni * di) / den, qi = (ni * dr - nr * di) / den;
+            const ld_t x = hr * qr - hi * qi, y = hr * qi + hi * qr;
+            hr = x;
+            hi = y;
+        }
+        T.H[2 * k] = (double)hr;
+        T.H[2 * k + 1] = (double)hi;
+    }
+    T.P.assign((size_t)32 * NM * 2, 0.0);
+    T.L.assign((size_t)kRMax * NM * 2, 0.0);
+    for (int q = 0; q < nm; ++q) {
+        for (int i = 0; i < 32; ++i) {
+            ld_t pr, pi;
+            mode_pow(modes[q], i < 16 ? 16 * i : i - 16, pr, pi);
+            T.P[((size_t)i * NM + q) * 2 + 0] = (double)pr;
+            T.P[((size_t)i * NM + q) * 2 + 1] = (double)pi;
+        }
+        for (int r = 0; r < kRMax; ++r) {
+            ld_t pr, pi;
+            mode_pow(modes[q], 256 * r, pr, pi);
+            T.L[((size_t)r * NM + q) * 2 + 0] = (double)pr;
+            T.L[((size_t)r * NM + q) * 2 + 1] = (double)pi;
+        }
+    }
+    T.NR = NR;
+    T.NM = NM;
+    T.nm = nm;
+    T.R = R;
+    T.eligible = true;
+    return T;
+}
+
+}  // namespace spec
+}  // namespace osz

@@ -1,0 +1,201 @@
+"""The host tables of the spectral FIR -> cascade kernel (openseize_amd/csrc/spec_tables.h,
+used by chain_spec.hip), built by g++ from the same header and (1) held against NumPy,
+(2) driven through a NumPy restatement of the kernel's dataflow -- whole pairs with the
+overlap add and the mode bursts, the opening pair's carry, the generic closing pair, runs
+with a one-pair pre-roll -- against scipy's sosfilt(convolve(x, h)): the block algorithm
+and its tables are pinned without a GPU."""
+
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import scipy.signal as sps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 4096
+
+
+@pytest.fixture(scope="module")
+def exe():
+    src = os.path.join(ROOT, "tests", "host", "spec_host_check.cpp")
+    inc = os.path.join(ROOT, "openseize_amd", "csrc")
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "spec_host_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", inc, src, "-o", path])
+    return path
+
+
+def tables(exe, taps, sos, forgets=True):
+    taps, sos = np.asarray(taps, np.float64), np.atleast_2d(np.asarray(sos, np.float64))
+    with tempfile.TemporaryDirectory() as tmp:
+        fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<iii", len(taps), len(sos), int(forgets)))
+            f.write(taps.tobytes())
+            f.write(sos.tobytes())
+        subprocess.check_call([exe, fin, fout])
+        raw = open(fout, "rb").read()
+    elig, NR, NM, nm, R = struct.unpack_from("<iiiii", raw, 0)
+    ratio, = struct.unpack_from("<d", raw, 20)
+    pos, arrs = 28, []
+    for _ in range(4):
+        n, = struct.unpack_from("<q", raw, pos)
+        arrs.append(np.frombuffer(raw, np.float64, n, pos + 8).copy())
+        pos += 8 + 8 * n
+    return dict(eligible=bool(elig), NR=NR, NM=NM, nm=nm, R=R, ratio=ratio, H=arrs[0], M=arrs[1],
+                P=arrs[2], L=arrs[3])
+
+
+class Model:
+    """The kernel's dataflow (chain_spec.hip) on one channel, with the tables of the C++ build."""
+
+    def __init__(self, T, wlen):
+        self.NR, self.NM, self.R = T["NR"], T["NM"], T["R"]
+        self.S, self.D = 256 * self.NR, 16 - self.NR
+        H = T["H"].reshape(N, 2)
+        self.Hc = (H[:, 0] + 1j * H[:, 1]) * N            # the tables carry the 1/4096
+        M = T["M"].reshape(2 * self.NM, 64)
+        self.M = M[:self.NM] + 1j * M[self.NM:]
+        P = T["P"].reshape(32, self.NM, 2)
+        P = P[..., 0] + 1j * P[..., 1]
+        t = np.arange(256)
+        self.P = P[t >> 4] * P[16 + (t & 15)]             # lambda^t as the kernel forms it
+        L = T["L"].reshape(5, self.NM, 2)
+        self.L = L[..., 0] + 1j * L[..., 1]
+        self.CL = N + 256 * self.R
+
+    def window(self, x):
+        buf = np.zeros(N)
+        buf[:len(x)] = x
+        return np.real(np.fft.ifft(np.fft.fft(buf) * self.Hc))
+
+    def fit(self, win):
+        return self.M @ win[3840:3904]
+
+    def burst(self, mu, e):
+        ok = (e >= 0) & (e < 256 * self.R)
+        ee = np.where(ok, e, 0)
+        return np.where(ok, np.real((self.L[ee >> 8] * self.P[ee & 255]) @ mu), 0.0)
+
+    def chunk(self, x, carry_in, nruns):
+        n, S, NR, D, R = len(x), self.S, self.NR, self.D, self.R
+        pair = 2 * S
+        npw = n // pair
+        rem = n - npw * pair
+        W = npw - 1 if rem == 0 else npw
+        assert W >= 1
+        f = np.full(n, np.nan)
+        nruns = max(1, min(nruns, W))
+        t = np.arange(256)
+        carry_out = None
+        for run in range(nruns):
+            p0, p1 = run * W // nruns, (run + 1) * W // nruns
+            cr, mu_prev = np.zeros((D, 256)), np.zeros(self.NM, complex)
+            for p in range(p0 if run == 0 else p0 - 1, p1):
+                o = p * pair
+                wa, wb = self.window(x[o:o + S]), self.window(x[o + S:o + pair])
+                mu_a, mu_b = self.fit(wa), self.fit(wb)
+                Ya, Yb = wa.reshape(16, 256), wb.reshape(16, 256)
+                A, B = Ya[:NR].copy(), Yb[:NR].copy()
+                A[:D] += cr
+                B[:D] += Ya[NR:]
+                cr = Yb[NR:].copy()
+                for r in range(R):
+                    A[r] += self.burst(-mu_a, 256 * r + t)
+                    A[D + r] += self.burst(mu_prev, 256 * r + t)
+                    B[r] += self.burst(-mu_b, 256 * r + t)
+                    B[D + r] += self.burst(mu_a, 256 * r + t)
+                mu_prev = mu_b
+                if p == 0:
+                    ci = np.zeros(pair)
+                    ci[:self.CL] = carry_in[:self.CL]
+                    A += ci[:S].reshape(NR, 256)
+                    B += ci[S:].reshape(NR, 256)
+                if p >= p0:
+                    f[o:o + S], f[o + S:o + pair] = A.ravel(), B.ravel()
+            if run == nruns - 1:
+                o = W * pair
+                la = min(n - o, S)
+                lb = n - o - la
+                wa, wb = self.window(x[o:o + la]), self.window(x[o + la:o + la + lb])
+                mu_a, mu_b = self.fit(wa), self.fit(wb)
+                acc, i = np.zeros(8192), np.arange(8192)
+                acc[:256 * D] += cr.ravel()
+                acc[:N] += wa
+                acc[la:la + N] += wb
+                for mu, off in ((mu_prev, 256 * D), (-mu_a, 0), (-mu_b, la), (mu_a, N), (mu_b, la + N)):
+                    acc += self.burst(mu, i - off)
+                f[o:n] = acc[:la + lb]
+                carry_out = np.zeros(7680)
+                seg = acc[la + lb:]
+                carry_out[:min(len(seg), 7680)] = seg[:7680]
+        return f, carry_out
+
+
+CASES = [
+    ("butter6 band-pass, 1024 taps (cfg-3)", 1024, sps.butter(6, [0.05, 0.3], "bandpass", output="sos")),
+    ("butter6 band-pass, 300 taps", 300, sps.butter(6, [0.05, 0.3], "bandpass", output="sos")),
+    ("cheby1 band-pass, 777 taps", 777, sps.cheby1(3, 1, [0.16, 0.48], "bandpass", output="sos")),
+    ("butter5 low-pass (a real pole), 513 taps", 513, sps.butter(5, 0.3, output="sos")),
+    ("elliptic high-pass, 64 taps", 64, sps.ellip(4, 0.5, 50, 0.25, "highpass", output="sos")),
+]
+
+
+@pytest.mark.parametrize("name,ntaps,sos", CASES, ids=[c[0] for c in CASES])
+def test_tables_and_block_algorithm(exe, name, ntaps, sos):
+    taps = sps.firwin(ntaps, 0.2)
+    T = tables(exe, taps, sos)
+    assert T["eligible"], name
+    NR, NM, R = T["NR"], T["NM"], T["R"]
+    assert NR == min((3841 - ntaps) // 256, 15) and 1 <= R <= min(16 - NR, 2 * NR - 16, 5)
+    # (1) against NumPy: the composite spectrum and the mode powers
+    w, h = sps.sosfreqz(sos, worN=N, whole=True)
+    Hc = np.fft.fft(taps, N) * h / N
+    H = T["H"].reshape(N, 2)
+    assert np.max(np.abs(H[:, 0] + 1j * H[:, 1] - Hc)) < 1e-15 * np.max(np.abs(Hc)) * 50
+    P = T["P"].reshape(32, NM, 2)
+    lam = P[17, :, 0] + 1j * P[17, :, 1]
+    assert np.all(np.abs(lam[:T["nm"]]) < 1) and np.all(lam[T["nm"]:] == 0)
+    poles = np.concatenate([np.roots(s[3:]) for s in sos if s[4] or s[5]])
+    for q in range(T["nm"]):
+        assert np.min(np.abs(poles - lam[q])) < 1e-12
+    assert np.allclose(P[3, :T["nm"], 0] + 1j * P[3, :T["nm"], 1], lam[:T["nm"]] ** 48, rtol=1e-13, atol=0)
+    L = T["L"].reshape(5, NM, 2)
+    assert np.allclose(L[2, :T["nm"], 0] + 1j * L[2, :T["nm"], 1], lam[:T["nm"]] ** 512, rtol=1e-12, atol=1e-300)
+    # (2) the block algorithm with these tables against scipy
+    rng = np.random.default_rng(len(taps))
+    m = Model(T, ntaps)
+    S = m.S
+    lens = [2 * S * 5 + 1024, 2 * S * 4, 2 * S * 3 + S + 17, 2 * S + 5, 2 * S * 3 + 2 * S - 1]
+    x = rng.standard_normal(sum(lens))
+    u = np.convolve(x, taps)
+    zi0 = sps.sosfilt_zi(sos) * u[0]
+    ref, _ = sps.sosfilt(sos, u, zi=zi0)
+    # import: the pending FIR tail (none yet) through the cascade from its state
+    carry = np.zeros(7680)
+    carry[:m.CL] = sps.sosfilt(sos, np.zeros(m.CL), zi=zi0)[0]
+    o, scale = 0, np.max(np.abs(ref))
+    for k, n in enumerate(lens):
+        f, carry = m.chunk(x[o:o + n], carry, nruns=[1, 2, 3, 4, 2][k])
+        assert np.max(np.abs(f - ref[o:o + n])) < 1e-12 * scale, (name, k)
+        o += n
+    # the carry IS the stream's future if the input stops: the flush of the chain
+    assert np.max(np.abs(carry[:ntaps - 1] - ref[o:o + ntaps - 1])) < 1e-12 * scale
+
+
+def test_what_the_scheme_does_not_take(exe):
+    """Cascades outside the scheme are refused (chain_kernel serves them): a double pole,
+    ringing that outlasts the guard rows, a filter too long for row 15 to be free, a
+    cascade that does not forget."""
+    bp = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    assert tables(exe, sps.firwin(1024, 0.2), bp)["eligible"]
+    twice = np.vstack([sps.butter(2, 0.2, output="sos")] * 2)          # every pole twice
+    assert not tables(exe, sps.firwin(256, 0.2), twice)["eligible"]
+    narrow = sps.butter(4, [0.0002, 0.0016], "bandpass", output="sos")  # 0.5-4 Hz at 5 kHz
+    assert not tables(exe, sps.firwin(256, 0.2), narrow)["eligible"]
+    assert not tables(exe, sps.firwin(1900, 0.2), bp)["eligible"]
+    assert not tables(exe, sps.firwin(1024, 0.2), bp, forgets=False)["eligible"]
+    assert not tables(exe, sps.firwin(64, 0.2), sps.butter(14, 0.3, output="sos"))["eligible"]   # 7 modes
