@@ -42,36 +42,19 @@ def optimal_nffts(arr):
 
 def convolved_shape(shape1, shape2, mode, axis):
     """Shape of the convolution of arrays of shape1 and shape2 along axis
-    (core/numerical.py:41-73).  A 1-D second shape is taken as the window
-    length whatever ``axis`` is (the reference indexes it with ``axis`` and
-    raises IndexError for 0 < axis, filtering/bases.py:411)."""
-    m = shape1[axis]
-    n = shape2[0] if len(shape2) == 1 else shape2[axis]
-    p, q = max(m, n), min(m, n)
-    outshape = sorted([list(shape1), list(shape2)], key=len)[-1]
-    if mode == "full":
-        outshape[axis] = m + n - 1
-    elif mode == "same":
-        outshape[axis] = p
-    elif mode == "valid":
-        outshape[axis] = m + n - 1 - 2 * (q - 1)
-    return tuple(outshape)
-
-
-def convolve_slicer(arr, shape1, shape2, mode, axis):
-    """Applies a numpy convolve mode to a full convolution
-    (core/numerical.py:76-116)."""
-    m = shape1[axis]
-    n = shape2[0] if len(shape2) == 1 else shape2[axis]
-    p, q = max(m, n), min(m, n)
-    if mode == "full":
-        return arr
-    if mode == "same":
-        start = (q - 1) // 2
-        return slice_along_axis(arr, start, start + p, axis=axis)
-    if mode == "valid":
-        return slice_along_axis(arr, q - 1, (n + m - 1) - (q - 1), axis=axis)
-    raise ValueError(f"unknown mode {mode!r}")
+    (same results as core/numerical.py:41-73).  The array with more dimensions
+    lends the other axes (the second one on a tie, as the reference's stable sort
+    has it); an unknown mode leaves the length alone.  A 1-D second shape is taken
+    as the window length whatever ``axis`` is (the reference indexes it with
+    ``axis`` and raises IndexError for 0 < axis, filtering/bases.py:411)."""
+    lengths = sorted((shape1[axis], shape2[0] if len(shape2) == 1 else shape2[axis]))
+    short, long_ = lengths
+    by_mode = {"full": long_ + short - 1, "same": long_, "valid": long_ - short + 1}
+    lender = shape2 if len(shape2) >= len(shape1) else shape1
+    out = list(lender)
+    if mode in by_mode:
+        out[axis] = by_mode[mode]
+    return tuple(out)
 
 
 def _chain_first(first, rest):

@@ -23,15 +23,16 @@ from openseize_amd.core.producer import Producer, producer
 
 
 def pad(pro, amt, axis, value=0):
-    amts = (amt, amt) if isinstance(amt, int) else tuple(amt)
-    if arraytools.normalize_axis(axis, pro.ndim) == pro.axis:
-        genfunc = _production_axis_padder
-    else:
-        genfunc = _other_axis_padder
-    func = partial(genfunc, pro, amts, axis, value)
-    new_shape = list(pro.shape)
-    new_shape[axis] = pro.shape[axis] + sum(amts)
-    return producer(func, pro.chunksize, pro.axis, shape=new_shape)
+    """Constant padding before and after ``axis`` (core/protools.py:182-232): along the
+    production axis two extra arrays frame the stream, along any other axis every
+    produced array grows."""
+    before, after = (amt, amt) if isinstance(amt, int) else tuple(amt)
+    grown = [n + before + after if i == arraytools.normalize_axis(axis, pro.ndim) else n
+             for i, n in enumerate(pro.shape)]
+    along_stream = arraytools.normalize_axis(axis, pro.ndim) == pro.axis
+    gen = _production_axis_padder if along_stream else _other_axis_padder
+    return producer(partial(gen, pro, (before, after), axis, value), pro.chunksize, pro.axis,
+                    shape=grown)
 
 
 @dev.chain_aware
@@ -65,22 +66,20 @@ def _other_axis_padder(pro, amt, axis, value):
 # the rest of the reference's protools
 # ---------------------------------------------------------------------------
 def squeeze(pro, axis=None):
-    """Removes singleton axes, tracking where the production axis moves
-    (core/protools.py:36-70)."""
-    enumerated = list(enumerate(pro.shape))
-    sample_axis = enumerated[pro.axis]
+    """Removes singleton axes (core/protools.py:36-70); the production axis keeps
+    its meaning: its new index is the number of kept axes in front of it."""
     if axis is None:
-        reduced = [(idx, size) for idx, size in enumerated if size > 1]
+        kept = [i for i, n in enumerate(pro.shape) if n > 1]
     else:
-        ax = arraytools.normalize_axis(axis, pro.ndim)
-        if pro.shape[ax] != 1:
+        gone = arraytools.normalize_axis(axis, pro.ndim)
+        if pro.shape[gone] != 1:
             raise ValueError("cannot select an axis to squeeze out which has "
                              "size not equal to one")
-        reduced = [tup for tup in enumerated if tup[0] != ax]
-    new_axis = reduced.index(sample_axis)
-    new_shape = tuple(size for _, size in reduced)
-    return producer(partial(_map_gen, pro, partial(dev.squeeze, axis=axis)),
-                    pro.chunksize, new_axis, shape=new_shape)
+        kept = [i for i in range(pro.ndim) if i != gone]
+    if pro.axis not in kept:
+        raise ValueError(f"{(pro.axis, pro.shape[pro.axis])} is not in list")
+    return producer(partial(_map_gen, pro, partial(dev.squeeze, axis=axis)), pro.chunksize,
+                    kept.index(pro.axis), shape=tuple(pro.shape[i] for i in kept))
 
 
 @dev.chain_aware
@@ -94,8 +93,13 @@ def _as_device(value, device):
     """float64 CUDA tensor of a number / ndarray / tensor (plumbing only)."""
     import torch
     if dev.is_tensor(value):
+        if value.is_complex():
+            raise TypeError("protools arithmetic runs float64 kernels: complex input is not supported")
         return value.to(device=device, dtype=torch.float64)
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(value, dtype=np.float64))).to(device)
+    value = np.asarray(value)
+    if np.iscomplexobj(value):
+        raise TypeError("protools arithmetic runs float64 kernels: complex input is not supported")
+    return torch.from_numpy(np.ascontiguousarray(value, dtype=np.float64)).to(device)
 
 
 def _operand(value, layout, chunk_shape, device):
@@ -164,54 +168,64 @@ def multiply(pro, other):
 
 
 def expand_dims(pro, axis=0):
-    """Inserts new axes, tracking the production axis (core/protools.py:266-312)."""
-    axes = (axis,) if isinstance(axis, int) else tuple(axis)
-    new_ndim = len(pro.shape) + len(axes)
-    new_shape = np.ones(new_ndim, dtype=int)
-    inserts = [arraytools.normalize_axis(ax, new_ndim) for ax in axes]
-    complements = sorted(set(range(new_ndim)).difference(inserts))
-    new_axis = complements[pro.axis]
-    for idx, comp in enumerate(complements):
-        new_shape[comp] = pro.shape[idx]
-    func = partial(_map_gen, pro, partial(dev.expand_dims, axes=tuple(inserts)))
-    return producer(func, pro.chunksize, new_axis, tuple(int(s) for s in new_shape))
+    """Inserts new axes (core/protools.py:266-320).  The old axes fill, in order, the
+    positions the new ones leave free; the production axis is wherever its old axis
+    lands."""
+    wanted = (axis,) if isinstance(axis, int) else tuple(axis)
+    ndim = pro.ndim + len(wanted)
+    fresh = {arraytools.normalize_axis(ax, ndim) for ax in wanted}
+    old = iter(enumerate(pro.shape))
+    shape, new_axis = [], None
+    for pos in range(ndim):
+        if pos in fresh:
+            shape.append(1)
+            continue
+        idx, size = next(old)
+        shape.append(int(size))
+        if idx == pro.axis:
+            new_axis = pos
+    func = partial(_map_gen, pro, partial(dev.expand_dims, axes=tuple(sorted(fresh))))
+    return producer(func, pro.chunksize, new_axis, tuple(shape))
 
 
 def multiply_along_axis(pro, arr, axis):
     """Produced arrays times a 1-D array laid along one axis, the production
-    axis included (core/protools.py:334-384).  Along the production axis the
+    axis included (core/protools.py:334-426).  Along the production axis the
     multiplier is walked in step with the data (one value per sample, kernel
     operand kind COL); along any other axis it is constant over a chunk."""
-    arr = np.array(arr)
-    if arr.ndim > 1:
+    factors = np.array(arr)
+    if factors.ndim > 1:
         raise ValueError("Dimensions of multiplier arr must be exactly 1.")
-    if len(arr) != pro.shape[axis]:
-        msg = "operands could not be broadcast together with shapes {} {}"
-        raise ValueError(msg.format(pro.shape, arr.shape))
+    if len(factors) != pro.shape[axis]:
+        raise ValueError("operands could not be broadcast together with shapes "
+                         f"{pro.shape} {factors.shape}")
+    if np.iscomplexobj(factors):
+        raise TypeError("multiply_along_axis: the device kernels are float64, got a complex multiplier")
     along = arraytools.normalize_axis(axis, pro.ndim)
-    return _same_shape_producer(pro, partial(_scale_gen, pro, arr.astype(np.float64), along))
+    return _same_shape_producer(pro, partial(_scale_gen, pro, factors.astype(np.float64), along))
 
 
 @dev.chain_aware
 def _scale_gen(pro, factors, along):
     laid = [1] * pro.ndim
-    if along != pro.axis:
-        # Reference quirk (Q14, pinned by the golden vectors): the multiplier is
-        # zipped with the producer as an ARRAY (zip_longest(pro, x, fillvalue=x),
-        # core/protools.py:378-384), so produced chunk k < len(arr) is scaled by
-        # the single value arr[k] and only later chunks by arr laid along its
-        # axis.  Replicated: it is what callers of the reference observe.
-        laid[along] = len(factors)
-        for k, arr in enumerate(pro):
-            scale = factors[k] if k < len(factors) else factors.reshape(laid)
-            yield _apply(_lib.EW_MUL, arr, pro.axis, scale)
+    if along == pro.axis:
+        seen = 0
+        for arr in pro:
+            m = arr.shape[pro.axis]
+            laid[along] = m
+            yield _apply(_lib.EW_MUL, arr, pro.axis, factors[seen:seen + m].reshape(laid))
+            seen += m
         return
-    seen = 0
-    for arr in pro:
-        m = arr.shape[pro.axis]
-        laid[along] = m
-        yield _apply(_lib.EW_MUL, arr, pro.axis, factors[seen:seen + m].reshape(laid))
-        seen += m
+    laid[along] = len(factors)
+    for k, arr in enumerate(pro):
+        # Reference quirk Q14 (pinned by g12_protools.npz): the producer is zipped with the
+        # reshaped multiplier ARRAY (zip_longest(pro, x, fillvalue=x), core/protools.py:418-426),
+        # and iterating an array walks its axis 0.  When the multiplied axis IS axis 0,
+        # produced chunk k < len(arr) therefore meets the single value arr[k]; along any
+        # other axis the one item of that walk is the whole multiplier (the docstring's
+        # (2, 4, 1250), axis=1 example) and every chunk sees the plain broadcast.
+        quirk = along == 0 and k < len(factors)
+        yield _apply(_lib.EW_MUL, arr, pro.axis, factors[k] if quirk else factors.reshape(laid))
 
 
 def slice_along_axis(pro, start=None, stop=None, step=None, axis=-1):

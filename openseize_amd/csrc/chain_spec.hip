@@ -403,6 +403,20 @@ __global__ __launch_bounds__(256, 2) void chain_spec_kernel(SpecArgs g) {
     }
 }
 
+// A NaN never leaves the cascade (sos_tile.h, "NaN reach"); the replay of spec_settle
+// knows nothing of one that lies before the samples it replays: the section states of
+// a channel whose carry is poisoned become NaN.
+__global__ void spec_poison_kernel(const double *carry, int probe, double *state, int nsec, int nch) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nch) return;
+    if (!sos_not_finite(carry[(int64_t)c * kSpecLdc + probe])) return;
+    const double qn = spec_qnan();
+    for (int q = 0; q < nsec; ++q) {
+        state[((int64_t)q * nch + c) * 2 + 0] = qn;
+        state[((int64_t)q * nch + c) * 2 + 1] = qn;
+    }
+}
+
 // ---------------------------------------------------------------- host side
 // The link between a FIR handle and a SOS handle that run this kernel together.
 struct ChainSpec {
@@ -533,6 +547,9 @@ int spec_settle(ChainSpec *s, hipStream_t st) {
         rc = sos_forward_raw(sos, s->dscratch, s->hist_cap, s->dscratch, s->hist_cap, s->hist_n, st);
         if (rc) return rc;
     }
+    hipLaunchKernelGGL(spec_poison_kernel, dim3((nch + 255) / 256), dim3(256), 0, st, s->dcarry[s->cur],
+                       4095 + 256 * s->R, sos->dstate, sos->nsec, nch);
+    OSZ_HIP(hipGetLastError());
     s->true_valid = true;
     return OSZ_OK;
 }

@@ -453,6 +453,18 @@ def g12_protools():
     out["std_other"] = ref_pt.std(pro, 0)
     out["standardize_prod"] = ref_pt.standardize(pro, -1).to_array()
     out["standardize_other"] = ref_pt.standardize(pro, 0).to_array()
+    # multiply_along_axis along a non-production axis: the reference zips the producer with
+    # the reshaped multiplier ARRAY (core/protools.py:418-426), which iterates its axis 0 --
+    # chunk k is scaled by the single value arr[k] only when the multiplied axis IS axis 0;
+    # along a middle axis (the docstring's own example) it is the plain broadcast
+    x3 = rng.standard_normal((2, 4, 1250))
+    w4, w2 = np.array([0.0, -1.0, 1.0, 0.5]), np.array([3.0, -2.0])
+    out["x3"], out["w4"], out["w2"] = x3, w4, w2
+    out["mul3_middle"] = ref_pt.multiply_along_axis(producer(x3, 100, axis=-1), w4, 1).to_array()
+    out["mul3_first"] = ref_pt.multiply_along_axis(producer(x3, 100, axis=-1), w2, 0).to_array()
+    w1250 = rng.standard_normal(1250)
+    out["w1250"] = w1250
+    out["mul3_last_prod0"] = ref_pt.multiply_along_axis(producer(x3, 1, axis=0), w1250, 2).to_array()
     save("g12_protools.npz", **out)
 
 

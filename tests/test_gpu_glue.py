@@ -60,6 +60,12 @@ def test_protools_arithmetic_golden(protools, golden, resident):
     assert close(protools.multiply_along_axis(pro, g["w"], -1).to_array(), g["mul_along_prod"])
     assert close(protools.multiply_along_axis(pro, np.array([1.0, 2.0, 3.0]), 0).to_array(),
                  g["mul_along_other"])
+    # 3-D, the reference's own outputs: a middle axis is the plain broadcast, axis 0 the quirk
+    x3 = torch.from_numpy(g["x3"]).cuda() if resident else g["x3"]
+    assert close(protools.multiply_along_axis(producer(x3, 100, axis=-1), g["w4"], 1).to_array(), g["mul3_middle"])
+    assert close(protools.multiply_along_axis(producer(x3, 100, axis=-1), g["w2"], 0).to_array(), g["mul3_first"])
+    assert close(protools.multiply_along_axis(producer(x3, 1, axis=0), g["w1250"], 2).to_array(),
+                 g["mul3_last_prod0"])
     for ignore in (True, False):
         m = protools.mean(pro, -1, ignore, keepdims=True)
         assert kind_ok(m) and close(m, g[f"mean_prod_{int(ignore)}"])
@@ -99,12 +105,14 @@ def test_protools_random_shapes(protools):
                 w = rng.standard_normal(shape[ax2])
                 wshape = [1] * ndim
                 wshape[ax2] = -1
-                # reference quirk Q14: chunk k < len(w) is scaled by the single value w[k]
+                # reference quirk Q14: when the multiplied axis is axis 0, chunk k < len(w) is
+                # scaled by the single value w[k]; along any other axis it is the plain product
                 want = x * w.reshape(wshape)
-                for k in range(min(len(w), -(-shape[axis] // 1777))):
-                    sl = [slice(None)] * ndim
-                    sl[axis] = slice(k * 1777, (k + 1) * 1777)
-                    want[tuple(sl)] = x[tuple(sl)] * w[k]
+                if ax2 == 0:
+                    for k in range(min(len(w), -(-shape[axis] // 1777))):
+                        sl = [slice(None)] * ndim
+                        sl[axis] = slice(k * 1777, (k + 1) * 1777)
+                        want[tuple(sl)] = x[tuple(sl)] * w[k]
                 assert close(protools.multiply_along_axis(pro, w, ax2).to_array(), want)
                 # an operand varying along BOTH the sample axis and another axis
                 full = rng.standard_normal(shape)
