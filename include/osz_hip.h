@@ -208,6 +208,58 @@ int osz_chain_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,
 /* `stream` is ordered behind the deferred backward pass of the last osz_chain_step. */
 int osz_chain_wait(osz_sos_t sos, void *stream);
 
+/* ---- K1 + K2 + K3 as one multiplication per bin: FIR -> sosfiltfilt ----- */
+/*
+ * The whole chain the reference builds from oaconvolve (core/numerical.py:158-298) and
+ * sosfiltfilt (:338-411), for streams whose chunks are much longer than the cascade's
+ * memory (osz_sos_warm_len): there the chunk-local backward pass of the reference equals,
+ * to 1e-18, the backward pass over the whole rest of the stream, and FIR, forward and
+ * backward cascade are the zero-phase filter H_fir |H_iir|^2 -- one spectrum multiply in
+ * the FIR's 4096-point transform plus the cascade's ringing on both sides of each block,
+ * put back by mode bursts (csrc/chain_zp.hip).  The forward stream never exists: 8 B read
+ * and 8 B written per channel-sample for what SURVEY 8d books at 48.
+ *
+ * The output stream runs osz_chain_zp_lag() samples behind the input: a block's backward
+ * ringing reaches that far into what the previous block has produced.  The two ends of a
+ * stream (where the reference's start state sosfilt_zi * x[0] and its last chunk's
+ * backward start matter) are the caller's, with the separate kernels: open after the
+ * start state has been set on the SOS handle, finish before the last chunks.
+ *
+ *   osz_chain_zp_lag        samples of delay (a multiple of 256), or -1 when the pair
+ *                           of filters does not take this kernel (poles that repeat,
+ *                           ringing longer than the transform's guard rows, FIR longer
+ *                           than 1793 taps or partitioned)
+ *   osz_chain_zp_min_chunk  shortest chunk osz_chain_zp_step takes (two pairs of blocks)
+ *   osz_chain_zp_open       starts a stream at sample 0: the FIR's overlap tail must be
+ *                           zero; the forward cascade starts from the state on the SOS
+ *                           handle (osz_sos_set_state*) at stream sample `skip` -- the
+ *                           FIR's left cut, which the cascade never sees -- and that state
+ *                           is consumed
+ *   osz_chain_zp_step       the next n input samples; y[0, n) = output samples
+ *                           [pos - lag, pos + n - lag) of the stream (pos: samples stepped
+ *                           before; the first lag outputs of a stream mean nothing)
+ *   osz_chain_zp_seal       NaN reach of sosfiltfilt: y holds output samples [s0, s0 + n)
+ *                           of a stream cut into chunks of cs samples from `origin` on; a
+ *                           chunk is NaN as a whole when the forward stream went bad in it
+ *                           or in the chunk after it (positions the steps so far have seen)
+ *   osz_chain_zp_finish     ends the zero-phase part: the handles' own states (FIR overlap
+ *                           tail, forward section states) become those at the end of the
+ *                           samples stepped -- osz_fir_push / osz_sos_forward /
+ *                           osz_chain_forward continue the forward stream from there --
+ *                           and y[0, ny) receives the next ny output samples, for which
+ *                           the first m samples of what follows are read (m >= min_chunk,
+ *                           ny <= m - lag - the FIR's length)
+ */
+int64_t osz_chain_zp_lag(osz_fir_t fir, osz_sos_t sos);
+int64_t osz_chain_zp_min_chunk(osz_fir_t fir, osz_sos_t sos);
+int osz_chain_zp_open(osz_fir_t fir, osz_sos_t sos, int64_t skip, void *stream);
+int osz_chain_zp_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,
+                      int64_t n, double *y, int64_t ldy, void *stream);
+int osz_chain_zp_seal(osz_fir_t fir, osz_sos_t sos, double *y, int64_t ldy, int64_t n,
+                      int64_t s0, int64_t origin, int64_t cs, void *stream);
+int osz_chain_zp_finish(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,
+                        int64_t m, double *y, int64_t ldy, int64_t ny, void *stream);
+
 /* ---- K4: polyphase rational resampler --------------------------------- */
 /*
  * Replaces scipy.signal.resample_poly(padded, L, M, window=h) as called at

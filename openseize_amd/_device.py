@@ -679,6 +679,50 @@ def chain_wait(sos):
     _lib.check(sos.lib.osz_chain_wait(sos.h, stream_ptr()))
 
 
+def chain_zp_lag(fir, sos):
+    """Delay of the zero-phase chain kernel in samples, or -1 when this pair of filters
+    does not take it (C ABI: osz_chain_zp_lag)."""
+    return int(fir.lib.osz_chain_zp_lag(fir.h, sos.h))
+
+
+def chain_zp_min_chunk(fir, sos):
+    return int(fir.lib.osz_chain_zp_min_chunk(fir.h, sos.h))
+
+
+def chain_zp_open(fir, sos, skip=0):
+    """Starts a zero-phase stream (C ABI: osz_chain_zp_open): the forward cascade starts
+    from the state on ``sos`` at stream sample ``skip``."""
+    _lib.check(fir.lib.osz_chain_zp_open(fir.h, sos.h, int(skip), stream_ptr()))
+
+
+def chain_zp_step(fir, sos, x2d, out=None):
+    """FIR -> sosfiltfilt of the next chunk in ONE kernel (C ABI: osz_chain_zp_step):
+    ``out[:, q]`` is output sample ``pos - lag + q`` of the stream."""
+    n = x2d.shape[1]
+    y = out if out is not None else torch.empty((fir.nch, n), dtype=torch.float64, device=x2d.device)
+    _lib.check(fir.lib.osz_chain_zp_step(fir.h, sos.h, ptr(x2d), x2d.stride(0), n, ptr(y),
+                                         max(y.stride(0), 1), stream_ptr()))
+    return y
+
+
+def chain_zp_seal(fir, sos, y, s0, origin, cs):
+    """NaN reach of sosfiltfilt on output samples [s0, s0 + n) (C ABI: osz_chain_zp_seal)."""
+    _lib.check(fir.lib.osz_chain_zp_seal(fir.h, sos.h, ptr(y), max(y.stride(0), 1), y.shape[1], int(s0),
+                                         int(origin), int(cs), stream_ptr()))
+
+
+def chain_zp_finish(fir, sos, x2d=None, out=None):
+    """Ends the zero-phase part of a stream (C ABI: osz_chain_zp_finish): the handles' own
+    states are those at the end of the samples stepped so far, ``out`` receives the next
+    output samples, computed from the head ``x2d`` of what follows."""
+    if x2d is None or out is None:
+        _lib.check(fir.lib.osz_chain_zp_finish(fir.h, sos.h, None, 0, 0, None, 0, 0, stream_ptr()))
+        return None
+    _lib.check(fir.lib.osz_chain_zp_finish(fir.h, sos.h, ptr(x2d), x2d.stride(0), x2d.shape[1], ptr(out),
+                                           max(out.stride(0), 1), out.shape[1], stream_ptr()))
+    return out
+
+
 class PolyStream(_Handle):
     """One iterator's polyphase resampler state (C ABI: osz_poly_*)."""
     _destroy = "osz_poly_destroy"

@@ -54,13 +54,9 @@
 #include "fir_pair.h"
 #include "handles.h"
 #include "sos_tile.h"
-#include "spec_tables.h"
+#include "chain_spec.h"
 
 namespace osz {
-
-constexpr int kSpecFit = spec::kFit;         // samples of row 15 the fit reads (one wave)
-constexpr int kSpecRMax = spec::kRMax;       // burst rows supported
-constexpr int kSpecLdc = 2 * 15 * 256;       // row pitch of the carry buffers (>= 2 S, >= 4096 + 256 R)
 
 struct SpecArgs {
     FirArgs f;                 // x, ldx, y, ldy, wlen, step, H (composite), tb
@@ -78,38 +74,6 @@ struct SpecArgs {
     int hist_len;
     int *segcnt;               // (nch) arrival counters of the runs
 };
-
-__device__ __forceinline__ double spec_qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
-
-// NaN reach of the forward pass across runs (sos_tile.h, "NaN reach"): the
-// workgroup of a channel that finishes last looks at the final output sample of
-// every earlier run; from the first one that is not finite the rest of the chunk
-// and the carry are NaN.
-template <class EndOf>
-__device__ __forceinline__ void spec_seal(int *__restrict__ segcnt, double *__restrict__ y, int64_t n,
-                                          int nseg, EndOf end_of, double *__restrict__ carry_row, int c) {
-    __syncthreads();
-    int last = 0;
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(segcnt + c, 1) == nseg - 1;
-    }
-    last = __syncthreads_or(last);
-    if (!last) return;
-    if (threadIdx.x == 0) atomicExch(segcnt + c, 0);     // ready for the next launch
-    __threadfence();
-    int bad = nseg;
-    for (int s = nseg - 2; s >= 0; --s) {
-        const unsigned long long bits = __hip_atomic_load(
-            reinterpret_cast<const unsigned long long *>(y + end_of(s) - 1), __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT);
-        if (sos_not_finite(__longlong_as_double((long long)bits))) bad = s;
-    }
-    if (bad == nseg) return;
-    const int64_t from = end_of(bad);
-    sos_fill_nan(y + from, n - from);
-    sos_fill_nan(carry_row, kSpecLdc);
-}
 
 // A workgroup walks a run of whole pairs of blocks of one channel (fast path);
 // run 0 opens the chunk (adds the carried sequence to its first pair), later
@@ -666,13 +630,10 @@ int spec_try_forward(osz_fir_s *fir, osz_sos_s *sos, const double *x, int64_t ld
         g.hist_len = 0;
     }
     s->since_import += n;
-    // development A/B (removed before the round ends): OSZ_SPEC_HP=-1 keeps the spectrum in registers
-    static int hp = 0;
-    if (!hp) hp = getenv("OSZ_SPEC_HP") ? atoi(getenv("OSZ_SPEC_HP")) : 16;
-    spec_kern_t kern = hp < 0 ? (s->NM == 2 ? spec_kernel_for<2, -1>(NR) : s->NM == 4 ? spec_kernel_for<4, -1>(NR)
-                                                                                       : spec_kernel_for<6, -1>(NR))
-                              : (s->NM == 2 ? spec_kernel_for<2, 16>(NR) : s->NM == 4 ? spec_kernel_for<4, 16>(NR)
-                                                                                       : spec_kernel_for<6, 16>(NR));
+    // the composite spectrum is requested per pair (FirPair HPRE = 16): resident in registers
+    // (HPRE = -1) the kernel spills 36 of its 64 words and the step takes 2.54 instead of 2.29 ms
+    spec_kern_t kern = s->NM == 2 ? spec_kernel_for<2, 16>(NR) : s->NM == 4 ? spec_kernel_for<4, 16>(NR)
+                                                                            : spec_kernel_for<6, 16>(NR);
     const size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS +
                        sizeof(double) * (2 * kSpecFit + 2 * 2 * s->NM * 2 + 5 * kSpecRMax * s->NM * 2 +
                                          kSpecRMax * s->NM * 2 + 32 * s->NM * 2 + 2 * s->NM * kSpecFit);

@@ -1,0 +1,785 @@
+// chain_zp.hip -- FIR -> sosfiltfilt of a long stream as ONE multiplication per bin.
+//
+// The reference chains oaconvolve (core/numerical.py:158-298) into sosfiltfilt
+// (:338-411): a forward pass of the cascade over the FIR output and, chunk by chunk, a
+// backward pass started from what back-filtering the NEXT chunk leaves (:397-403).  When a
+// chunk is much longer than the cascade's memory (warm_len samples, sos.hip) that start
+// state is, to 1e-18, what back-filtering the whole rest of the stream leaves: the two
+// passes are the zero-phase filter |H_iir|^2 applied to the FIR output, everywhere except
+// within warm_len samples of the stream's two ends, which the caller finishes with the
+// separate kernels (openseize_amd/core/numerical.py, _sosfiltfilt_after_fir).
+//
+// chain_spec.hip folds the FORWARD cascade into the FIR's spectrum; here the spectrum is
+// H_fir |H_iir|^2 and a block rings on both sides of its window: behind its FIR output
+// (causal modes, amplitudes mu, as there) and BEFORE its first sample (the backward pass:
+// the same modes running towards the past, amplitudes nu).  In the circular 4096-sample
+// window the second lot sits at the end of row 15, running down from sample 4095; one
+// joint least-squares fit on the first and last nh samples of that row gives both.  Per
+// block four bursts of R rows put things where they belong:
+//     -mu forwards from the block's first sample      (the wrapped right tail leaves the window)
+//     +mu forwards from its first sample + 4096       (and continues behind it)
+//     -nu backwards from its first sample + 4095      (the wrapped left tail leaves the window)
+//     +nu backwards from its first sample - 1         (and lands in front of the block)
+// The last one reaches into rows the PREVIOUS block has produced: the last R rows of
+// block b of a pair wait in registers for the next pair's fit, a run ends with one more
+// pair (and starts one early, as in chain_spec.hip), and a chunk's last 256 R samples
+// wait in `held` for the next chunk: the output stream runs L = 256 R samples late
+// (osz_chain_zp_lag).  Nothing else crosses a chunk: `carry` is the same kind of sequence
+// as in chain_spec.hip (what the outputs behind the chunk would be if the input stopped).
+//
+// HBM traffic: 8 B read + 8 B written per channel-sample for the whole chain (the forward
+// stream never exists); SURVEY 8d books the chain at 48.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+
+#include "chain_spec.h"
+#include "fft4096.h"
+#include "fir_pair.h"
+#include "handles.h"
+
+namespace osz {
+
+struct ZpArgs {
+    FirArgs f;                 // x, ldx, y, ldy, wlen, step, H (zero-phase composite), tb
+    int64_t n;                 // samples of this chunk
+    int64_t W;                 // whole pairs on the fast path
+    int nruns;
+    int la, lb;                // lengths of the closing pair's two blocks
+    int R, nh;                 // burst rows; fit samples at either end of row 15
+    const double *M;           // [4 NM][2 nh]
+    const double *P;           // [20][NM][2]
+    const double *Lrow;        // [R][NM][2]
+    const double *carry_in;    // (nch, kSpecLdc)
+    double *carry_out;
+    const double *held_in;     // (nch, 256 R): the previous chunk's last samples, one burst short
+    double *held_out;
+    double *hist;              // (nch, hist_len): the chunk's last input samples, or null
+    int hist_len;
+    int *segcnt;
+    long long *nanpos;         // (nch): stream position at which the forward stream went bad
+    long long pos;             // stream position of this chunk's first sample
+};
+
+// lambda^e for e = 0..255 from the three-level table [20][NM][2]
+template <int NM>
+__device__ __forceinline__ void zp_powers(const double *ptab, int e, double *pr, double *pi) {
+    const double *p1 = ptab + ((e >> 5) * NM) * 2, *p2 = ptab + ((8 + ((e >> 2) & 7)) * NM) * 2,
+                 *p3 = ptab + ((16 + (e & 3)) * NM) * 2;
+#pragma unroll
+    for (int q = 0; q < NM; ++q) {
+        const double ar = p1[2 * q] * p2[2 * q] - p1[2 * q + 1] * p2[2 * q + 1];
+        const double ai = p1[2 * q] * p2[2 * q + 1] + p1[2 * q + 1] * p2[2 * q];
+        pr[q] = ar * p3[2 * q] - ai * p3[2 * q + 1];
+        pi[q] = ar * p3[2 * q + 1] + ai * p3[2 * q];
+    }
+}
+
+// Re sum_q kappa_q P_q
+template <int NM>
+__device__ __forceinline__ double zp_dot(const double *kk, const double *pr, const double *pi) {
+    double c = 0.0;
+#pragma unroll
+    for (int q = 0; q < NM; ++q) c = fma(kk[2 * q], pr[q], fma(-kk[2 * q + 1], pi[q], c));
+    return c;
+}
+
+template <int NR, int NM>
+__global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
+    constexpr int D = 16 - NR, S = 256 * NR;
+    extern __shared__ fft::cube::C2 cube_lds[];
+    const int R = g.R, nh = g.nh, ns = 2 * nh;
+    constexpr int MU = 2 * 2 * NM * 2;                 // doubles per parity: [2 blk][2 kind][NM][2]
+    double *xl = reinterpret_cast<double *>(cube_lds) + 2 * fft::cube::SLOTS;   // behind the cube
+    double *fitbuf = xl;                               // [2 blk][2 nh]
+    double *mu = fitbuf + 2 * ns;                      // [2 parity][2 blk][2 kind][NM][2]
+    double *kap = mu + 2 * MU;                         // [8 src][R][NM][2]
+    double *lrow = kap + 8 * R * NM * 2;               // [R][NM][2]
+    double *ptab = lrow + R * NM * 2;                  // [20][NM][2]
+    double *mtab = ptab + 20 * NM * 2;                 // [4 NM][2 nh]
+    const FirArgs &a = g.f;
+    const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
+    const int L = 256 * R;
+    const double *xr = a.x + (int64_t)c * a.ldx;
+    double *yr = a.y + (int64_t)c * a.ldy;
+    double *ho = g.held_out + (int64_t)c * L;
+    const int64_t n = g.n;
+    const int64_t p0 = ((int64_t)run * g.W) / g.nruns;
+    const int64_t p1 = ((int64_t)(run + 1) * g.W) / g.nruns;
+    const int64_t first = run == 0 ? 0 : p0 - 1;
+    const int64_t lastf = run < g.nruns - 1 ? p1 : p1 - 1;
+    const int kinv = (65536 + R * NM - 1) / (R * NM);   // t / (R NM) for t < 256 by multiplication
+
+    FirPair<NR, 16> P{a, t, a.wlen - 1, xr, yr, 0, cube_lds};
+    fft::cube::tw_load(t, a.tb, P.tw1, P.tw2);
+#pragma unroll
+    for (int j = 0; j < D; ++j) P.cr[j] = 0.0;
+    for (int i = t; i < R * NM * 2; i += 256) lrow[i] = g.Lrow[i];
+    for (int i = t; i < 20 * NM * 2; i += 256) ptab[i] = g.P[i];
+    for (int i = t; i < 4 * NM * ns; i += 256) mtab[i] = g.M[i];
+    for (int i = t; i < 2 * MU; i += 256) mu[i] = 0.0;
+    double held[kSpecRMax];          // rows NR-1-r of the previous pair's block b, one burst short
+#pragma unroll
+    for (int r = 0; r < kSpecRMax; ++r) held[r] = 0.0;
+    bool bad = false;
+    int64_t bad_at = -1;             // chunk position of the pair that went bad
+    int par = 0;
+    __syncthreads();
+
+    // a sample of the chunk (position i, value v) goes to the output, L samples late, or,
+    // the chunk's last L samples, to `held`
+#define OSZ_ZP_PUT(i_, v_)                      \
+    do {                                        \
+        const int64_t q_ = (i_) + L;            \
+        if (q_ < n) yr[q_] = (v_);              \
+        else ho[q_ - n] = (v_);                 \
+    } while (0)
+
+    for (int64_t p = first; p <= lastf; ++p) {
+        const int64_t o = p * (2 * S);
+        double re[16], im[16];
+        {
+            int64_t off = o + t;
+            asm volatile("" : "+v"(off));   // per pair: hoisted, 2 NR row addresses would spill
+            const double *pa = xr + off;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = j < NR ? pa[256 * j] : 0.0;
+                im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
+            }
+        }
+        P.transform(re, im);
+        // thread -> role indices, recomputed per pair from an opaque copy of t
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        if (tt < nh) {
+            fitbuf[tt] = re[15];
+            fitbuf[ns + tt] = im[15];
+        } else if (tt >= 256 - nh) {
+            fitbuf[tt - 256 + ns] = re[15];
+            fitbuf[ns + tt - 256 + ns] = im[15];
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            re[j] += P.cr[j];
+            im[j] += re[j + NR];
+            P.cr[j] = im[j + NR];
+        }
+        __syncthreads();
+        {   // fit: 4 consecutive lanes share one row of M (block, amplitude, component, mode)
+            const int fg = tt >> 2, p4 = tt & 3;
+            const bool fvalid = fg < 8 * NM;
+            const int fblk = fvalid ? fg / (4 * NM) : 0, frow = fvalid ? fg % (4 * NM) : 0;
+            const int per = nh >> 1;                                  // samples per lane
+            const double *yb = fitbuf + ns * fblk + per * p4;
+            const double *mc = mtab + ns * frow + per * p4;
+            double s = 0.0;
+            for (int k = 0; k < per; ++k) s = fma(mc[k], yb[k], s);
+            if (!fvalid) s = 0.0;
+            s += dpp_row_shr0<1>(s);
+            s += dpp_row_shr0<2>(s);
+            // frow = (2 kind + comp) NM + q
+            const int kind2 = frow / NM, q = frow % NM;
+            if (p4 == 3 && fvalid) mu[par * MU + (((fblk * 2 + (kind2 >> 1)) * NM + q) * 2) + (kind2 & 1)] = s;
+        }
+        __syncthreads();
+        // kappa[src][r][q] = (+-) amplitude * lambda^(256 r):
+        //   0: block a, -mu_a forwards from row 0          4: block b, -mu_b forwards from row 0
+        //   1: block a, +mu_pb forwards from row D         5: block b, +mu_a forwards from row D
+        //   2: block a, -nu_pb backwards from row D-1      6: block b, -nu_a backwards from row D-1
+        //   3: block a, +nu_b backwards from row NR-1      7: held rows of the previous b, +nu_a
+        {
+            const int ksrc = (tt * kinv) >> 16, kr_ = (tt / NM) % R, kq = tt % NM;
+            if (ksrc < 8) {
+                const int mpar = (ksrc == 1 || ksrc == 2) ? par ^ 1 : par;
+                const int mblk = (ksrc == 1 || ksrc == 2 || ksrc == 3 || ksrc == 4) ? 1 : 0;
+                const int mkind = (ksrc == 2 || ksrc == 3 || ksrc == 6 || ksrc == 7) ? 1 : 0;
+                const double sg = (ksrc == 0 || ksrc == 2 || ksrc == 4 || ksrc == 6) ? -1.0 : 1.0;
+                const double *m = mu + mpar * MU + ((mblk * 2 + mkind) * NM + kq) * 2;
+                const double lr = lrow[(kr_ * NM + kq) * 2 + 0], li = lrow[(kr_ * NM + kq) * 2 + 1];
+                kap[((ksrc * R + kr_) * NM + kq) * 2 + 0] = sg * (m[0] * lr - m[1] * li);
+                kap[((ksrc * R + kr_) * NM + kq) * 2 + 1] = sg * (m[0] * li + m[1] * lr);
+            }
+        }
+        __syncthreads();
+        double c7[kSpecRMax];
+        {
+            // forward bursts with lambda^t, then (the same registers) backward ones with
+            // lambda^(255 - t): both sets of powers at once do not fit beside the data
+            double Pr[NM], Pi[NM];
+            zp_powers<NM>(ptab, tt, Pr, Pi);
+#pragma unroll
+            for (int r = 0; r < kSpecRMax; ++r) {
+                if (r < R && r < D) {
+                    const double c0 = zp_dot<NM>(kap + ((0 * R + r) * NM) * 2, Pr, Pi);
+                    const double c4 = zp_dot<NM>(kap + ((4 * R + r) * NM) * 2, Pr, Pi);
+                    re[r] += c0;
+                    im[r] += c4;
+                    re[(D + r) & 15] += zp_dot<NM>(kap + ((1 * R + r) * NM) * 2, Pr, Pi);
+                    im[(D + r) & 15] += zp_dot<NM>(kap + ((5 * R + r) * NM) * 2, Pr, Pi);
+                    if (r == 0 && !bad && (sos_not_finite(c0) || sos_not_finite(c4))) {
+                        bad = true;
+                        bad_at = o;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            zp_powers<NM>(ptab, 255 - tt, Pr, Pi);
+#pragma unroll
+            for (int r = 0; r < kSpecRMax; ++r) {
+                c7[r] = 0.0;
+                if (r < R && r < D) {
+                    re[(D - 1 - r) & 15] += zp_dot<NM>(kap + ((2 * R + r) * NM) * 2, Pr, Pi);
+                    im[(D - 1 - r) & 15] += zp_dot<NM>(kap + ((6 * R + r) * NM) * 2, Pr, Pi);
+                    re[(NR - 1 - r) & 15] += zp_dot<NM>(kap + ((3 * R + r) * NM) * 2, Pr, Pi);
+                    c7[r] = zp_dot<NM>(kap + ((7 * R + r) * NM) * 2, Pr, Pi);
+                }
+            }
+        }
+        const double qn = spec_qnan();
+        const bool own = p >= p0 && p < p1;
+        const bool edge = p == g.W - 1;        // its samples may be among the chunk's last L
+        if (run == 0 && p == 0) {
+            // the chunk opens: what the stream so far still owes these samples, and the
+            // previous chunk's last L samples, complete with this block's +nu
+            const double *ci = g.carry_in + (int64_t)c * kSpecLdc + tt;
+            if (sos_not_finite(g.carry_in[(int64_t)c * kSpecLdc + 4095 + 256 * R]) && !bad) {
+                bad = true;
+                bad_at = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                re[j] += ci[256 * j];
+                im[j] += ci[S + 256 * j];
+            }
+            const double *hi = g.held_in + (int64_t)c * L + tt;
+#pragma unroll
+            for (int r = 0; r < kSpecRMax; ++r)
+                if (r < R) yr[256 * (R - 1 - r) + tt] = bad ? qn : hi[256 * (R - 1 - r)] + c7[r];
+        } else if (p > first) {
+            // the previous pair's last R rows of block b, complete now
+            if (p - 1 >= p0 && p - 1 < p1) {
+                const int64_t ob = o - S + tt;
+#pragma unroll
+                for (int r = 0; r < kSpecRMax; ++r)
+                    if (r < R) yr[ob + 256 * (NR - 1 - r) + L] = bad ? qn : held[r] + c7[r];
+            }
+        }
+        if (own) {
+            int64_t off = o + tt;
+            asm volatile("" : "+v"(off));
+            if (!edge) {
+                double *q = yr + off + L;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    q[256 * j] = bad ? qn : re[j];
+                    if (j < NR - R) q[256 * (j + NR)] = bad ? qn : im[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    OSZ_ZP_PUT(off + 256 * j, bad ? qn : re[j]);
+                    if (j < NR - R) OSZ_ZP_PUT(off + 256 * (j + NR), bad ? qn : im[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kSpecRMax; ++r)
+            if (r < R) held[r] = im[(NR - 1 - r) & 15];
+        par ^= 1;
+    }
+
+    if (run == g.nruns - 1) {
+        // ---- the closing pair: blocks of la and lb samples (lb > 0 only behind a whole
+        // block a), accumulated in LDS over the idle cube: acc[i], i = samples from its start
+        double *acc = reinterpret_cast<double *>(cube_lds);     // 8192 doubles
+        const int64_t o = g.W * (2 * S);
+        const int la = g.la, lb = g.lb;
+        double re[16], im[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int pp = 256 * j + t;
+            re[j] = pp < la ? xr[o + pp] : 0.0;
+            im[j] = pp < lb ? xr[o + la + pp] : 0.0;
+        }
+        P.transform(re, im);
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        if (tt < nh) {
+            fitbuf[tt] = re[15];
+            fitbuf[ns + tt] = im[15];
+        } else if (tt >= 256 - nh) {
+            fitbuf[tt - 256 + ns] = re[15];
+            fitbuf[ns + tt - 256 + ns] = im[15];
+        }
+        __syncthreads();     // also: every thread is done reading the cube
+        {
+            const int fg = tt >> 2, p4 = tt & 3;
+            const bool fvalid = fg < 8 * NM;
+            const int fblk = fvalid ? fg / (4 * NM) : 0, frow = fvalid ? fg % (4 * NM) : 0;
+            const int per = nh >> 1;
+            const double *yb = fitbuf + ns * fblk + per * p4;
+            const double *mc = mtab + ns * frow + per * p4;
+            double s = 0.0;
+            for (int k = 0; k < per; ++k) s = fma(mc[k], yb[k], s);
+            if (!fvalid) s = 0.0;
+            s += dpp_row_shr0<1>(s);
+            s += dpp_row_shr0<2>(s);
+            const int kind2 = frow / NM, q = frow % NM;
+            if (p4 == 3 && fvalid) mu[par * MU + (((fblk * 2 + (kind2 >> 1)) * NM + q) * 2) + (kind2 & 1)] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc[256 * j + t] = re[j] + (j < D ? P.cr[j < D ? j : 0] : 0.0);
+            acc[4096 + 256 * j + t] = 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[la + 256 * j + t] += im[j];
+        {
+            bool nf = false;
+            for (int i = 0; i < MU; ++i) nf = nf || sos_not_finite(mu[par * MU + i]);
+            if (nf && !bad) {
+                bad = true;
+                bad_at = o;
+            }
+        }
+        double Pfr[NM], Pfi[NM], Pbr[NM], Pbi[NM];
+        zp_powers<NM>(ptab, tt, Pfr, Pfi);
+        zp_powers<NM>(ptab, 255 - tt, Pbr, Pbi);
+        // ten sources in two rounds of the kappa table: (parity, block, kind, sign, forward?,
+        // offset: first sample of a forward burst / last sample of a backward one)
+        for (int round = 0; round < 2; ++round) {
+            __syncthreads();
+            const int ksrc = (tt * kinv) >> 16, kr_ = (tt / NM) % R, kq = tt % NM;
+            const int nsrc = round == 0 ? 8 : 2;
+            if (ksrc < nsrc) {
+                int mpar, mblk, mkind;
+                double sg;
+                if (round == 0) {
+                    // 0 +mu_pb  1 -mu_a  2 -mu_b  3 +mu_a  4 +mu_b  5 -nu_pb  6 -nu_a  7 +nu_a (held)
+                    mpar = (ksrc == 0 || ksrc == 5) ? par ^ 1 : par;
+                    mblk = (ksrc == 0 || ksrc == 2 || ksrc == 4 || ksrc == 5) ? 1 : 0;
+                    mkind = ksrc >= 5 ? 1 : 0;
+                    sg = (ksrc == 1 || ksrc == 2 || ksrc == 5 || ksrc == 6) ? -1.0 : 1.0;
+                } else {
+                    // 0 -nu_b  1 +nu_b
+                    mpar = par;
+                    mblk = 1;
+                    mkind = 1;
+                    sg = ksrc == 0 ? -1.0 : 1.0;
+                }
+                const double *m = mu + mpar * MU + ((mblk * 2 + mkind) * NM + kq) * 2;
+                const double lr = lrow[(kr_ * NM + kq) * 2 + 0], li = lrow[(kr_ * NM + kq) * 2 + 1];
+                kap[((ksrc * R + kr_) * NM + kq) * 2 + 0] = sg * (m[0] * lr - m[1] * li);
+                kap[((ksrc * R + kr_) * NM + kq) * 2 + 1] = sg * (m[0] * li + m[1] * lr);
+            }
+            __syncthreads();
+            for (int s = 0; s < nsrc; ++s) {
+                const bool fwd = round == 0 && s < 5;
+                int off;
+                if (round == 0)
+                    off = s == 0 ? 256 * D : s == 1 ? 0 : s == 2 ? la : s == 3 ? 4096 : s == 4 ? la + 4096
+                        : s == 5 ? 256 * D - 1 : s == 6 ? 4095 : -1;
+                else
+                    off = s == 0 ? la + 4095 : la - 1;
+                if (round == 0 && s == 7) {
+                    // the previous pair's last R rows of block b: complete with this block's +nu
+                    const int64_t ob = o - S + tt;
+#pragma unroll
+                    for (int r = 0; r < kSpecRMax; ++r)
+                        if (r < R)
+                            OSZ_ZP_PUT(ob + 256 * (NR - 1 - r),
+                                       bad ? spec_qnan() : held[r] + zp_dot<NM>(kap + ((7 * R + r) * NM) * 2, Pbr, Pbi));
+                    continue;
+                }
+                for (int r = 0; r < R; ++r) {
+                    const double cs = fwd ? zp_dot<NM>(kap + ((s * R + r) * NM) * 2, Pfr, Pfi)
+                                          : zp_dot<NM>(kap + ((s * R + r) * NM) * 2, Pbr, Pbi);
+                    const int i = fwd ? off + 256 * r + tt : off - 256 * r - (255 - tt);
+                    if (i >= 0 && i < 8192) acc[i] += cs;
+                }
+                __syncthreads();
+            }
+        }
+        const double qn = spec_qnan();
+        const int ltot = la + lb;
+        for (int i = t; i < ltot; i += 256) OSZ_ZP_PUT(o + i, bad ? qn : acc[i]);
+        double *co = g.carry_out + (int64_t)c * kSpecLdc;
+        for (int i = t; i < kSpecLdc; i += 256) {
+            const int src = ltot + i;
+            co[i] = bad ? qn : (src < 8192 ? acc[src] : 0.0);
+        }
+        if (g.hist) {
+            double *hr = g.hist + (int64_t)c * g.hist_len;
+            const double *src = xr + n - g.hist_len;
+            for (int i = t; i < g.hist_len; i += 256) hr[i] = src[i];
+        }
+    }
+#undef OSZ_ZP_PUT
+    // where the forward stream of this channel first went bad (the caller's NaN reach)
+    if (bad && t == 0 && g.nanpos) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
+    if (g.nruns > 1 && g.segcnt) {
+        const int64_t pairlen = 2 * (int64_t)S, Wp = g.W;
+        const int nr_ = g.nruns;
+        // the last stored sample of run q: its last pair's held rows, L samples late
+        __syncthreads();
+        int last = 0;
+        if (threadIdx.x == 0) {
+            __threadfence();
+            last = atomicAdd(g.segcnt + c, 1) == nr_ - 1;
+        }
+        last = __syncthreads_or(last);
+        if (last) {
+            if (threadIdx.x == 0) atomicExch(g.segcnt + c, 0);
+            __threadfence();
+            int badrun = nr_;
+            for (int s = nr_ - 2; s >= 0; --s) {
+                const int64_t e = (((int64_t)(s + 1) * Wp) / nr_) * pairlen + L;
+                const unsigned long long bits = __hip_atomic_load(
+                    reinterpret_cast<const unsigned long long *>(yr + e - 1), __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+                if (sos_not_finite(__longlong_as_double((long long)bits))) badrun = s;
+            }
+            if (badrun < nr_) {
+                const int64_t from = (((int64_t)(badrun + 1) * Wp) / nr_) * pairlen + L;
+                sos_fill_nan(yr + from, n - from);
+                sos_fill_nan(ho, L);
+                sos_fill_nan(g.carry_out + (int64_t)c * kSpecLdc, kSpecLdc);
+            }
+        }
+    }
+}
+
+// NaN reach of sosfiltfilt (sos_tile.h): a chunk of the reference's output is NaN as a
+// whole when the forward stream is NaN anywhere in it or in the chunk after it.  y holds
+// output samples [s0, s0 + n) of channel c; chunks are cs samples from `origin` on.
+__global__ void zp_seal_kernel(double *y, int64_t ldy, int64_t n, long long s0, long long origin, long long cs,
+                               const long long *nanpos) {
+    const int c = blockIdx.y;
+    const long long np = nanpos[c];
+    if (np == 0x7fffffffffffffffLL) return;
+    long long k = (np - origin) / cs;
+    if (np < origin) k = 0;
+    const long long from = origin + (k - 1) * cs;       // the chunk before the one that holds the NaN
+    double *yr = y + (int64_t)c * ldy;
+    const double qn = spec_qnan();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (s0 + i >= from) yr[i] = qn;
+}
+
+__global__ void zp_fill_ll_kernel(long long *p, int n, long long v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------- host side
+struct ChainZp {
+    osz_fir_s *fir = nullptr;
+    osz_sos_s *sos = nullptr;
+    bool eligible = false, open = false;
+    int NR = 0, NM = 0, R = 0, nh = 0;
+    double *dH = nullptr, *dM = nullptr, *dP = nullptr, *dL = nullptr;
+    double *dcarry[2] = {nullptr, nullptr}, *dheld[2] = {nullptr, nullptr};
+    int cur = 0;
+    int64_t pos = 0;               // stream position of the next chunk's first sample
+    long long *dnanpos = nullptr;
+    int hist_cap = 0;              // wlen - 1 + warm_len
+    double *dhist[2] = {nullptr, nullptr};
+    int hcur = 0;
+    int64_t hist_n = 0;
+    double *dscratch = nullptr;
+    double *dzero = nullptr;       // (nsec, nch, 2) zeros: start state of the opening's backward pass
+};
+
+static void zp_free(ChainZp *s) {
+    (void)hipFree(s->dH);
+    (void)hipFree(s->dM);
+    (void)hipFree(s->dP);
+    (void)hipFree(s->dL);
+    for (int q = 0; q < 2; ++q) {
+        (void)hipFree(s->dcarry[q]);
+        (void)hipFree(s->dheld[q]);
+        (void)hipFree(s->dhist[q]);
+    }
+    (void)hipFree(s->dnanpos);
+    (void)hipFree(s->dscratch);
+    (void)hipFree(s->dzero);
+    delete s;
+}
+
+void zp_unlink(ChainZp *s) {
+    if (!s) return;
+    if (s->fir) s->fir->zp = nullptr;
+    if (s->sos) s->sos->zp = nullptr;
+    zp_free(s);
+}
+
+static size_t zp_lds_bytes(const ChainZp *s) {
+    const int NM = s->NM, R = s->R, ns = 2 * s->nh;
+    return sizeof(fft::cube::C2) * fft::cube::SLOTS +
+           sizeof(double) * (2 * ns + 2 * 2 * 2 * NM * 2 + 8 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * ns);
+}
+
+static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
+    ChainZp *s = sos->zp;
+    if (s && s->fir != fir) {
+        zp_unlink(s);
+        s = nullptr;
+    }
+    if (!s && fir->zp) zp_unlink(fir->zp);
+    if (!s) {
+        s = new ChainZp();
+        s->fir = fir;
+        s->sos = sos;
+        fir->zp = sos->zp = s;
+        if (fir->parts.size() == 1 && fir->nch == sos->nch) {
+            const spec::TablesZp T = spec::build_zp(fir->htaps.data(), fir->ntaps, sos->coef, sos->nsec,
+                                                    sos->warm_len <= (1 << 20));
+            if (T.eligible) {
+                auto up = [](double **d, const std::vector<double> &v) -> int {
+                    OSZ_HIP(hipMalloc(d, v.size() * sizeof(double)));
+                    OSZ_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+                    return OSZ_OK;
+                };
+                int rc;
+                if ((rc = up(&s->dH, T.H)) || (rc = up(&s->dM, T.M)) || (rc = up(&s->dP, T.P)) ||
+                    (rc = up(&s->dL, T.L)))
+                    return rc;
+                const int nch = fir->nch;
+                for (int q = 0; q < 2; ++q) {
+                    OSZ_HIP(hipMalloc(&s->dcarry[q], sizeof(double) * (size_t)nch * kSpecLdc));
+                    OSZ_HIP(hipMalloc(&s->dheld[q], sizeof(double) * (size_t)nch * 256 * T.R));
+                }
+                s->hist_cap = (fir->ntaps - 1) + (int)sos->warm_len;
+                for (int q = 0; q < 2; ++q)
+                    OSZ_HIP(hipMalloc(&s->dhist[q], sizeof(double) * (size_t)nch * s->hist_cap));
+                OSZ_HIP(hipMalloc(&s->dnanpos, sizeof(long long) * (size_t)nch));
+                const size_t sb = sizeof(double) * (size_t)sos->nsec * nch * 2;
+                OSZ_HIP(hipMalloc(&s->dzero, sb));
+                OSZ_HIP(hipMemset(s->dzero, 0, sb));
+                s->NR = T.NR;
+                s->NM = T.NM;
+                s->R = T.R;
+                s->nh = T.nh;
+                s->eligible = true;
+            }
+        }
+    }
+    *out = s;
+    return OSZ_OK;
+}
+
+using zp_kern_t = void (*)(ZpArgs);
+template <int NM>
+static zp_kern_t zp_kernel_for(int nr) {
+    static const zp_kern_t k[8] = {chain_zp_kernel<8, NM>,  chain_zp_kernel<9, NM>,  chain_zp_kernel<10, NM>,
+                                   chain_zp_kernel<11, NM>, chain_zp_kernel<12, NM>, chain_zp_kernel<13, NM>,
+                                   chain_zp_kernel<14, NM>, chain_zp_kernel<15, NM>};
+    return k[nr - 8];
+}
+
+// one chunk through the kernel; hist: keep the input a later osz_chain_zp_finish replays
+static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double *y, int64_t ldy,
+                     hipStream_t st) {
+    osz_fir_s *fir = s->fir;
+    osz_sos_s *sos = s->sos;
+    const int NR = s->NR, S = 256 * NR;
+    const int64_t pair = 2 * (int64_t)S;
+    const int64_t npw = n / pair, rem = n - npw * pair;
+    const int64_t W = rem == 0 ? npw - 1 : npw;
+    const int64_t nlast = n - W * pair;
+    // one round of resident workgroups (two per CU); a run has a pair of its own
+    int64_t nruns = 512 / fir->nch;
+    if (nruns > W) nruns = W;
+    if (nruns < 1) nruns = 1;
+    ZpArgs g{};
+    g.f.x = x;
+    g.f.y = y;
+    g.f.ldx = ldx;
+    g.f.ldy = ldy;
+    g.f.n = n;
+    g.f.skip = 0;
+    g.f.wlen = fir->ntaps;
+    g.f.step = S;
+    g.f.H = s->dH;
+    g.f.tb = fir->tb;
+    g.n = n;
+    g.W = W;
+    g.nruns = (int)nruns;
+    g.la = (int)std::min<int64_t>(nlast, S);
+    g.lb = (int)(nlast - g.la);
+    g.R = s->R;
+    g.nh = s->nh;
+    g.M = s->dM;
+    g.P = s->dP;
+    g.Lrow = s->dL;
+    g.carry_in = s->dcarry[s->cur];
+    g.carry_out = s->dcarry[s->cur ^ 1];
+    g.held_in = s->dheld[s->cur];
+    g.held_out = s->dheld[s->cur ^ 1];
+    g.segcnt = sos_nanfix() ? sos->dsegcnt : nullptr;
+    g.nanpos = s->dnanpos;
+    g.pos = s->pos;
+    if (n >= s->hist_cap) {
+        g.hist = s->dhist[s->hcur];
+        g.hist_len = s->hist_cap;
+        s->hist_n = s->hist_cap;
+    } else {
+        const int64_t keep = std::min<int64_t>(s->hist_n, s->hist_cap - n);
+        double *dst = s->dhist[s->hcur ^ 1];
+        if (keep > 0)
+            OSZ_HIP(hipMemcpy2DAsync(dst, sizeof(double) * s->hist_cap, s->dhist[s->hcur] + (s->hist_n - keep),
+                                     sizeof(double) * s->hist_cap, sizeof(double) * keep, fir->nch,
+                                     hipMemcpyDeviceToDevice, st));
+        OSZ_HIP(hipMemcpy2DAsync(dst + keep, sizeof(double) * s->hist_cap, x, sizeof(double) * ldx,
+                                 sizeof(double) * n, fir->nch, hipMemcpyDeviceToDevice, st));
+        s->hcur ^= 1;
+        s->hist_n = keep + n;
+        g.hist = nullptr;
+        g.hist_len = 0;
+    }
+    zp_kern_t kern = s->NM == 2 ? zp_kernel_for<2>(NR) : s->NM == 4 ? zp_kernel_for<4>(NR) : zp_kernel_for<6>(NR);
+    const size_t lds = zp_lds_bytes(s);
+    OSZ_DYN_LDS(kern, lds);
+    {
+        KernelTimer kt("chain_zp", st);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nruns, fir->nch), dim3(256), lds, st, g);
+    }
+    OSZ_HIP(hipGetLastError());
+    s->cur ^= 1;
+    s->pos += n;
+    return OSZ_OK;
+}
+
+}  // namespace osz
+
+using namespace osz;
+
+extern "C" {
+
+int64_t osz_chain_zp_lag(osz_fir_t fir, osz_sos_t sos) {
+    if (!fir || !sos) return -1;
+    ChainZp *s = nullptr;
+    if (zp_get(fir, sos, &s) != OSZ_OK || !s->eligible) return -1;
+    return 256 * (int64_t)s->R;
+}
+
+int64_t osz_chain_zp_min_chunk(osz_fir_t fir, osz_sos_t sos) {
+    if (!fir || !sos) return -1;
+    ChainZp *s = nullptr;
+    if (zp_get(fir, sos, &s) != OSZ_OK || !s->eligible) return -1;
+    return 4 * 256 * (int64_t)s->NR;
+}
+
+int osz_chain_zp_open(osz_fir_t fir, osz_sos_t sos, int64_t skip, void *stream) {
+    OSZ_REQUIRE(fir && sos, "osz_chain_zp_open: null handle");
+    OSZ_SAME_DEVICE(fir, "osz_chain_zp_open");
+    OSZ_SAME_DEVICE(sos, "osz_chain_zp_open");
+    hipStream_t st = as_stream(stream);
+    ChainZp *s = nullptr;
+    int rc = zp_get(fir, sos, &s);
+    if (rc) return rc;
+    if (!s->eligible)
+        return fail(OSZ_ERR_UNSUPPORTED, "osz_chain_zp_open: this filter pair does not take the zero-phase kernel");
+    const int cl = 4096 + 256 * s->R;
+    OSZ_REQUIRE(skip >= 0 && skip + cl <= kSpecLdc, "osz_chain_zp_open: skip=%lld", (long long)skip);
+    // the handles' own states must be current (the cascade's start state is read from the SOS handle)
+    rc = spec_touch(sos->spec, st);
+    if (rc) return rc;
+    const int nch = fir->nch;
+    // carry[skip + i] = what the cascade's start state rings, forwards, then filtered backwards
+    double *cb = s->dcarry[s->cur];
+    OSZ_HIP(hipMemsetAsync(cb, 0, sizeof(double) * (size_t)nch * kSpecLdc, st));
+    rc = sos_forward_raw(sos, cb + skip, kSpecLdc, cb + skip, kSpecLdc, cl, st);
+    if (rc) return rc;
+    rc = sos_backward_raw(sos, cb + skip, kSpecLdc, cb + skip, kSpecLdc, cl, s->dzero, st);
+    if (rc) return rc;
+    OSZ_HIP(hipMemsetAsync(s->dheld[s->cur], 0, sizeof(double) * (size_t)nch * 256 * s->R, st));
+    hipLaunchKernelGGL(zp_fill_ll_kernel, dim3((nch + 255) / 256), dim3(256), 0, st, s->dnanpos, nch,
+                       0x7fffffffffffffffLL);
+    OSZ_HIP(hipGetLastError());
+    s->pos = 0;
+    s->hist_n = 0;
+    s->open = true;
+    return OSZ_OK;
+}
+
+int osz_chain_zp_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, int64_t n, double *y,
+                      int64_t ldy, void *stream) {
+    OSZ_REQUIRE(fir && sos && x && y, "osz_chain_zp_step: null argument");
+    OSZ_REQUIRE(n >= 1 && ldx >= n && ldy >= n, "osz_chain_zp_step: n=%lld ldx=%lld ldy=%lld", (long long)n,
+                (long long)ldx, (long long)ldy);
+    OSZ_SAME_DEVICE(fir, "osz_chain_zp_step");
+    OSZ_SAME_DEVICE(sos, "osz_chain_zp_step");
+    ChainZp *s = sos->zp;
+    OSZ_REQUIRE(s && s->fir == fir && s->open, "osz_chain_zp_step: osz_chain_zp_open first");
+    OSZ_REQUIRE(n >= 4 * 256 * (int64_t)s->NR, "osz_chain_zp_step: a chunk of %lld samples is shorter than two pairs of blocks (%d)",
+                (long long)n, 4 * 256 * s->NR);
+    return zp_launch(s, x, ldx, n, y, ldy, as_stream(stream));
+}
+
+int osz_chain_zp_finish(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, int64_t m, double *y,
+                        int64_t ldy, int64_t ny, void *stream) {
+    OSZ_REQUIRE(fir && sos, "osz_chain_zp_finish: null handle");
+    OSZ_SAME_DEVICE(fir, "osz_chain_zp_finish");
+    OSZ_SAME_DEVICE(sos, "osz_chain_zp_finish");
+    hipStream_t st = as_stream(stream);
+    ChainZp *s = sos->zp;
+    OSZ_REQUIRE(s && s->fir == fir && s->open, "osz_chain_zp_finish: no zero-phase stream is open");
+    const int nch = fir->nch;
+    FirPart &pt = fir->parts[0];
+    const int wm1 = pt.ntaps - 1;
+    // 1. the handles' own states at the end of the samples stepped so far: the plain
+    // kernels over the last hist_cap of them (everything, when fewer have gone by: the
+    // stream started from a zero FIR tail; the cascade's state then is approximate only
+    // if fewer than warm_len samples were stepped, which the callers exclude)
+    {
+        int rc = spec_touch(sos->spec, st);
+        if (rc) return rc;
+    }
+    OSZ_HIP(hipMemsetAsync(pt.dstate[pt.cur], 0, sizeof(double) * (size_t)nch * wm1, st));
+    OSZ_HIP(hipMemsetAsync(sos->dstate, 0, sizeof(double) * (size_t)sos->nsec * nch * 2, st));
+    if (s->hist_n > 0) {
+        if (!s->dscratch) OSZ_HIP(hipMalloc(&s->dscratch, sizeof(double) * (size_t)nch * s->hist_cap));
+        int rc = fir_push_raw(fir, s->dhist[s->hcur], s->hist_cap, s->hist_n, s->dscratch, s->hist_cap, 0, st);
+        if (rc) return rc;
+        rc = sos_forward_raw(sos, s->dscratch, s->hist_cap, s->dscratch, s->hist_cap, s->hist_n, st);
+        if (rc) return rc;
+    }
+    // 2. the output samples the stream is still short of need the head of what follows
+    if (ny > 0) {
+        OSZ_REQUIRE(x && y && m >= 4 * 256 * (int64_t)s->NR && ldx >= m && ny <= m && ldy >= ny,
+                    "osz_chain_zp_finish: %lld output samples from %lld input samples", (long long)ny, (long long)m);
+        // through a scratch output: the kernel writes all m of them
+        double *tmp = nullptr;
+        OSZ_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)nch * m));
+        int rc = zp_launch(s, x, ldx, m, tmp, m, st);
+        if (rc == OSZ_OK)
+            rc = hipMemcpy2DAsync(y, sizeof(double) * ldy, tmp, sizeof(double) * m, sizeof(double) * ny, nch,
+                                  hipMemcpyDeviceToDevice, st) == hipSuccess ? OSZ_OK
+                                                                            : fail(OSZ_ERR_HIP, "osz_chain_zp_finish: copy");
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(tmp);
+        if (rc) return rc;
+    }
+    s->open = false;
+    return OSZ_OK;
+}
+
+int osz_chain_zp_seal(osz_fir_t fir, osz_sos_t sos, double *y, int64_t ldy, int64_t n, int64_t s0,
+                      int64_t origin, int64_t cs, void *stream) {
+    OSZ_REQUIRE(fir && sos && y, "osz_chain_zp_seal: null argument");
+    OSZ_REQUIRE(n >= 0 && ldy >= n && cs >= 1, "osz_chain_zp_seal: n=%lld cs=%lld", (long long)n, (long long)cs);
+    ChainZp *s = sos->zp;
+    OSZ_REQUIRE(s && s->fir == fir, "osz_chain_zp_seal: no zero-phase stream");
+    if (n == 0) return OSZ_OK;
+    hipLaunchKernelGGL(zp_seal_kernel, dim3(4, fir->nch), dim3(256), 0, as_stream(stream), y, ldy, n,
+                       (long long)s0, (long long)origin, (long long)cs, s->dnanpos);
+    OSZ_HIP(hipGetLastError());
+    return OSZ_OK;
+}
+
+}  // extern "C"

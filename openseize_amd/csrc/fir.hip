@@ -443,6 +443,7 @@ int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch) {
     (void)hipGetDevice(&p->device);
     p->dtails = p->dD = p->dW = nullptr;
     p->spec = nullptr;
+    p->zp = nullptr;
     p->htaps.assign(taps, taps + ntaps);
     p->tails_cap = p->w_cap = 0;
     p->dlen = 0;
@@ -475,6 +476,7 @@ int osz_fir_create(osz_fir_t *h, const double *taps, int ntaps, int nch) {
 int osz_fir_destroy(osz_fir_t h) {
     if (!h) return OSZ_OK;
     spec_unlink(h->spec);
+    zp_unlink(h->zp);
     for (auto &pt : h->parts) {
         (void)hipFree(pt.dH);
         (void)hipFree(pt.dstate[0]);

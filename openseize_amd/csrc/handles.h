@@ -12,6 +12,7 @@
 
 namespace osz {
 struct ChainSpec;   // chain_spec.hip: a FIR and a SOS handle that run the spectral kernel together
+struct ChainZp;     // chain_zp.hip: the same pair on the zero-phase kernel
 }
 
 struct FirPart {
@@ -34,6 +35,7 @@ struct osz_fir_s {
     osz::fft::Tables tb;
     std::vector<double> htaps;   // host copy of the taps
     osz::ChainSpec *spec;        // set while the handle's stream runs in the spectral chain kernel
+    osz::ChainZp *zp;            // tables and carried sequences of the zero-phase kernel
 };
 
 
@@ -67,6 +69,7 @@ struct osz_sos_s {
     const double *side_in[2];             // fa, fb of that pass: (nch, n) views with row pitch ld
     int64_t side_ld[2], side_n[2];
     osz::ChainSpec *spec;                 // see osz_fir_s
+    osz::ChainZp *zp;
 };
 
 namespace osz {
@@ -101,4 +104,9 @@ int fir_push_raw(osz_fir_s *h, const double *x, int64_t ldx, int64_t n, double *
                  int64_t skip, hipStream_t st);
 int sos_forward_raw(osz_sos_s *h, const double *x, int64_t ldx, double *y, int64_t ldy, int64_t n,
                     hipStream_t st);
+// a backward pass over (nch, n) from the section states in `state` ((nsec, nch, 2), device);
+// the handle's own state is not touched (sos.hip)
+int sos_backward_raw(osz_sos_s *h, const double *x, int64_t ldx, double *y, int64_t ldy, int64_t n,
+                     const double *state, hipStream_t st);
+void zp_unlink(ChainZp *s);
 }  // namespace osz

@@ -1361,6 +1361,7 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     p->dtmp_side = p->dcarry_side = nullptr;
     p->side_busy = false;
     p->spec = nullptr;
+    p->zp = nullptr;
     p->touch = 0;
     if (const char *e = getenv("OSZ_SOS_TOUCH")) p->touch = atoi(e);
     {
@@ -1418,6 +1419,7 @@ int64_t osz_sos_warm_len(osz_sos_t h) { return h ? h->warm_len : -1; }
 int osz_sos_destroy(osz_sos_t h) {
     if (!h) return OSZ_OK;
     spec_unlink(h->spec);
+    zp_unlink(h->zp);
     if (h->side) (void)hipStreamSynchronize(h->side);   // a deferred backward pass of osz_chain_step
     (void)hipFree(h->dsec);
     for (int i = 0; i < 33; ++i) (void)hipFree(h->dsec_t[i]);
@@ -1532,6 +1534,25 @@ int osz::sos_forward_raw(osz_sos_s *h, const double *x, int64_t ldx, double *y, 
     if (rc) return rc;
     std::swap(h->dstate, h->dstate_alt);
     return OSZ_OK;
+}
+
+int osz::sos_backward_raw(osz_sos_s *h, const double *x, int64_t ldx, double *y, int64_t ldy, int64_t n,
+                          const double *state, hipStream_t st) {
+    SosArgs a{};
+    a.x = x;
+    a.y = y;
+    a.ldx = ldx;
+    a.ldy = ldy;
+    a.n = n;
+    a.sec = h->dsec;
+    a.state_in = state;
+    a.zi_unit = nullptr;
+    a.state_out = nullptr;
+    a.nsec = h->nsec;
+    a.nch = h->nch;
+    a.tab2 = h->dtab2;
+    a.touch = h->touch;
+    return sos_launch<true>(a, h->dcarry, h->T, h->NW, h->warm_len, st);
 }
 
 extern "C" {

@@ -280,5 +280,189 @@ inline Tables build(const double *taps, int wlen, const double *sos, int nsec, b
     return T;
 }
 
+// ---- the two-sided scheme (chain_zp.hip): FIR -> forward cascade -> backward cascade,
+// i.e. the zero-phase filter |H_iir|^2 H_fir, as one multiplication per bin.  A block now
+// rings on both sides: after its FIR output has ended (causal modes, as above) and BEFORE
+// its first sample (the backward pass: the same modes, decaying towards the past).  In the
+// circular window the left tail sits at the END of row 15, running down from sample 4095.
+// One joint least-squares fit on the first and the last `nh` samples of row 15 gives both
+// sets of amplitudes: mu_q (causal, extrapolated to window sample 4096) and nu_q
+// (anticausal, at window sample 4095).
+//   H     [4096][2]  FFT(h) |prod_s B_s / A_s|^2 / 4096
+//   M     [4 NM][2 nh]  rows: Re mu, Im mu, Re nu, Im nu (NM each); columns: samples
+//         l = 0 .. nh-1, then 256-nh .. 255 of row 15
+//   P     [20][NM][2]  lambda^(32 i), i < 8; lambda^(4 i), i < 8; lambda^i, i < 4
+//   L     [5][NM][2]   lambda^(256 r)
+//   R     burst rows, from both tails of the two-sided composite impulse response
+// NR is the largest block height whose guard rows hold the bursts (R <= D, D + R <= NR).
+struct TablesZp {
+    bool eligible = false;
+    int NR = 0, NM = 0, nm = 0, R = 0, nh = 0;
+    double fit_ratio = 0.0;
+    std::vector<double> H, M, P, L;
+};
+
+// lds_budget: bytes the kernel may use behind the cube (two workgroups per CU); the fit
+// reads as many samples as its matrix then leaves room for
+inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int nsec, bool forgets,
+                         int lds_budget = 16384) {
+    TablesZp T;
+    if (wlen < 2 || !forgets) return T;
+    std::vector<Mode> modes;
+    for (int q = 0; q < nsec; ++q) {
+        const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+        if (a1 == 0.0L && a2 == 0.0L) continue;
+        if (a2 == 0.0L) {
+            modes.push_back({-a1, 0.0L, true});
+            continue;
+        }
+        const ld_t disc = a1 * a1 - 4.0L * a2;
+        if (disc < 0.0L) {
+            modes.push_back({-a1 / 2, sqrtl(-disc) / 2, false});
+        } else if (disc > 0.0L) {
+            modes.push_back({(-a1 + sqrtl(disc)) / 2, 0.0L, true});
+            modes.push_back({(-a1 - sqrtl(disc)) / 2, 0.0L, true});
+        } else {
+            return T;
+        }
+    }
+    const int nm = (int)modes.size();
+    if (nm < 1 || nm > 6) return T;
+    for (auto &m : modes)
+        if (!(m.re * m.re + m.im * m.im < 1.0L)) return T;
+    const int NM = (nm + 1) & ~1;
+    // two-sided composite impulse response g2[m], m = -Lg .. Lg-1, stored at index Lg + m
+    const int Lg = kN + 256 * 17;
+    std::vector<ld_t> g2(2 * Lg, 0.0L);
+    for (int i = 0; i < wlen && i < Lg; ++i) g2[Lg + i] = taps[i];
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int q = 0; q < nsec; ++q) {
+            const ld_t b0 = sos[6 * q], b1 = sos[6 * q + 1], b2 = sos[6 * q + 2];
+            const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+            ld_t z0 = 0.0L, z1 = 0.0L;
+            for (int i = 0; i < 2 * Lg; ++i) {
+                const int idx = pass == 0 ? i : 2 * Lg - 1 - i;
+                const ld_t xin = g2[idx], y = b0 * xin + z0;
+                z0 = b1 * xin - a1 * y + z1;
+                z1 = b2 * xin - a2 * y;
+                g2[idx] = y;
+            }
+        }
+    }
+    std::vector<ld_t> right2(2 * Lg + 1, 0.0L), left2(2 * Lg + 1, 0.0L);   // tail energies
+    for (int i = 2 * Lg - 1; i >= 0; --i) right2[i] = right2[i + 1] + g2[i] * g2[i];
+    for (int i = 0; i < 2 * Lg; ++i) left2[i + 1] = left2[i] + g2[i] * g2[i];
+    const ld_t tot = sqrtl(right2[0]);
+    int NRmax = (3841 - wlen) / 256;
+    if (NRmax > 15) NRmax = 15;
+    int NR = 0, R = 0;
+    for (int cand = NRmax; cand >= 8 && !NR; --cand) {
+        const int S = 256 * cand, D = 16 - cand;
+        for (int r = 1; r <= kRMax; ++r) {
+            const int ir = Lg + kN + 256 * r - S + 1, il = Lg - 256 * r;
+            if (ir >= 2 * Lg || il < 0) break;
+            if (sqrtl(right2[ir]) <= 3e-18L * tot && sqrtl(left2[il]) <= 3e-18L * tot) {
+                if (r <= D && D + r <= cand) {
+                    NR = cand;
+                    R = r;
+                }
+                break;
+            }
+        }
+    }
+    if (!NR) return T;
+    // LDS behind the cube: fit samples [2][2 nh], amplitudes [2][2][2][NM][2], kappa
+    // [8][R][NM][2], L [R][NM][2], P [20][NM][2], M [4 NM][2 nh]
+    int nh = 0;
+    for (int cand = 32; cand >= 12 && !nh; cand -= 4) {
+        const int bytes = 8 * (2 * 2 * cand + 2 * 2 * 2 * NM * 2 + 8 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 +
+                               4 * NM * 2 * cand);
+        if (bytes <= lds_budget) nh = cand;
+    }
+    if (!nh) return T;
+    const int ns = 2 * nh;
+    std::vector<int> col_mode, col_kind;      // kind: 0 Re causal, 1 Im causal, 2 Re anticausal, 3 Im anticausal
+    for (int side = 0; side < 2; ++side)
+        for (int q = 0; q < nm; ++q) {
+            col_mode.push_back(q);
+            col_kind.push_back(2 * side);
+            if (!modes[q].real) {
+                col_mode.push_back(q);
+                col_kind.push_back(2 * side + 1);
+            }
+        }
+    const int nd = (int)col_mode.size();
+    std::vector<ld_t> B((size_t)ns * nd);
+    for (int j = 0; j < nd; ++j)
+        for (int i = 0; i < ns; ++i) {
+            const int l = i < nh ? i : 256 - ns + i;
+            ld_t pr, pi;
+            mode_pow(modes[col_mode[j]], col_kind[j] < 2 ? l : 255 - l, pr, pi);
+            B[(size_t)j * ns + i] = (col_kind[j] & 1) ? -pi : pr;
+        }
+    std::vector<ld_t> Pinv;
+    const ld_t ratio = pinv_qr(B, ns, nd, Pinv);
+    T.fit_ratio = (double)ratio;
+    if (!(ratio > 1e-9L)) return T;
+    T.M.assign((size_t)4 * NM * ns, 0.0);
+    for (int side = 0; side < 2; ++side)
+        for (int q = 0; q < nm; ++q) {
+            int ja = -1, jb = -1;
+            for (int j = 0; j < nd; ++j)
+                if (col_mode[j] == q && col_kind[j] / 2 == side) ((col_kind[j] & 1) ? jb : ja) = j;
+            ld_t cr = 1.0L, ci = 0.0L;
+            if (side == 0) mode_pow(modes[q], 256, cr, ci);       // mu = gamma lambda^256; nu as fitted
+            for (int i = 0; i < ns; ++i) {
+                const ld_t av = Pinv[(size_t)ja * ns + i];
+                const ld_t bv = jb >= 0 ? Pinv[(size_t)jb * ns + i] : 0.0L;
+                T.M[(size_t)((2 * side) * NM + q) * ns + i] = (double)(cr * av - ci * bv);
+                T.M[(size_t)((2 * side + 1) * NM + q) * ns + i] = (double)(ci * av + cr * bv);
+            }
+        }
+    // zero-phase composite spectrum / 4096
+    std::vector<ld_t> fr, fi;
+    fir_spectrum(taps, wlen, fr, fi);
+    const ld_t PI = acosl(-1.0L);
+    T.H.assign(2 * kN, 0.0);
+    for (int k = 0; k < kN; ++k) {
+        const ld_t ang = -2.0L * PI * (ld_t)k / (ld_t)kN;
+        const ld_t zr = cosl(ang), zi = sinl(ang);
+        const ld_t z2r = zr * zr - zi * zi, z2i = 2.0L * zr * zi;
+        ld_t gain = 1.0L;
+        for (int q = 0; q < nsec; ++q) {
+            const ld_t b0 = sos[6 * q], b1 = sos[6 * q + 1], b2 = sos[6 * q + 2];
+            const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+            const ld_t nr = b0 + b1 * zr + b2 * z2r, ni = b1 * zi + b2 * z2i;
+            const ld_t dr = 1.0L + a1 * zr + a2 * z2r, di = a1 * zi + a2 * z2i;
+            gain *= (nr * nr + ni * ni) / (dr * dr + di * di);
+        }
+        T.H[2 * k] = (double)(fr[k] / kN * gain);
+        T.H[2 * k + 1] = (double)(fi[k] / kN * gain);
+    }
+    T.P.assign((size_t)20 * NM * 2, 0.0);
+    T.L.assign((size_t)kRMax * NM * 2, 0.0);
+    for (int q = 0; q < nm; ++q) {
+        for (int i = 0; i < 20; ++i) {
+            ld_t pr, pi;
+            mode_pow(modes[q], i < 8 ? 32 * i : i < 16 ? 4 * (i - 8) : i - 16, pr, pi);
+            T.P[((size_t)i * NM + q) * 2 + 0] = (double)pr;
+            T.P[((size_t)i * NM + q) * 2 + 1] = (double)pi;
+        }
+        for (int r = 0; r < kRMax; ++r) {
+            ld_t pr, pi;
+            mode_pow(modes[q], 256 * r, pr, pi);
+            T.L[((size_t)r * NM + q) * 2 + 0] = (double)pr;
+            T.L[((size_t)r * NM + q) * 2 + 1] = (double)pi;
+        }
+    }
+    T.NR = NR;
+    T.NM = NM;
+    T.nm = nm;
+    T.R = R;
+    T.nh = nh;
+    T.eligible = true;
+    return T;
+}
+
 }  // namespace spec
 }  // namespace osz

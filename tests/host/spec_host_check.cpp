@@ -1,6 +1,6 @@
 // Builds the host tables of the spectral FIR -> cascade kernel (csrc/spec_tables.h)
 // with g++ and writes them out for tests/test_spec_host.py.
-//   spec_host_check <in.bin> <out.bin>
+//   spec_host_check <in.bin> <out.bin> [zp]      (zp: the two-sided tables of chain_zp.hip)
 // in:  int32 wlen, int32 nsec, int32 forgets, double taps[wlen], double sos[nsec][6]
 // out: int32 eligible, NR, NM, nm, R, double fit_ratio, then H, M, P, L (each: int64 count, doubles)
 #include <cstdint>
@@ -10,7 +10,7 @@
 #include "spec_tables.h"
 
 int main(int argc, char **argv) {
-    if (argc != 3) return 2;
+    if (argc != 3 && argc != 4) return 2;
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 2;
     int32_t hdr[3];
@@ -19,6 +19,21 @@ int main(int argc, char **argv) {
     if (fread(taps.data(), sizeof(double), taps.size(), f) != taps.size()) return 2;
     if (fread(sos.data(), sizeof(double), sos.size(), f) != sos.size()) return 2;
     fclose(f);
+    if (argc == 4) {
+        const osz::spec::TablesZp T = osz::spec::build_zp(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0);
+        f = fopen(argv[2], "wb");
+        if (!f) return 2;
+        const int32_t out[6] = {T.eligible, T.NR, T.NM, T.nm, T.R, T.nh};
+        fwrite(out, sizeof(int32_t), 6, f);
+        fwrite(&T.fit_ratio, sizeof(double), 1, f);
+        for (const std::vector<double> *v : {&T.H, &T.M, &T.P, &T.L}) {
+            const int64_t n = (int64_t)v->size();
+            fwrite(&n, sizeof(int64_t), 1, f);
+            fwrite(v->data(), sizeof(double), v->size(), f);
+        }
+        fclose(f);
+        return 0;
+    }
     const osz::spec::Tables T = osz::spec::build(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0);
     f = fopen(argv[2], "wb");
     if (!f) return 2;

@@ -199,3 +199,196 @@ def test_what_the_scheme_does_not_take(exe):
     assert not tables(exe, sps.firwin(1900, 0.2), bp)["eligible"]
     assert not tables(exe, sps.firwin(1024, 0.2), bp, forgets=False)["eligible"]
     assert not tables(exe, sps.firwin(64, 0.2), sps.butter(14, 0.3, output="sos"))["eligible"]   # 7 modes
+
+
+# ------------------------------------------------------------------ the two-sided scheme
+def tables_zp(exe, taps, sos, forgets=True):
+    taps, sos = np.asarray(taps, np.float64), np.atleast_2d(np.asarray(sos, np.float64))
+    with tempfile.TemporaryDirectory() as tmp:
+        fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<iii", len(taps), len(sos), int(forgets)))
+            f.write(taps.tobytes())
+            f.write(sos.tobytes())
+        subprocess.check_call([exe, fin, fout, "zp"])
+        raw = open(fout, "rb").read()
+    elig, NR, NM, nm, R, nh = struct.unpack_from("<iiiiii", raw, 0)
+    ratio, = struct.unpack_from("<d", raw, 24)
+    pos, arrs = 32, []
+    for _ in range(4):
+        n, = struct.unpack_from("<q", raw, pos)
+        arrs.append(np.frombuffer(raw, np.float64, n, pos + 8).copy())
+        pos += 8 + 8 * n
+    return dict(eligible=bool(elig), NR=NR, NM=NM, nm=nm, R=R, nh=nh, ratio=ratio, H=arrs[0], M=arrs[1],
+                P=arrs[2], L=arrs[3])
+
+
+class ModelZp:
+    """The dataflow of chain_zp_kernel on one channel with the tables of the C++ build:
+    whole pairs (overlap add, four forward and four backward bursts, the last R rows of
+    block b held back until the next pair's block a has been fitted), runs with a pre-roll
+    and a post-roll pair, the opening pair (carry, held samples of the previous chunk), the
+    generic closing pair, outputs delayed by L = 256 R samples."""
+
+    def __init__(self, T):
+        self.NR, self.NM, self.R, self.nh = T["NR"], T["NM"], T["R"], T["nh"]
+        self.S, self.D, self.L = 256 * self.NR, 16 - self.NR, 256 * T["R"]
+        H = T["H"].reshape(N, 2)
+        self.Hc = (H[:, 0] + 1j * H[:, 1]) * N
+        M = T["M"].reshape(4 * self.NM, 2 * self.nh)
+        self.Mmu = M[:self.NM] + 1j * M[self.NM:2 * self.NM]
+        self.Mnu = M[2 * self.NM:3 * self.NM] + 1j * M[3 * self.NM:]
+        P = T["P"].reshape(20, self.NM, 2)
+        P = P[..., 0] + 1j * P[..., 1]
+        t = np.arange(256)
+        self.P = P[t >> 5] * P[8 + ((t >> 2) & 7)] * P[16 + (t & 3)]     # lambda^t as the kernel forms it
+        Lr = T["L"].reshape(5, self.NM, 2)
+        self.Lr = Lr[..., 0] + 1j * Lr[..., 1]
+        self.lsel = np.concatenate([np.arange(self.nh), np.arange(256 - self.nh, 256)])
+
+    def window(self, x):
+        buf = np.zeros(N)
+        buf[:len(x)] = x
+        return np.real(np.fft.ifft(np.fft.fft(buf) * self.Hc))
+
+    def fit(self, win):
+        y = win[3840 + self.lsel]
+        return self.Mmu @ y, self.Mnu @ y
+
+    def burst(self, amp, e):
+        ok = (e >= 0) & (e < 256 * self.R)
+        ee = np.where(ok, e, 0)
+        return np.where(ok, np.real((self.Lr[ee >> 8] * self.P[ee & 255]) @ amp), 0.0)
+
+    def chunk(self, x, carry_in, held_in, nruns):
+        n, S, NR, D, R, L = len(x), self.S, self.NR, self.D, self.R, self.L
+        pair = 2 * S
+        npw = n // pair
+        rem = n - npw * pair
+        W = npw - 1 if rem == 0 else npw
+        assert W >= 1
+        lc = n - W * pair
+        y, held_out = np.full(n, np.nan), np.full(L, np.nan)
+        t = np.arange(256)
+
+        def put(i, v):
+            q = i + L
+            m = q < n
+            y[q[m]] = v[m]
+            m2 = (~m) & (i < n)
+            held_out[q[m2] - n] = v[m2]
+
+        F = lambda amp, r: self.burst(amp, 256 * r + t)             # forward burst, row r
+        Bk = lambda amp, r: self.burst(amp, 256 * r + 255 - t)      # backward burst, r-th row down
+        nruns = max(1, min(nruns, W))
+        carry_out = None
+        for run in range(nruns):
+            p0, p1 = run * W // nruns, (run + 1) * W // nruns
+            first = p0 if run == 0 else p0 - 1
+            lastf = p1 if run < nruns - 1 else p1 - 1
+            cr = np.zeros((D, 256))
+            mu_pb = nu_pb = np.zeros(self.NM, complex)
+            held = None
+            for p in range(first, lastf + 1):
+                o = p * pair
+                wa, wb = self.window(x[o:o + S]), self.window(x[o + S:o + pair])
+                (mu_a, nu_a), (mu_b, nu_b) = self.fit(wa), self.fit(wb)
+                Ya, Yb = wa.reshape(16, 256), wb.reshape(16, 256)
+                A, B = Ya[:NR].copy(), Yb[:NR].copy()
+                A[:D] += cr
+                B[:D] += Ya[NR:]
+                cr = Yb[NR:].copy()
+                for r in range(R):
+                    A[r] += F(-mu_a, r)
+                    A[D + r] += F(mu_pb, r)
+                    A[D - 1 - r] += Bk(-nu_pb, r)
+                    A[NR - 1 - r] += Bk(nu_b, r)
+                    B[r] += F(-mu_b, r)
+                    B[D + r] += F(mu_a, r)
+                    B[D - 1 - r] += Bk(-nu_a, r)
+                if p == 0:
+                    ci = np.zeros(pair)
+                    ci[:len(carry_in)] = carry_in[:pair]
+                    A += ci[:S].reshape(NR, 256)
+                    B += ci[S:].reshape(NR, 256)
+                if held is not None:
+                    for r in range(R):
+                        held[r] += Bk(nu_a, r)
+                        if p0 <= p - 1 < p1:
+                            put((p - 1) * pair + S + 256 * (NR - 1 - r) + t, held[r])
+                elif p == 0:
+                    for rr in range(R):
+                        y[256 * rr + t] = held_in[256 * rr + t] + Bk(nu_a, R - 1 - rr)
+                if p0 <= p < p1:
+                    for j in range(NR):
+                        put(o + 256 * j + t, A[j])
+                    for j in range(NR - R):
+                        put(o + S + 256 * j + t, B[j])
+                held = [B[NR - 1 - r].copy() for r in range(R)]
+                mu_pb, nu_pb = mu_b, nu_b
+            if run == nruns - 1:
+                o = W * pair
+                la = min(lc, S)
+                lb = lc - la
+                wa, wb = self.window(x[o:o + la]), self.window(x[o + la:o + la + lb])
+                (mu_a, nu_a), (mu_b, nu_b) = self.fit(wa), self.fit(wb)
+                for r in range(R):
+                    held[r] += Bk(nu_a, r)
+                    put((W - 1) * pair + S + 256 * (NR - 1 - r) + t, held[r])
+                acc, i = np.zeros(8192), np.arange(8192)
+                acc[:256 * D] += cr.ravel()
+                acc[:N] += wa
+                acc[la:la + N] += wb
+                for amp, off in ((mu_pb, 256 * D), (-mu_a, 0), (-mu_b, la), (mu_a, N), (mu_b, la + N)):
+                    acc += self.burst(amp, i - off)
+                for amp, e0 in ((-nu_pb, 256 * D - 1), (-nu_a, N - 1), (-nu_b, la + N - 1), (nu_b, la - 1)):
+                    acc += self.burst(amp, e0 - i)
+                put(o + i[:lc], acc[:lc])
+                carry_out = np.zeros(7680)
+                seg = acc[lc:]
+                carry_out[:min(len(seg), 7680)] = seg[:7680]
+        return y, carry_out, held_out
+
+
+ZP_CASES = [
+    ("butter6 band-pass, 1024 taps (cfg-3)", 1024, sps.butter(6, [0.05, 0.3], "bandpass", output="sos")),
+    ("butter6 band-pass, 300 taps", 300, sps.butter(6, [0.05, 0.3], "bandpass", output="sos")),
+    ("cheby1 band-pass, 777 taps", 777, sps.cheby1(3, 1, [0.16, 0.48], "bandpass", output="sos")),
+    ("butter5 low-pass (a real pole), 513 taps", 513, sps.butter(5, 0.3, output="sos")),
+]
+
+
+@pytest.mark.parametrize("name,ntaps,sos", ZP_CASES, ids=[c[0] for c in ZP_CASES])
+def test_zero_phase_tables_and_block_algorithm(exe, name, ntaps, sos):
+    """FIR -> forward cascade -> backward cascade as one multiplication per bin: the C++
+    tables drive the NumPy restatement of chain_zp_kernel against scipy (forward pass from
+    sosfilt_zi * u[0], backward pass over the whole stream), every kind of chunk."""
+    taps = sps.firwin(ntaps, 0.2)
+    T = tables_zp(exe, taps, sos)
+    assert T["eligible"], name
+    NR, R = T["NR"], T["R"]
+    assert 8 <= NR <= min((3841 - ntaps) // 256, 15) and 1 <= R <= min(16 - NR, 2 * NR - 16, 5)
+    w, h = sps.sosfreqz(sos, worN=N, whole=True)
+    Hc = np.fft.fft(taps, N) * np.abs(h) ** 2 / N
+    H = T["H"].reshape(N, 2)
+    assert np.max(np.abs(H[:, 0] + 1j * H[:, 1] - Hc)) < 1e-15 * np.max(np.abs(Hc)) * 50
+    m = ModelZp(T)
+    S, L = m.S, m.L
+    rng = np.random.default_rng(ntaps)
+    lens = [2 * S * 5 + 1024, 2 * S * 4, 2 * S * 3 + S + 17, 2 * S + 5, 2 * S * 3 + 2 * S - 1, 2 * S * 3 + 300]
+    x = rng.standard_normal(sum(lens))
+    u = np.convolve(x, taps)
+    zi0 = sps.sosfilt_zi(sos) * u[0]
+    f, _ = sps.sosfilt(sos, u, zi=zi0)
+    ref = sps.sosfilt(sos, np.concatenate([f, np.zeros(8192)])[::-1])[::-1][:len(f)]
+    # the stream opens: what the forward start state rings, filtered backwards as well
+    zir = sps.sosfilt(sos, np.zeros(7680), zi=zi0)[0]
+    carry, held = sps.sosfilt(sos, zir[::-1])[::-1], np.zeros(L)
+    out, o = [], 0
+    for k, n in enumerate(lens):
+        y, carry, held = m.chunk(x[o:o + n], carry, held, nruns=[1, 2, 3, 1, 2, 2][k])
+        out.append(y)
+        o += n
+    got = np.concatenate(out)                     # got[q] is stream sample q - L
+    assert np.isfinite(got).all()
+    assert np.max(np.abs(got[L:] - ref[:len(got) - L])) < 1e-12 * np.max(np.abs(ref)), name
