@@ -61,7 +61,7 @@ RAGGED = 100_000_000 - 95 * CHUNK     # last chunk of the literal 1e8-sample str
 # and the backward pass of an earlier chunk side by side on two streams, one osz_chain_step:
 # the whole 48 B of the chain.  What these launches really move is roofline.traffic.)
 KERNEL_BYTES = {"fir_oa": 16, "sos_dual": 32, "sos_fwd": 16, "sos_bwd": 16, "sos_fwd_split": 16,
-                "sos_bwd_split": 16, "chain_fwd": 32, "chain_step": 48, "sos_warmup": 0,
+                "sos_bwd_split": 16, "chain_fwd": 32, "chain_step": 48, "chain_zp": 48, "sos_warmup": 0,
                 "fir_seam": 0, "spec_fused": 8, "poly_block": 9.6}
 CHAIN_BYTES = 48         # FIR 16 + sosfiltfilt 32 (the unfused accounting of the metric)
 METRIC = "Msamples/sec/node (FIR+IIR chain, 256ch f64); HBM GB/s vs roofline at 1/2/4/8 GPU"
@@ -259,7 +259,8 @@ def roofline_of(kernels, samples_per_step):
     # one osz_chain_step is the unit when the step ran: its members (fused kernel on
     # the caller's stream, backward pass on the handle's) overlap inside it, and a
     # member's own bracket may include its wait for the other
-    dom = "chain_step" if "chain_step" in kernels else max(kernels, key=lambda nm: kernels[nm]["total_ms"])
+    dom = ("chain_zp" if "chain_zp" in kernels else "chain_step" if "chain_step" in kernels
+           else max(kernels, key=lambda nm: kernels[nm]["total_ms"]))
     # PMC counters cannot be read from inside a timed run: the bytes come from the
     # committed rocprofv3 --pmc passes, and only while the kernel sources are the ones
     # those passes ran (fingerprint written by benchmarks/summarise_profiles.py)
@@ -270,6 +271,12 @@ def roofline_of(kernels, samples_per_step):
            "traffic": traffic, "traffic_source": traffic_note,
            "algorithmic_bytes_per_launch": KERNEL_BYTES[dom] * samples_per_step,
            "avg_launch_ms": kernels[dom]["avg_ms"]}
+    if traffic:
+        # what the launch really moves against the peak, beside the algorithmic `frac`
+        out["frac_physical"] = traffic / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    if dom == "chain_zp":
+        out["kernel"] = ("chain_zp (FIR, forward and backward cascade as one spectrum multiply: the chain's 48 "
+                         "algorithmic B per sample, 16 of them moved)")
     if dom == "chain_step":
         # two kernels side by side under one call: the duration is that of the pair
         # (HIP events on the caller's stream around osz_chain_step), the bytes are the
@@ -295,10 +302,14 @@ def run_chain(args, R, h, sos):
     from openseize_amd import _device as dev
     from openseize_amd import _lib
     lib = _lib.load()
-    C = C_PER_GPU
-    ring = [dev.synth_normal(C, CHUNK, seed=0, ch0=R.rank * C, n0=k * CHUNK) for k in range(3)]
+    C, ch0 = chain_channels(args, R)
+    ring = [dev.synth_normal(C, CHUNK, seed=0, ch0=ch0, n0=k * CHUNK) for k in range(3)]
     fir = dev.FirStream(h, C)
     iir = dev.SosStream(sos, C)
+    zp = not (args.unfused or args.fused or args.two_kernel)
+    lag = dev.chain_zp_lag(fir, iir) if zp else -1
+    if zp and lag < 0:
+        raise RuntimeError("the zero-phase chain kernel refused the benchmark's filters")
     # resident buffers with defined contents (zero-filled, so every page of the ring
     # has been written once before the first step reads or overwrites it)
     fir_out = torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda")
@@ -307,6 +318,17 @@ def run_chain(args, R, h, sos):
     y_out = torch.zeros_like(fir_out)
 
     def step(k):
+        if zp:
+            # default: ONE kernel per chunk, osz_chain_zp_step = FIR, forward and backward
+            # cascade of input chunk k as one multiplication per bin; its outputs (the stream
+            # runs `lag` samples late) are the tail of output chunk k-1 and the head of chunk
+            # k; output chunk k-2 is sealed (NaN reach of sosfiltfilt) and the caller's
+            yb = fwd[k % nf]
+            dev.chain_zp_step(fir, iir, ring[k % len(ring)], out=yb[:, :CHUNK - lag],
+                              tail=fwd[(k - 1) % nf][:, CHUNK - lag:])
+            if k >= 2:
+                dev.chain_zp_seal(fir, iir, fwd[(k - 2) % nf], (k - 2) * CHUNK, 0, CHUNK)
+            return
         if args.unfused:
             # chunk k: FIR, then ONE launch = forward(chunk k) + backward(chunk
             # k-2, warmed up over forward chunk k-1)  [osz_sosfiltfilt_step]
@@ -324,7 +346,7 @@ def run_chain(args, R, h, sos):
             if args.fused and k >= 2:
                 iir.backward(fwd[(k - 2) % nf], fwd[(k - 1) % nf], out=y_out)
             return
-        # default: ONE call, osz_chain_step = the fused forward half of chunk k on this
+        # --two-kernel: ONE call, osz_chain_step = the fused forward half of chunk k on this
         # stream and, beside it on the handle's own stream, the backward pass of chunk
         # k-2 (warmed up over forward chunk k-1); OSZ_CHAIN_DEFER + four forward buffers:
         # the pass may finish under the next step's forward kernel, y is taken one step late
@@ -333,6 +355,8 @@ def run_chain(args, R, h, sos):
 
     # start of the stream: steady-state init as sosfiltfilt does, then warm up
     iir.set_state_scaled(ring[0], 0)
+    if zp:
+        dev.chain_zp_open(fir, iir, 0)
     k = 0
     for _ in range(max(args.warmup, 2)):
         step(k)
@@ -352,9 +376,9 @@ def run_chain(args, R, h, sos):
     R.barrier()
     # order-independent checksum of the last output chunk (also the 8 B/lane
     # streaming read of known size that calibrates FETCH_SIZE in the PMC runs)
-    bits, fsum = dev.checksum(y_out)
+    bits, fsum = dev.checksum(fwd[(k - 3) % nf] if zp else y_out)
     kernels = kernel_table(lib, C * CHUNK)
-    if not args.unfused:
+    if not args.unfused and not zp:
         # beside the fused kernel and the backward pass, a step has the head of the chunk
         # (the 4096 of 2^20 samples that are not whole block pairs) on the plain kernels,
         # plus, with --fused, small warm-up launches: durations only, a rate per full
@@ -364,12 +388,25 @@ def run_chain(args, R, h, sos):
                 rec["achieved_gbps"] = None
                 rec["note"] = "small launch: head of the chunk / warm-up"
     extra = {"output_checksum": {"bits": f"{bits:#018x}", "sum": fsum}}
+    if zp:
+        extra["output_lag_samples"] = lag
     if args.full_stream:
         del fwd, y_out, fir_out
         fir.close()
         iir.close()
         extra["full_stream"] = full_stream_leg(R, ring, h, sos)
     return elapsed, kernels, roofline_of(kernels, C * CHUNK), extra
+
+
+def chain_channels(args, R):
+    """(channels of this rank, first channel).  weak: 256 per rank (BASELINE cfg-3's shard);
+    strong: the metric's 256 channels split channel_block-wise over the ranks (cfg-4's 32 per
+    GPU at 8 ranks)."""
+    if args.scaling == "strong":
+        from openseize_amd import sharding
+        lo, hi = sharding.channel_block(C_PER_GPU, R.rank, R.world)
+        return hi - lo, lo
+    return C_PER_GPU, R.rank * C_PER_GPU
 
 
 def full_stream_leg(R, ring, h, sos):
@@ -648,10 +685,16 @@ def main():
                     help="welch: all-reduce through torch.distributed (RCCL) or through "
                          "osz_welch_reduce of the C ABI")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="chain: weak = 256 channels per rank; strong = the metric's 256 channels "
+                         "split over the ranks (32 per GPU at 8 ranks)")
+    ap.add_argument("--two-kernel", action="store_true",
+                    help="chain: osz_chain_step, the fused FIR + forward SOS kernel with the backward "
+                         "pass of chunk k-2 beside it on a second stream (the round-2 step; the "
+                         "default is the single zero-phase kernel, osz_chain_zp_step)")
     ap.add_argument("--fused", action="store_true",
                     help="chain: FIR + forward SOS as one kernel (osz_chain_forward), then the "
-                         "backward pass, on ONE stream (the default runs them side by side: "
-                         "osz_chain_step)")
+                         "backward pass, on ONE stream")
     ap.add_argument("--ordered", action="store_true",
                     help="chain: osz_chain_step without OSZ_CHAIN_DEFER (every step stream-ordered)")
     ap.add_argument("--unfused", action="store_true",
@@ -700,19 +743,29 @@ def main():
         how = ("three launches per chunk: fir_oa, fir_seam, sos_dual" if args.unfused else
                "osz_chain_forward then the backward pass, one stream" if args.fused else
                "one osz_chain_step per chunk: fused FIR + forward SOS kernel with the backward "
-               "pass of chunk k-2 beside it on a second stream")
+               "pass of chunk k-2 beside it on a second stream" if args.two_kernel else
+               "one osz_chain_zp_step per chunk: FIR, forward and backward cascade as ONE spectrum "
+               "multiply in the FIR's transform (+ osz_chain_zp_seal of the finished output chunk)")
         bytes_per_sample, label = CHAIN_BYTES, (
             "cfg-3: 256 ch/GPU x 2^20-sample chunks, FIR overlap-add 1024 taps -> 6-section "
             "Butterworth band-pass sosfiltfilt, steady-state stream; " + how)
         parallelism = f"channel-shard x{R.world}"
     ch_per_gpu = {"stft": STFT_CH, "fir": FIR_CH}.get(args.workload, C_PER_GPU)
-    samples_per_step = ch_per_gpu * CHUNK
-    value = samples_per_step * args.steps * R.world / elapsed / 1e6
+    strong = args.workload == "chain" and args.scaling == "strong"
+    if strong:
+        # the job is the metric's 256 channels whatever the rank count
+        samples_per_step = C_PER_GPU * CHUNK
+        value = samples_per_step * args.steps / elapsed / 1e6
+        ch_per_gpu = C_PER_GPU / R.world
+        parallelism = f"256 channels split over {R.world} ranks (channel_block)"
+    else:
+        samples_per_step = ch_per_gpu * CHUNK
+        value = samples_per_step * args.steps * R.world / elapsed / 1e6
     out = {
         "metric": metric, "value": value, "unit": "Msamples/s", "n_gpus": R.world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": label,
                    "channels_per_gpu": ch_per_gpu, "chunksize": CHUNK,

@@ -235,9 +235,12 @@ int osz_chain_wait(osz_sos_t sos, void *stream);
  *                           handle (osz_sos_set_state*) at stream sample `skip` -- the
  *                           FIR's left cut, which the cascade never sees -- and that state
  *                           is consumed
- *   osz_chain_zp_step       the next n input samples; y[0, n) = output samples
+ *   osz_chain_zp_step       the next n input samples; the n output samples
  *                           [pos - lag, pos + n - lag) of the stream (pos: samples stepped
- *                           before; the first lag outputs of a stream mean nothing)
+ *                           before; the first lag outputs of a stream mean nothing) go to
+ *                           y0[0, n0) and y[0, n - n0): a caller that cuts the output into
+ *                           chunks of its own passes the tail of the previous chunk and
+ *                           the head of the current one (n0 = 0: everything to y)
  *   osz_chain_zp_seal       NaN reach of sosfiltfilt: y holds output samples [s0, s0 + n)
  *                           of a stream cut into chunks of cs samples from `origin` on; a
  *                           chunk is NaN as a whole when the forward stream went bad in it
@@ -248,13 +251,15 @@ int osz_chain_wait(osz_sos_t sos, void *stream);
  *                           osz_chain_forward continue the forward stream from there --
  *                           and y[0, ny) receives the next ny output samples, for which
  *                           the first m samples of what follows are read (m >= min_chunk,
- *                           ny <= m - lag - the FIR's length)
+ *                           ny <= m - min_chunk / 2: the last pair of blocks of those m
+ *                           samples is not what the continued stream would have there)
  */
 int64_t osz_chain_zp_lag(osz_fir_t fir, osz_sos_t sos);
 int64_t osz_chain_zp_min_chunk(osz_fir_t fir, osz_sos_t sos);
 int osz_chain_zp_open(osz_fir_t fir, osz_sos_t sos, int64_t skip, void *stream);
 int osz_chain_zp_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,
-                      int64_t n, double *y, int64_t ldy, void *stream);
+                      int64_t n, double *y0, int64_t ldy0, int64_t n0, double *y,
+                      int64_t ldy, void *stream);
 int osz_chain_zp_seal(osz_fir_t fir, osz_sos_t sos, double *y, int64_t ldy, int64_t n,
                       int64_t s0, int64_t origin, int64_t cs, void *stream);
 int osz_chain_zp_finish(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,

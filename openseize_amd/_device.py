@@ -632,6 +632,10 @@ class FirStream(_Handle):
             skip, stream_ptr()))
         return y
 
+    def reset(self):
+        """Forget the carried overlap tail (C ABI: osz_fir_reset)."""
+        _lib.check(self.lib.osz_fir_reset(self.h, stream_ptr()))
+
     def flush(self, device, skip=0, drop=0, out=None):
         cnt = self.ntaps - 1 - skip - drop
         y = out if out is not None else torch.empty(
@@ -695,13 +699,16 @@ def chain_zp_open(fir, sos, skip=0):
     _lib.check(fir.lib.osz_chain_zp_open(fir.h, sos.h, int(skip), stream_ptr()))
 
 
-def chain_zp_step(fir, sos, x2d, out=None):
-    """FIR -> sosfiltfilt of the next chunk in ONE kernel (C ABI: osz_chain_zp_step):
-    ``out[:, q]`` is output sample ``pos - lag + q`` of the stream."""
+def chain_zp_step(fir, sos, x2d, out=None, tail=None):
+    """FIR -> sosfiltfilt of the next chunk in ONE kernel (C ABI: osz_chain_zp_step).  The
+    chunk's n output samples -- stream samples ``pos - lag`` onwards -- go to ``tail`` (its
+    width of them: the end of the caller's previous output chunk) and then to ``out``."""
     n = x2d.shape[1]
-    y = out if out is not None else torch.empty((fir.nch, n), dtype=torch.float64, device=x2d.device)
-    _lib.check(fir.lib.osz_chain_zp_step(fir.h, sos.h, ptr(x2d), x2d.stride(0), n, ptr(y),
-                                         max(y.stride(0), 1), stream_ptr()))
+    n0 = 0 if tail is None else tail.shape[1]
+    y = out if out is not None else torch.empty((fir.nch, n - n0), dtype=torch.float64, device=x2d.device)
+    _lib.check(fir.lib.osz_chain_zp_step(
+        fir.h, sos.h, ptr(x2d), x2d.stride(0), n, ptr(tail) if n0 else None, tail.stride(0) if n0 else 0, n0,
+        ptr(y) if n > n0 else None, max(y.stride(0), 1), stream_ptr()))
     return y
 
 

@@ -83,7 +83,7 @@ SIGNATURES = {
     "osz_chain_zp_lag": (c_i64, [c_vp, c_vp]),
     "osz_chain_zp_min_chunk": (c_i64, [c_vp, c_vp]),
     "osz_chain_zp_open": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
-    "osz_chain_zp_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    "osz_chain_zp_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "osz_chain_zp_seal": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp]),
     "osz_chain_zp_finish": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "osz_sos_warm_len": (c_i64, [c_vp]),

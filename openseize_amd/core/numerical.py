@@ -15,6 +15,7 @@ CUDA tensors stay in HBM.
 """
 
 import math
+import os
 from functools import partial
 
 from collections import deque
@@ -330,6 +331,12 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
             device = first.device if resident else "cuda"
             pipe = None if resident else dev.HostPipe(layout)
             flying = deque()
+            lag = dev.chain_zp_lag(fir, iir)
+            if (lag >= 0 and nchunks >= 6 and os.environ.get("OSZ_CHAIN_ZP", "1") != "0"
+                    and cs >= max(4 * (lcut + lag), warm + lcut + lag, 2 * dev.chain_zp_min_chunk(fir, iir))):
+                yield from _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, total,
+                                              lcut, rcut, lag, device)
+                return
 
             def feed(arr):
                 return layout.to2d(arr)[0] if pipe is None else pipe.feed(arr)
@@ -435,6 +442,118 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
         gen.close()
         return None
     return gen
+
+
+def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, total, lcut, rcut, lag, device):
+    """The body of ``_sosfiltfilt_after_fir`` on the zero-phase kernel (C ABI: osz_chain_zp_*,
+    csrc/chain_zp.hip): FIR, forward and backward cascade of an input chunk in ONE launch.
+
+    The reference's backward pass of chunk i starts from what back-filtering forward chunk
+    i + 1 leaves (core/numerical.py:397-403); for chunks much longer than the cascade's
+    memory -- the caller has checked chunksize against ``warm_len`` -- that is, to 1e-18,
+    what back-filtering the whole rest of the stream leaves, i.e. the zero-phase filter
+    |H_iir|^2 on the FIR output.  Only the two ends of the stream differ:
+      * the start: the cascade's forward pass begins at FIR output sample ``lcut`` from
+        ``sosfilt_zi * u[lcut]`` (:374-386); what the ``lcut`` samples before -- which it
+        never sees -- would have left in its state is taken off that start state;
+      * the end: the last two output chunks come from the separate kernels (forward stream
+        from the states ``osz_chain_zp_finish`` leaves, then the chunk-local backward
+        passes with the reference's own start states, :397-411).
+    The kernel's output runs ``lag`` samples late, 'same' drops ``lcut`` more: input chunk
+    k delivers output samples [k cs - shift, (k + 1) cs - shift), i.e. the tail of output
+    chunk k - 1 and the head of chunk k, which is where the kernel writes them.  Output
+    chunk j is handed on two steps later, after ``osz_chain_zp_seal`` (NaN reach: a NaN in
+    the forward stream of chunk j + 1 makes chunk j NaN as a whole)."""
+    import torch
+    C = layout.nch
+    wlen = len(taps)
+    nchunks = -(-total // cs)
+    shift = lcut + lag
+
+    def feed(arr):
+        return layout.to2d(arr)[0] if pipe is None else pipe.feed(arr)
+
+    def emit(y):
+        if pipe is None or dev.emit_resident():
+            yield layout.from2d(y, False)
+            return
+        flying.append(pipe.download(y))
+        while len(flying) > 2:
+            out, done = flying.popleft()
+            done.synchronize()
+            yield pipe.restore(out)
+
+    def fresh(j):
+        return torch.empty((C, min(cs, total - j * cs)), dtype=torch.float64, device=device)
+
+    # ---- the start state of the forward cascade
+    x0 = feed(first)
+    u = fir.push(x0[:, :lcut + 1].contiguous(), 0)            # FIR output samples 0 .. lcut
+    seen = 0.0
+    if lcut > 0:
+        iir.set_state(None)
+        iir.forward(u[:, :lcut].contiguous())
+        seen = iir.get_state()
+    iir.set_state_scaled(u, lcut)
+    iir.set_state(iir.get_state() - seen)
+    fir.reset()
+    dev.chain_zp_open(fir, iir, lcut)
+    junk = torch.empty((C, shift), dtype=torch.float64, device=device)     # outputs before sample 0
+    ys = {0: fresh(0)}
+    dev.chain_zp_step(fir, iir, x0, out=ys[0][:, :cs - shift], tail=junk)
+    k, x2d = 1, None
+    for arr in chunks:
+        if arr.shape[layout.axis] == 0:
+            continue
+        x2d = feed(arr)
+        if k * cs >= total or x2d.shape[1] != min(cs, total - k * cs):
+            raise RuntimeError("sosfiltfilt after oaconvolve: an inner chunk of the source "
+                               f"is not chunksize = {cs} long")
+        if k == nchunks - 2:
+            break
+        ys[k] = fresh(k)
+        dev.chain_zp_step(fir, iir, x2d, out=ys[k][:, :cs - shift], tail=ys[k - 1][:, cs - shift:])
+        if k >= 2:
+            j = k - 2
+            dev.chain_zp_seal(fir, iir, ys[j], lcut + j * cs, lcut, cs)
+            yield from emit(ys.pop(j))
+        k += 1
+    if k != nchunks - 2 or x2d is None:
+        raise RuntimeError(f"sosfiltfilt after oaconvolve: the source ended after {k} of {nchunks} chunks")
+    # ---- the end: chunks n-2 and n-1 on the separate kernels.  The rest of output chunk
+    # n-3 needs the head of input chunk n-2; the handles' own states are those at its start.
+    m = shift + dev.chain_zp_min_chunk(fir, iir)
+    dev.chain_zp_finish(fir, iir, x2d[:, :m], out=ys[k - 1][:, cs - shift:])
+    off = lcut & 1                                            # chunk views on even columns
+    n_last = total - (nchunks - 1) * cs
+    F = torch.empty((C, off + lcut + cs + n_last + 2), dtype=torch.float64, device=device)
+    dev.chain_forward(fir, iir, x2d, out=F[:, off:off + cs])
+    last = next(chunks, None)
+    while last is not None and last.shape[layout.axis] == 0:
+        last = next(chunks, None)
+    if last is None:
+        raise RuntimeError("sosfiltfilt after oaconvolve: the source ended before its last chunk")
+    xl = feed(last)
+    if xl.shape[1] != n_last:
+        raise RuntimeError(f"sosfiltfilt after oaconvolve: the last chunk has {xl.shape[1]} of {n_last} samples")
+    dev.chain_forward(fir, iir, xl, out=F[:, off + cs:off + cs + n_last])
+    cnt = max(wlen - 1 - rcut, 0)
+    if cnt > 0:
+        F[:, off + cs + n_last:off + cs + n_last + cnt].copy_(iir.forward(fir.flush(device, skip=0, drop=rcut)))
+    fa = F[:, off + lcut:off + lcut + cs]
+    fb = F[:, off + lcut + cs:off + lcut + cs + n_last]
+    # NaN reach across the seam: the zero-phase steps have seen chunk n-2 only up to its head
+    for j in (nchunks - 4, nchunks - 3):
+        dev.chain_zp_seal(fir, iir, ys[j], lcut + j * cs, lcut, cs)
+    ys[nchunks - 3].masked_fill_(~torch.isfinite(fa[:, -1:]), float("nan"))
+    yield from emit(ys.pop(nchunks - 4))
+    yield from emit(ys.pop(nchunks - 3))
+    yield from emit(iir.backward(fa, fb))
+    yield from emit(iir.backward(fb, None))
+    while flying:
+        out, done = flying.popleft()
+        done.synchronize()
+        yield pipe.restore(out)
 
 
 @dev.chain_aware

@@ -43,7 +43,9 @@
 namespace osz {
 
 struct ZpArgs {
-    FirArgs f;                 // x, ldx, y, ldy, wlen, step, H (zero-phase composite), tb
+    FirArgs f;                 // x, ldx, wlen, step, H (zero-phase composite), tb; y / ldy: outputs n0 .. n
+    double *y0;                // outputs 0 .. n0 (the tail of the caller's previous output chunk), or null
+    int64_t ldy0, n0;
     int64_t n;                 // samples of this chunk
     int64_t W;                 // whole pairs on the fast path
     int nruns;
@@ -103,9 +105,11 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
     const int L = 256 * R;
     const double *xr = a.x + (int64_t)c * a.ldx;
-    double *yr = a.y + (int64_t)c * a.ldy;
+    // output q of this chunk: q < n0 -> y0r[q], else yr[q] (yr: the second buffer, shifted by n0)
+    const int64_t n = g.n, n0 = g.n0;
+    double *y0r = g.y0 ? g.y0 + (int64_t)c * g.ldy0 : nullptr;
+    double *yr = a.y + (int64_t)c * a.ldy - n0;
     double *ho = g.held_out + (int64_t)c * L;
-    const int64_t n = g.n;
     const int64_t p0 = ((int64_t)run * g.W) / g.nruns;
     const int64_t p1 = ((int64_t)(run + 1) * g.W) / g.nruns;
     const int64_t first = run == 0 ? 0 : p0 - 1;
@@ -133,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
 #define OSZ_ZP_PUT(i_, v_)                      \
     do {                                        \
         const int64_t q_ = (i_) + L;            \
-        if (q_ < n) yr[q_] = (v_);              \
+        if (q_ < n0) y0r[q_] = (v_);            \
+        else if (q_ < n) yr[q_] = (v_);         \
         else ho[q_ - n] = (v_);                 \
     } while (0)
 
@@ -257,20 +262,29 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             const double *hi = g.held_in + (int64_t)c * L + tt;
 #pragma unroll
             for (int r = 0; r < kSpecRMax; ++r)
-                if (r < R) yr[256 * (R - 1 - r) + tt] = bad ? qn : hi[256 * (R - 1 - r)] + c7[r];
+                if (r < R) {
+                    const int64_t q = 256 * (R - 1 - r) + tt;
+                    (q < n0 ? y0r : yr)[q] = bad ? qn : hi[256 * (R - 1 - r)] + c7[r];
+                }
         } else if (p > first) {
             // the previous pair's last R rows of block b, complete now
             if (p - 1 >= p0 && p - 1 < p1) {
                 const int64_t ob = o - S + tt;
+                if (o - S + L >= n0) {
 #pragma unroll
-                for (int r = 0; r < kSpecRMax; ++r)
-                    if (r < R) yr[ob + 256 * (NR - 1 - r) + L] = bad ? qn : held[r] + c7[r];
+                    for (int r = 0; r < kSpecRMax; ++r)
+                        if (r < R) yr[ob + 256 * (NR - 1 - r) + L] = bad ? qn : held[r] + c7[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < kSpecRMax; ++r)
+                        if (r < R) OSZ_ZP_PUT(ob + 256 * (NR - 1 - r), bad ? qn : held[r] + c7[r]);
+                }
             }
         }
         if (own) {
             int64_t off = o + tt;
             asm volatile("" : "+v"(off));
-            if (!edge) {
+            if (!edge && o + L >= n0) {
                 double *q = yr + off + L;
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
@@ -439,13 +453,14 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             for (int s = nr_ - 2; s >= 0; --s) {
                 const int64_t e = (((int64_t)(s + 1) * Wp) / nr_) * pairlen + L;
                 const unsigned long long bits = __hip_atomic_load(
-                    reinterpret_cast<const unsigned long long *>(yr + e - 1), __ATOMIC_RELAXED,
+                    reinterpret_cast<const unsigned long long *>((e - 1 < n0 ? y0r : yr) + e - 1), __ATOMIC_RELAXED,
                     __HIP_MEMORY_SCOPE_AGENT);
                 if (sos_not_finite(__longlong_as_double((long long)bits))) badrun = s;
             }
             if (badrun < nr_) {
                 const int64_t from = (((int64_t)(badrun + 1) * Wp) / nr_) * pairlen + L;
-                sos_fill_nan(yr + from, n - from);
+                if (from < n0) sos_fill_nan(y0r + from, n0 - from);
+                sos_fill_nan(yr + (from < n0 ? n0 : from), n - (from < n0 ? n0 : from));
                 sos_fill_nan(ho, L);
                 sos_fill_nan(g.carry_out + (int64_t)c * kSpecLdc, kSpecLdc);
             }
@@ -468,6 +483,16 @@ __global__ void zp_seal_kernel(double *y, int64_t ldy, int64_t n, long long s0, 
     const double qn = spec_qnan();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         if (s0 + i >= from) yr[i] = qn;
+}
+
+__global__ void zp_poison_kernel(const long long *nanpos, double *state, int nsec, int nch) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nch || nanpos[c] == 0x7fffffffffffffffLL) return;
+    const double qn = spec_qnan();
+    for (int q = 0; q < nsec; ++q) {
+        state[((int64_t)q * nch + c) * 2 + 0] = qn;
+        state[((int64_t)q * nch + c) * 2 + 1] = qn;
+    }
 }
 
 __global__ void zp_fill_ll_kernel(long long *p, int n, long long v) {
@@ -582,8 +607,8 @@ static zp_kern_t zp_kernel_for(int nr) {
 }
 
 // one chunk through the kernel; hist: keep the input a later osz_chain_zp_finish replays
-static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double *y, int64_t ldy,
-                     hipStream_t st) {
+static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double *y0, int64_t ldy0,
+                     int64_t n0, double *y, int64_t ldy, hipStream_t st) {
     osz_fir_s *fir = s->fir;
     osz_sos_s *sos = s->sos;
     const int NR = s->NR, S = 256 * NR;
@@ -606,6 +631,9 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
     g.f.step = S;
     g.f.H = s->dH;
     g.f.tb = fir->tb;
+    g.y0 = y0;
+    g.ldy0 = ldy0;
+    g.n0 = n0;
     g.n = n;
     g.W = W;
     g.nruns = (int)nruns;
@@ -707,18 +735,19 @@ int osz_chain_zp_open(osz_fir_t fir, osz_sos_t sos, int64_t skip, void *stream) 
     return OSZ_OK;
 }
 
-int osz_chain_zp_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, int64_t n, double *y,
-                      int64_t ldy, void *stream) {
-    OSZ_REQUIRE(fir && sos && x && y, "osz_chain_zp_step: null argument");
-    OSZ_REQUIRE(n >= 1 && ldx >= n && ldy >= n, "osz_chain_zp_step: n=%lld ldx=%lld ldy=%lld", (long long)n,
-                (long long)ldx, (long long)ldy);
+int osz_chain_zp_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, int64_t n, double *y0,
+                      int64_t ldy0, int64_t n0, double *y, int64_t ldy, void *stream) {
+    OSZ_REQUIRE(fir && sos && x, "osz_chain_zp_step: null argument");
+    OSZ_REQUIRE(n >= 1 && ldx >= n, "osz_chain_zp_step: n=%lld ldx=%lld", (long long)n, (long long)ldx);
+    OSZ_REQUIRE(n0 >= 0 && n0 <= n && (n0 == 0 || (y0 && ldy0 >= n0)) && (n0 == n || (y && ldy >= n - n0)),
+                "osz_chain_zp_step: outputs n0=%lld of n=%lld", (long long)n0, (long long)n);
     OSZ_SAME_DEVICE(fir, "osz_chain_zp_step");
     OSZ_SAME_DEVICE(sos, "osz_chain_zp_step");
     ChainZp *s = sos->zp;
     OSZ_REQUIRE(s && s->fir == fir && s->open, "osz_chain_zp_step: osz_chain_zp_open first");
     OSZ_REQUIRE(n >= 4 * 256 * (int64_t)s->NR, "osz_chain_zp_step: a chunk of %lld samples is shorter than two pairs of blocks (%d)",
                 (long long)n, 4 * 256 * s->NR);
-    return zp_launch(s, x, ldx, n, y, ldy, as_stream(stream));
+    return zp_launch(s, x, ldx, n, y0, ldy0, n0, y, ldy, as_stream(stream));
 }
 
 int osz_chain_zp_finish(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx, int64_t m, double *y,
@@ -749,14 +778,19 @@ int osz_chain_zp_finish(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t l
         rc = sos_forward_raw(sos, s->dscratch, s->hist_cap, s->dscratch, s->hist_cap, s->hist_n, st);
         if (rc) return rc;
     }
+    // (a NaN never leaves the cascade: the replay knows nothing of one before its samples)
+    hipLaunchKernelGGL(zp_poison_kernel, dim3((nch + 255) / 256), dim3(256), 0, st, s->dnanpos, sos->dstate,
+                       sos->nsec, nch);
+    OSZ_HIP(hipGetLastError());
     // 2. the output samples the stream is still short of need the head of what follows
     if (ny > 0) {
-        OSZ_REQUIRE(x && y && m >= 4 * 256 * (int64_t)s->NR && ldx >= m && ny <= m && ldy >= ny,
+        OSZ_REQUIRE(x && y && m >= 4 * 256 * (int64_t)s->NR && ldx >= m && ny <= m - 2 * 256 * (int64_t)s->NR &&
+                        ldy >= ny,
                     "osz_chain_zp_finish: %lld output samples from %lld input samples", (long long)ny, (long long)m);
         // through a scratch output: the kernel writes all m of them
         double *tmp = nullptr;
         OSZ_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)nch * m));
-        int rc = zp_launch(s, x, ldx, m, tmp, m, st);
+        int rc = zp_launch(s, x, ldx, m, nullptr, 0, 0, tmp, m, st);
         if (rc == OSZ_OK)
             rc = hipMemcpy2DAsync(y, sizeof(double) * ldy, tmp, sizeof(double) * m, sizeof(double) * ny, nch,
                                   hipMemcpyDeviceToDevice, st) == hipSuccess ? OSZ_OK

@@ -94,9 +94,11 @@ def test_nonfinite_reach_many_channels_whole_tiles(nm):
                          [False, False, True, True, True], [True] * 5, [False] * 5]
 
 
-def test_nonfinite_reach_fused_chain(nm):
-    """FIR -> sosfiltfilt on the fused step (chain_kernel: several runs per channel that
-    start from zero states; backward pass beside it): a NaN in the input reaches the
+@pytest.mark.parametrize("zero_phase", [True, False])
+def test_nonfinite_reach_fused_chain(nm, zero_phase):
+    """FIR -> sosfiltfilt on the zero-phase kernel (osz_chain_zp_step + osz_chain_zp_seal)
+    and, with OSZ_CHAIN_ZP=0, on the two-kernel step (several runs per channel that
+    start from nothing; backward pass beside it): a NaN in the input reaches the
     end of the stream in the forward half, so from the chunk before the NaN on every
     output chunk of that channel is NaN; the other channels equal the oracle.  (How
     far a NaN spreads inside the FIR differs from the reference by construction -- an
@@ -114,13 +116,18 @@ def test_nonfinite_reach_fused_chain(nm):
     x[30, 5 * cs + cs // 2:] = float("nan")
     src = producer(x, cs, -1)
     fir = producer(partial(nm.oaconvolve, src, taps, -1, "same"), cs, -1, shape=src.shape)
-    steps, plain_step = [], dev.chain_step
-    dev.chain_step = lambda *a, **k: (steps.append(1), plain_step(*a, **k))[1]
+    import os
+    steps, plain_step, plain_zp = [], dev.chain_step, dev.chain_zp_step
+    dev.chain_step = lambda *a, **k: (steps.append("step"), plain_step(*a, **k))[1]
+    dev.chain_zp_step = lambda *a, **k: (steps.append("zp"), plain_zp(*a, **k))[1]
+    if not zero_phase:
+        os.environ["OSZ_CHAIN_ZP"] = "0"
     try:
         got = torch.cat(list(nm.sosfiltfilt(fir, sos, -1)), -1).cpu().numpy()
     finally:
-        dev.chain_step = plain_step
-    assert steps, "the fused step did not run"
+        dev.chain_step, dev.chain_zp_step = plain_step, plain_zp
+        os.environ.pop("OSZ_CHAIN_ZP", None)
+    assert steps and set(steps) == {"zp" if zero_phase else "step"}, "the fused path did not run"
     nan_chunk = np.array([[bool(np.isnan(got[c, k * cs:(k + 1) * cs]).all()) for k in range(nchunks)]
                           for c in range(C)])
     some_nan = np.array([[bool(np.isnan(got[c, k * cs:(k + 1) * cs]).any()) for k in range(nchunks)]

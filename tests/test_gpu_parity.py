@@ -1123,13 +1123,19 @@ def test_fir_then_sosfiltfilt_through_the_api_fused(osz):
                                  (64, 4, 70001, 70001 * 7 + 5)):
         taps = sps.firwin(taps_n, 0.2)
         x = dev.synth_normal(C, total, seed=44)
-        steps, plain_step = [], dev.chain_step
-        dev.chain_step = lambda *a, **k: (steps.append(1), plain_step(*a, **k))[1]
+        steps, plain_step, plain_zp = [], dev.chain_step, dev.chain_zp_step
+        dev.chain_step = lambda *a, **k: (steps.append("step"), plain_step(*a, **k))[1]
+        dev.chain_zp_step = lambda *a, **k: (steps.append("zp"), plain_zp(*a, **k))[1]
         try:
             got = chain(x, taps, cs, -1)
         finally:
-            dev.chain_step = plain_step
-        assert len(steps) == -(-total // cs) - 2, (taps_n, len(steps))   # the fused path DID run
+            dev.chain_step, dev.chain_zp_step = plain_step, plain_zp
+        # a fused path DID run: the zero-phase kernel (six chunks or more, filters it takes:
+        # every chunk but the last two, plus the head of the next for the seam) or the
+        # two-kernel step (every chunk but the first two)
+        nchunks = -(-total // cs)
+        assert steps in (["zp"] * (nchunks - 2), ["step"] * (nchunks - 2)), (taps_n, steps)
+        assert (steps[0] == "zp") == (taps_n != 2049), taps_n
         os.environ["OSZ_CHAIN_API"] = "0"
         try:
             ref = chain(x, taps, cs, -1)
@@ -1147,12 +1153,12 @@ def test_fir_then_sosfiltfilt_through_the_api_fused(osz):
     # host-fed: ndarray chunks in, ndarray chunks out, one trip over PCIe each way
     taps = sps.firwin(513, 0.2)
     xh = np.random.default_rng(46).standard_normal((4, 90000 * 7 + 1234))
-    steps, plain_step = [], dev.chain_step
-    dev.chain_step = lambda *a, **k: (steps.append(1), plain_step(*a, **k))[1]
+    steps, plain_zp = [], dev.chain_zp_step
+    dev.chain_zp_step = lambda *a, **k: (steps.append(1), plain_zp(*a, **k))[1]
     try:
         got = chain(xh, taps, 90000, -1)
     finally:
-        dev.chain_step = plain_step
+        dev.chain_zp_step = plain_zp
     assert len(steps) == 8 - 2 and all(isinstance(g, np.ndarray) for g in got)
     assert [g.shape[-1] for g in got] == [90000] * 7 + [1234]
     want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, 90000)

@@ -1,0 +1,190 @@
+"""GPU parity of the zero-phase chain kernel (C ABI osz_chain_zp_*, csrc/chain_zp.hip):
+FIR -> forward cascade -> backward cascade of a chunked stream in one launch per chunk,
+against SciPy's convolve + sosfilt forward + sosfilt backward over the whole stream (what the
+reference's oaconvolve -> sosfiltfilt, core/numerical.py:158-298 + :338-411, computes away
+from the stream's ends when chunks are much longer than the cascade's memory), and through
+the public generators against the CPU oracle's chunk-local scheme and the two-kernel step."""
+
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import scipy.signal as sps
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+BP = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from openseize_amd import _lib
+    _lib.load()
+    from openseize_amd import _device
+    return _device
+
+
+def whole_stream_reference(xh, h, sos):
+    """Forward pass from sosfilt_zi * u[0], backward pass over everything (zero-extended)."""
+    total = xh.shape[1]
+    u = sps.oaconvolve(xh, h[None], axes=-1)[:, :total]
+    zi = sps.sosfilt_zi(sos)[:, None, :] * u[:, :1][None]
+    f, _ = sps.sosfilt(sos, u, axis=-1, zi=zi)
+    ext = np.concatenate([f, np.zeros((xh.shape[0], 8192))], 1)
+    return sps.sosfilt(sos, ext[:, ::-1], axis=-1)[:, ::-1][:, :total]
+
+
+def run_stream(dev, x, h, sos, lens, split=False):
+    """The chunks of x through osz_chain_zp_step; returns (outputs as one tensor whose
+    column q is stream sample q - lag, lag).  split: the outputs of every step go to the
+    tail of the previous chunk's buffer and the head of the current one, as a caller that
+    cuts the stream into chunks of its own has them."""
+    import torch
+    C = x.shape[0]
+    fir, iir = dev.FirStream(h, C), dev.SosStream(sos, C)
+    try:
+        lag = dev.chain_zp_lag(fir, iir)
+        assert lag >= 0
+        iir.set_state_scaled((x[:, :1] * float(h[0])).contiguous(), 0)
+        dev.chain_zp_open(fir, iir, 0)
+        outs, o = [], 0
+        if not split:
+            for n in lens:
+                outs.append(dev.chain_zp_step(fir, iir, x[:, o:o + n]))
+                o += n
+            return torch.cat(outs, 1), lag
+        cut = lag + 37                                        # where the caller's chunks begin
+        bufs = [torch.full((C, cut), float("nan"), dtype=torch.float64, device="cuda")]
+        for n in lens:
+            bufs.append(torch.full((C, n), float("nan"), dtype=torch.float64, device="cuda"))
+        for k, n in enumerate(lens):
+            prev, cur = bufs[k], bufs[k + 1]
+            dev.chain_zp_step(fir, iir, x[:, o:o + n], out=cur[:, :n - cut], tail=prev[:, prev.shape[1] - cut:])
+            o += n
+        return torch.cat([b[:, :b.shape[1]] for b in bufs], 1)[:, :sum(lens)], lag
+    finally:
+        fir.close()
+        iir.close()
+
+
+CASES = [
+    # taps, cascade, channels, chunk lengths (S = 2816 for 1024 taps)
+    (1024, BP, 5, [2 * 2816 * 6 + 1024, 2 * 2816 * 4, 2 * 2816 * 3 + 2816 + 17, 2 * 2816 * 2 + 5,
+                   2 * 2816 * 4 - 1, 2 * 2816 * 3 + 300]),
+    (1024, BP, 256, [2 * 2816 * 30 + 777] * 3),
+    (1024, BP, 64, [1 << 18] * 3),
+    (300, BP, 7, [150000, 150000, 90001]),
+    (513, sps.butter(5, 0.3, output="sos"), 3, [100000] * 3),
+    (777, sps.cheby1(3, 1, [0.16, 0.48], "bandpass", output="sos"), 4, [65536, 70000, 65537]),
+    (64, sps.ellip(4, 0.5, 50, 0.25, "highpass", output="sos"), 2, [80000, 80001]),
+]
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_zero_phase_stream_against_scipy(dev, case, split):
+    taps_n, sos, C, lens = CASES[case]
+    h = sps.firwin(taps_n, 0.2)
+    total = sum(lens)
+    x = dev.synth_normal(C, total, seed=3 + case)
+    got, lag = run_stream(dev, x, h, sos, lens, split)
+    pick = sorted({0, C // 2, C - 1})
+    ref = whole_stream_reference(x[pick].cpu().numpy(), h, sos)
+    g = got[pick].cpu().numpy()
+    assert np.isfinite(g[:, lag:]).all()
+    hi = total - lag - 6000                       # the stream's end is the caller's
+    err = np.max(np.abs(g[:, lag:lag + hi] - ref[:, :hi])) / np.max(np.abs(ref))
+    assert err < 1e-11, (taps_n, C, err)
+
+
+def test_what_the_kernel_refuses(dev):
+    """Pairs of filters outside the scheme report -1 (and the public generators then take
+    the two-kernel step): a FIR too long for row 15 to stay free, a cascade that hardly
+    forgets, poles that repeat."""
+    def lag(taps_n, sos):
+        fir, iir = dev.FirStream(sps.firwin(taps_n, 0.2), 2), dev.SosStream(sos, 2)
+        try:
+            return dev.chain_zp_lag(fir, iir)
+        finally:
+            fir.close()
+            iir.close()
+    assert lag(1024, BP) == 1024
+    assert lag(1900, BP) == -1
+    assert lag(256, sps.butter(4, [0.0002, 0.0016], "bandpass", output="sos")) == -1
+    assert lag(256, np.vstack([sps.butter(2, 0.2, output="sos")] * 2)) == -1
+
+
+def test_full_size_chunks_linearity_and_checksum(dev):
+    """BASELINE cfg-3's chunk shape (256 channels x 2^20 samples, three chunks): the kernel is
+    linear (a x1 + b x2 in = a y1 + b y2 out, to rounding) and reproducible bit for bit."""
+    import torch
+    h = sps.firwin(1024, 0.2)
+    C, cs = 256, 1 << 20
+    x1 = [dev.synth_normal(C, cs, seed=11, n0=k * cs) for k in range(3)]
+    x2 = [dev.synth_normal(C, cs, seed=12, n0=k * cs) for k in range(3)]
+
+    def run(chunks):
+        fir, iir = dev.FirStream(h, C), dev.SosStream(BP, C)
+        try:
+            iir.set_state(None)
+            dev.chain_zp_open(fir, iir, 0)
+            return [dev.chain_zp_step(fir, iir, c) for c in chunks]
+        finally:
+            fir.close()
+            iir.close()
+
+    y1, y2 = run(x1), run(x2)
+    y12 = run([0.5 * a - 2.0 * b for a, b in zip(x1, x2)])
+    again = run(x1)
+    for k in range(3):
+        want = 0.5 * y1[k] - 2.0 * y2[k]
+        assert float((y12[k] - want).abs().max()) < 1e-12 * float(want.abs().max())
+        assert torch.equal(again[k].view(torch.int64), y1[k].view(torch.int64))
+
+
+def test_public_generators_take_the_kernel_and_match_the_reference_scheme(dev):
+    """FIR producer -> sosfiltfilt generator on device-resident data: the zero-phase flow
+    (numerical._zero_phase_stream) chunk for chunk against the two-kernel flow
+    (OSZ_CHAIN_ZP=0) and against the oracle's oaconvolve('same') -> chunk-local sosfiltfilt
+    on three channels: odd and even left cuts, ragged last chunk, a stream ending exactly on
+    a chunk, a real pole."""
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import producer
+    from openseize_amd.core import numerical as nm
+
+    def chain(x, taps, sos, cs):
+        src = producer(x, cs, -1)
+        fir = producer(partial(nm.oaconvolve, src, taps, -1, "same"), cs, -1, shape=src.shape)
+        return [c for c in nm.sosfiltfilt(fir, sos, -1)]
+
+    for taps_n, sos, C, cs, total in ((1024, BP, 256, 6144 * 24, 6144 * 24 * 6 + 6144 * 9 + 321),
+                                      (301, BP, 5, 100000, 100000 * 8),
+                                      (64, sps.butter(5, 0.3, output="sos"), 4, 70001, 70001 * 7 + 5)):
+        taps = sps.firwin(taps_n, 0.2)
+        x = dev.synth_normal(C, total, seed=44)
+        steps, plain_zp = [], dev.chain_zp_step
+        dev.chain_zp_step = lambda *a, **k: (steps.append(1), plain_zp(*a, **k))[1]
+        try:
+            got = chain(x, taps, sos, cs)
+        finally:
+            dev.chain_zp_step = plain_zp
+        assert len(steps) == -(-total // cs) - 2, (taps_n, len(steps))
+        os.environ["OSZ_CHAIN_ZP"] = "0"
+        try:
+            ref = chain(x, taps, sos, cs)
+        finally:
+            del os.environ["OSZ_CHAIN_ZP"]
+        assert [g.shape for g in got] == [r.shape for r in ref], taps_n
+        for k, (a, b) in enumerate(zip(got, ref)):
+            err = float((a - b).abs().max()) / float(b.abs().max())
+            assert err < 1e-11, (taps_n, C, k, err)
+        pick = [0, C // 2, C - 1]
+        xh = x[pick].cpu().numpy()
+        want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, cs)
+        gh = torch.cat(got, -1)[pick].cpu().numpy()
+        assert np.max(np.abs(gh - want)) < RTOL * np.max(np.abs(want)), taps_n
