@@ -88,17 +88,58 @@ __device__ __forceinline__ double zp_dot(const double *kk, const double *pr, con
     return c;
 }
 
+// The fit and the burst amplitudes of a pair in one stage.  Four consecutive lanes share one
+// amplitude (block, causal / anticausal, mode): each takes a quarter of the 2 nh fit samples
+// for the real AND the imaginary row of M, two DPP steps add the quarters up in the quad's
+// last lane, and that lane writes kappa[r] = amplitude * lambda^(256 r), r < R:
+//   kapA[amp][r][q]   amp = 0 mu_a, 1 mu_b, 2 nu_a, 3 nu_b              (this pair)
+//   kapN[k][r][q]     k = 0 mu_b, 1 nu_b: what the NEXT pair meets as mu_pb, nu_pb
+template <int NM>
+__device__ __forceinline__ void zp_fit_kappa(int tt, int nh, int R, const double *fitbuf, const double *mtab,
+                                             const double *lrow, double *kapA, double *kapN) {
+    const int ns = 2 * nh, per = nh >> 1;
+    const int qd = tt >> 2, p4 = tt & 3;
+    const bool valid = qd < 4 * NM;
+    const int blk = valid ? qd / (2 * NM) : 0, kind = valid ? (qd / NM) % 2 : 0, q = valid ? qd % NM : 0;
+    const double *yb = fitbuf + ns * blk + per * p4;
+    const double *mr = mtab + ns * ((2 * kind) * NM + q) + per * p4;
+    const double *mi = mtab + ns * ((2 * kind + 1) * NM + q) + per * p4;
+    double sr = 0.0, si = 0.0;
+    for (int k = 0; k < per; ++k) {
+        const double y = yb[k];
+        sr = fma(mr[k], y, sr);
+        si = fma(mi[k], y, si);
+    }
+    if (!valid) sr = si = 0.0;
+    sr += dpp_row_shr0<1>(sr);
+    si += dpp_row_shr0<1>(si);
+    sr += dpp_row_shr0<2>(sr);
+    si += dpp_row_shr0<2>(si);
+    if (p4 == 3 && valid) {
+        const int amp = kind * 2 + blk;
+        for (int r = 0; r < R; ++r) {
+            const double lr = lrow[(r * NM + q) * 2 + 0], li = lrow[(r * NM + q) * 2 + 1];
+            const double kr = sr * lr - si * li, ki = sr * li + si * lr;
+            kapA[((amp * R + r) * NM + q) * 2 + 0] = kr;
+            kapA[((amp * R + r) * NM + q) * 2 + 1] = ki;
+            if (blk == 1) {
+                kapN[((kind * R + r) * NM + q) * 2 + 0] = kr;
+                kapN[((kind * R + r) * NM + q) * 2 + 1] = ki;
+            }
+        }
+    }
+}
+
 template <int NR, int NM>
 __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     constexpr int D = 16 - NR, S = 256 * NR;
     extern __shared__ fft::cube::C2 cube_lds[];
     const int R = g.R, nh = g.nh, ns = 2 * nh;
-    constexpr int MU = 2 * 2 * NM * 2;                 // doubles per parity: [2 blk][2 kind][NM][2]
     double *xl = reinterpret_cast<double *>(cube_lds) + 2 * fft::cube::SLOTS;   // behind the cube
     double *fitbuf = xl;                               // [2 blk][2 nh]
-    double *mu = fitbuf + 2 * ns;                      // [2 parity][2 blk][2 kind][NM][2]
-    double *kap = mu + 2 * MU;                         // [8 src][R][NM][2]
-    double *lrow = kap + 8 * R * NM * 2;               // [R][NM][2]
+    double *kapA = fitbuf + 2 * ns;                    // [4 amp][R][NM][2]: this pair's mu_a mu_b nu_a nu_b
+    double *kapP = kapA + 4 * R * NM * 2;              // [2 parity][2][R][NM][2]: mu_pb, nu_pb
+    double *lrow = kapP + 4 * R * NM * 2;              // [R][NM][2]
     double *ptab = lrow + R * NM * 2;                  // [20][NM][2]
     double *mtab = ptab + 20 * NM * 2;                 // [4 NM][2 nh]
     const FirArgs &a = g.f;
@@ -114,7 +155,6 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     const int64_t p1 = ((int64_t)(run + 1) * g.W) / g.nruns;
     const int64_t first = run == 0 ? 0 : p0 - 1;
     const int64_t lastf = run < g.nruns - 1 ? p1 : p1 - 1;
-    const int kinv = (65536 + R * NM - 1) / (R * NM);   // t / (R NM) for t < 256 by multiplication
 
     FirPair<NR, 16> P{a, t, a.wlen - 1, xr, yr, 0, cube_lds};
     fft::cube::tw_load(t, a.tb, P.tw1, P.tw2);
@@ -123,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     for (int i = t; i < R * NM * 2; i += 256) lrow[i] = g.Lrow[i];
     for (int i = t; i < 20 * NM * 2; i += 256) ptab[i] = g.P[i];
     for (int i = t; i < 4 * NM * ns; i += 256) mtab[i] = g.M[i];
-    for (int i = t; i < 2 * MU; i += 256) mu[i] = 0.0;
+    for (int i = t; i < 4 * R * NM * 2; i += 256) kapP[i] = 0.0;
     double held[kSpecRMax];          // rows NR-1-r of the previous pair's block b, one burst short
 #pragma unroll
     for (int r = 0; r < kSpecRMax; ++r) held[r] = 0.0;
@@ -173,42 +213,15 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             P.cr[j] = im[j + NR];
         }
         __syncthreads();
-        {   // fit: 4 consecutive lanes share one row of M (block, amplitude, component, mode)
-            const int fg = tt >> 2, p4 = tt & 3;
-            const bool fvalid = fg < 8 * NM;
-            const int fblk = fvalid ? fg / (4 * NM) : 0, frow = fvalid ? fg % (4 * NM) : 0;
-            const int per = nh >> 1;                                  // samples per lane
-            const double *yb = fitbuf + ns * fblk + per * p4;
-            const double *mc = mtab + ns * frow + per * p4;
-            double s = 0.0;
-            for (int k = 0; k < per; ++k) s = fma(mc[k], yb[k], s);
-            if (!fvalid) s = 0.0;
-            s += dpp_row_shr0<1>(s);
-            s += dpp_row_shr0<2>(s);
-            // frow = (2 kind + comp) NM + q
-            const int kind2 = frow / NM, q = frow % NM;
-            if (p4 == 3 && fvalid) mu[par * MU + (((fblk * 2 + (kind2 >> 1)) * NM + q) * 2) + (kind2 & 1)] = s;
-        }
+        // fit and amplitudes: this pair's into kapA, block b's also into the other half of
+        // kapP for the next pair
+        zp_fit_kappa<NM>(tt, nh, R, fitbuf, mtab, lrow, kapA, kapP + (par ^ 1) * (2 * R * NM * 2));
         __syncthreads();
-        // kappa[src][r][q] = (+-) amplitude * lambda^(256 r):
-        //   0: block a, -mu_a forwards from row 0          4: block b, -mu_b forwards from row 0
-        //   1: block a, +mu_pb forwards from row D         5: block b, +mu_a forwards from row D
-        //   2: block a, -nu_pb backwards from row D-1      6: block b, -nu_a backwards from row D-1
-        //   3: block a, +nu_b backwards from row NR-1      7: held rows of the previous b, +nu_a
-        {
-            const int ksrc = (tt * kinv) >> 16, kr_ = (tt / NM) % R, kq = tt % NM;
-            if (ksrc < 8) {
-                const int mpar = (ksrc == 1 || ksrc == 2) ? par ^ 1 : par;
-                const int mblk = (ksrc == 1 || ksrc == 2 || ksrc == 3 || ksrc == 4) ? 1 : 0;
-                const int mkind = (ksrc == 2 || ksrc == 3 || ksrc == 6 || ksrc == 7) ? 1 : 0;
-                const double sg = (ksrc == 0 || ksrc == 2 || ksrc == 4 || ksrc == 6) ? -1.0 : 1.0;
-                const double *m = mu + mpar * MU + ((mblk * 2 + mkind) * NM + kq) * 2;
-                const double lr = lrow[(kr_ * NM + kq) * 2 + 0], li = lrow[(kr_ * NM + kq) * 2 + 1];
-                kap[((ksrc * R + kr_) * NM + kq) * 2 + 0] = sg * (m[0] * lr - m[1] * li);
-                kap[((ksrc * R + kr_) * NM + kq) * 2 + 1] = sg * (m[0] * li + m[1] * lr);
-            }
-        }
-        __syncthreads();
+        const double *kap = kapA, *kpb = kapP + par * (2 * R * NM * 2);
+        // Six burst evaluations per row index r serve the eight places a burst lands: the
+        // wrapped right tail of block a leaves its row r and arrives, one window on, in row
+        // D + r of block b with the same values (mu_a), and so do the left tail of block a
+        // in row D-1-r of block b and in the rows the previous block b holds back (nu_a).
         double c7[kSpecRMax];
         {
             // forward bursts with lambda^t, then (the same registers) backward ones with
@@ -218,13 +231,13 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
 #pragma unroll
             for (int r = 0; r < kSpecRMax; ++r) {
                 if (r < R && r < D) {
-                    const double c0 = zp_dot<NM>(kap + ((0 * R + r) * NM) * 2, Pr, Pi);
-                    const double c4 = zp_dot<NM>(kap + ((4 * R + r) * NM) * 2, Pr, Pi);
-                    re[r] += c0;
-                    im[r] += c4;
-                    re[(D + r) & 15] += zp_dot<NM>(kap + ((1 * R + r) * NM) * 2, Pr, Pi);
-                    im[(D + r) & 15] += zp_dot<NM>(kap + ((5 * R + r) * NM) * 2, Pr, Pi);
-                    if (r == 0 && !bad && (sos_not_finite(c0) || sos_not_finite(c4))) {
+                    const double ca = zp_dot<NM>(kap + ((0 * R + r) * NM) * 2, Pr, Pi);   // mu_a
+                    const double cb = zp_dot<NM>(kap + ((1 * R + r) * NM) * 2, Pr, Pi);   // mu_b
+                    re[r] -= ca;
+                    im[(D + r) & 15] += ca;
+                    im[r] -= cb;
+                    re[(D + r) & 15] += zp_dot<NM>(kpb + ((0 * R + r) * NM) * 2, Pr, Pi); // mu_pb
+                    if (r == 0 && !bad && (sos_not_finite(ca) || sos_not_finite(cb))) {
                         bad = true;
                         bad_at = o;
                     }
@@ -236,10 +249,11 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             for (int r = 0; r < kSpecRMax; ++r) {
                 c7[r] = 0.0;
                 if (r < R && r < D) {
-                    re[(D - 1 - r) & 15] += zp_dot<NM>(kap + ((2 * R + r) * NM) * 2, Pr, Pi);
-                    im[(D - 1 - r) & 15] += zp_dot<NM>(kap + ((6 * R + r) * NM) * 2, Pr, Pi);
-                    re[(NR - 1 - r) & 15] += zp_dot<NM>(kap + ((3 * R + r) * NM) * 2, Pr, Pi);
-                    c7[r] = zp_dot<NM>(kap + ((7 * R + r) * NM) * 2, Pr, Pi);
+                    const double na = zp_dot<NM>(kap + ((2 * R + r) * NM) * 2, Pr, Pi);   // nu_a
+                    im[(D - 1 - r) & 15] -= na;
+                    c7[r] = na;
+                    re[(NR - 1 - r) & 15] += zp_dot<NM>(kap + ((3 * R + r) * NM) * 2, Pr, Pi);  // nu_b
+                    re[(D - 1 - r) & 15] -= zp_dot<NM>(kpb + ((1 * R + r) * NM) * 2, Pr, Pi);   // nu_pb
                 }
             }
         }
@@ -329,21 +343,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             fitbuf[ns + tt - 256 + ns] = im[15];
         }
         __syncthreads();     // also: every thread is done reading the cube
-        {
-            const int fg = tt >> 2, p4 = tt & 3;
-            const bool fvalid = fg < 8 * NM;
-            const int fblk = fvalid ? fg / (4 * NM) : 0, frow = fvalid ? fg % (4 * NM) : 0;
-            const int per = nh >> 1;
-            const double *yb = fitbuf + ns * fblk + per * p4;
-            const double *mc = mtab + ns * frow + per * p4;
-            double s = 0.0;
-            for (int k = 0; k < per; ++k) s = fma(mc[k], yb[k], s);
-            if (!fvalid) s = 0.0;
-            s += dpp_row_shr0<1>(s);
-            s += dpp_row_shr0<2>(s);
-            const int kind2 = frow / NM, q = frow % NM;
-            if (p4 == 3 && fvalid) mu[par * MU + (((fblk * 2 + (kind2 >> 1)) * NM + q) * 2) + (kind2 & 1)] = s;
-        }
+        zp_fit_kappa<NM>(tt, nh, R, fitbuf, mtab, lrow, kapA, kapP + (par ^ 1) * (2 * R * NM * 2));
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             acc[256 * j + t] = re[j] + (j < D ? P.cr[j < D ? j : 0] : 0.0);
@@ -353,8 +353,9 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[la + 256 * j + t] += im[j];
         {
+            // non-finite amplitudes poison the rest of the stream
             bool nf = false;
-            for (int i = 0; i < MU; ++i) nf = nf || sos_not_finite(mu[par * MU + i]);
+            for (int i = 0; i < 4 * NM * 2; ++i) nf = nf || sos_not_finite(kapA[((i / (NM * 2)) * R) * NM * 2 + i % (NM * 2)]);
             if (nf && !bad) {
                 bad = true;
                 bad_at = o;
@@ -363,60 +364,37 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         double Pfr[NM], Pfi[NM], Pbr[NM], Pbi[NM];
         zp_powers<NM>(ptab, tt, Pfr, Pfi);
         zp_powers<NM>(ptab, 255 - tt, Pbr, Pbi);
-        // ten sources in two rounds of the kappa table: (parity, block, kind, sign, forward?,
-        // offset: first sample of a forward burst / last sample of a backward one)
-        for (int round = 0; round < 2; ++round) {
-            __syncthreads();
-            const int ksrc = (tt * kinv) >> 16, kr_ = (tt / NM) % R, kq = tt % NM;
-            const int nsrc = round == 0 ? 8 : 2;
-            if (ksrc < nsrc) {
-                int mpar, mblk, mkind;
-                double sg;
-                if (round == 0) {
-                    // 0 +mu_pb  1 -mu_a  2 -mu_b  3 +mu_a  4 +mu_b  5 -nu_pb  6 -nu_a  7 +nu_a (held)
-                    mpar = (ksrc == 0 || ksrc == 5) ? par ^ 1 : par;
-                    mblk = (ksrc == 0 || ksrc == 2 || ksrc == 4 || ksrc == 5) ? 1 : 0;
-                    mkind = ksrc >= 5 ? 1 : 0;
-                    sg = (ksrc == 1 || ksrc == 2 || ksrc == 5 || ksrc == 6) ? -1.0 : 1.0;
-                } else {
-                    // 0 -nu_b  1 +nu_b
-                    mpar = par;
-                    mblk = 1;
-                    mkind = 1;
-                    sg = ksrc == 0 ? -1.0 : 1.0;
-                }
-                const double *m = mu + mpar * MU + ((mblk * 2 + mkind) * NM + kq) * 2;
-                const double lr = lrow[(kr_ * NM + kq) * 2 + 0], li = lrow[(kr_ * NM + kq) * 2 + 1];
-                kap[((ksrc * R + kr_) * NM + kq) * 2 + 0] = sg * (m[0] * lr - m[1] * li);
-                kap[((ksrc * R + kr_) * NM + kq) * 2 + 1] = sg * (m[0] * li + m[1] * lr);
-            }
-            __syncthreads();
-            for (int s = 0; s < nsrc; ++s) {
-                const bool fwd = round == 0 && s < 5;
-                int off;
-                if (round == 0)
-                    off = s == 0 ? 256 * D : s == 1 ? 0 : s == 2 ? la : s == 3 ? 4096 : s == 4 ? la + 4096
-                        : s == 5 ? 256 * D - 1 : s == 6 ? 4095 : -1;
-                else
-                    off = s == 0 ? la + 4095 : la - 1;
-                if (round == 0 && s == 7) {
-                    // the previous pair's last R rows of block b: complete with this block's +nu
-                    const int64_t ob = o - S + tt;
+        // ten bursts: (amplitude table, sign, forwards?, first sample of a forward burst /
+        // last sample of a backward one); the previous block b's from kapP, block b's own
+        // "next" entries from the other half of kapP
+        const double *kpb = kapP + par * (2 * R * NM * 2), *kpn = kapP + (par ^ 1) * (2 * R * NM * 2);
+        __syncthreads();
+        for (int s = 0; s < 10; ++s) {
+            const double *tab = s == 0 ? kpb : s == 1 ? kapA : s == 2 ? kpn : s == 3 ? kapA : s == 4 ? kpn
+                              : s == 5 ? kpb + R * NM * 2 : s == 6 ? kapA + 2 * R * NM * 2 : s == 7 ? kapA + 2 * R * NM * 2
+                              : kpn + R * NM * 2;
+            //              0 +mu_pb  1 -mu_a  2 -mu_b  3 +mu_a  4 +mu_b | 5 -nu_pb  6 -nu_a  7 +nu_a (held)  8 -nu_b  9 +nu_b
+            const double sg = (s == 1 || s == 2 || s == 5 || s == 6 || s == 8) ? -1.0 : 1.0;
+            const bool fwd = s < 5;
+            const int off = s == 0 ? 256 * D : s == 1 ? 0 : s == 2 ? la : s == 3 ? 4096 : s == 4 ? la + 4096
+                          : s == 5 ? 256 * D - 1 : s == 6 ? 4095 : s == 7 ? -1 : s == 8 ? la + 4095 : la - 1;
+            if (s == 7) {
+                // the previous pair's last R rows of block b: complete with this block's +nu
+                const int64_t ob = o - S + tt;
 #pragma unroll
-                    for (int r = 0; r < kSpecRMax; ++r)
-                        if (r < R)
-                            OSZ_ZP_PUT(ob + 256 * (NR - 1 - r),
-                                       bad ? spec_qnan() : held[r] + zp_dot<NM>(kap + ((7 * R + r) * NM) * 2, Pbr, Pbi));
-                    continue;
-                }
-                for (int r = 0; r < R; ++r) {
-                    const double cs = fwd ? zp_dot<NM>(kap + ((s * R + r) * NM) * 2, Pfr, Pfi)
-                                          : zp_dot<NM>(kap + ((s * R + r) * NM) * 2, Pbr, Pbi);
-                    const int i = fwd ? off + 256 * r + tt : off - 256 * r - (255 - tt);
-                    if (i >= 0 && i < 8192) acc[i] += cs;
-                }
-                __syncthreads();
+                for (int r = 0; r < kSpecRMax; ++r)
+                    if (r < R)
+                        OSZ_ZP_PUT(ob + 256 * (NR - 1 - r),
+                                   bad ? spec_qnan() : held[r] + zp_dot<NM>(tab + (r * NM) * 2, Pbr, Pbi));
+                continue;
             }
+            for (int r = 0; r < R; ++r) {
+                const double cs = sg * (fwd ? zp_dot<NM>(tab + (r * NM) * 2, Pfr, Pfi)
+                                            : zp_dot<NM>(tab + (r * NM) * 2, Pbr, Pbi));
+                const int i = fwd ? off + 256 * r + tt : off - 256 * r - (255 - tt);
+                if (i >= 0 && i < 8192) acc[i] += cs;
+            }
+            __syncthreads();
         }
         const double qn = spec_qnan();
         const int ltot = la + lb;
@@ -545,7 +523,7 @@ void zp_unlink(ChainZp *s) {
 static size_t zp_lds_bytes(const ChainZp *s) {
     const int NM = s->NM, R = s->R, ns = 2 * s->nh;
     return sizeof(fft::cube::C2) * fft::cube::SLOTS +
-           sizeof(double) * (2 * ns + 2 * 2 * 2 * NM * 2 + 8 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * ns);
+           sizeof(double) * (2 * ns + 8 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * ns);
 }
 
 static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
