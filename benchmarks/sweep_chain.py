@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
-"""The cfg-3 chain (1024-tap FIR -> 6-section sosfiltfilt, steady state, inputs
-resident) over channel counts and chunk sizes: how the kernels hold up away
-from the headline shape (the 8-GPU split of cfg-4/5 leaves 32 / 128 channels
-per GPU).  One JSON line per shape."""
+"""Channel sweep of the three BASELINE workloads with this round's kernels, steady state,
+inputs resident: how the kernels hold up away from the headline shape.  The 8-GPU channel
+split of the metric's 256 channels leaves 32 per GPU; the reference's own
+tutorials run 4 channels.  One JSON line per (workload, channels):
+
+    PYTHONPATH=. python benchmarks/sweep_chain.py > profiles/rNN_channel_sweep.jsonl
+
+  chain  FIR(1024) -> sosfiltfilt(6 sections), one osz_chain_zp_step (+ seal) per 2^20-sample chunk
+  fir    FIR(1024) overlap-add alone (osz_fir_push)
+  welch  Welch PSD nperseg 4096, 50 % overlap, segment average (osz_spec_push)
+`rel_256` is the rate relative to the same workload at 256 channels (printed last)."""
 import json
 import os
 import sys
@@ -11,8 +18,22 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+CHUNK = 1 << 20
 
-def run(C, CHUNK, steps=12):
+
+def timed(step, steps, warm):
+    import torch
+    for k in range(warm):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(warm, warm + steps):
+        step(k)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def chain(C, steps=24, warm=6):
     import scipy.signal as sps
     import torch
     from openseize_amd import _device as dev
@@ -20,33 +41,60 @@ def run(C, CHUNK, steps=12):
     sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
     ring = [dev.synth_normal(C, CHUNK, seed=0, n0=k * CHUNK) for k in range(3)]
     fir, iir = dev.FirStream(h, C), dev.SosStream(sos, C)
-    fo = torch.empty((C, CHUNK), dtype=torch.float64, device="cuda")
-    fwd = [torch.empty_like(fo) for _ in range(3)]
-    y = torch.empty_like(fo)
+    lag = dev.chain_zp_lag(fir, iir)
+    ys = [torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda") for _ in range(4)]
     iir.set_state_scaled(ring[0], 0)
+    dev.chain_zp_open(fir, iir, 0)
 
     def step(k):
-        fir.push(ring[k % 3], 0, out=fo)
-        if k < 2:
-            iir.forward(fo, out=fwd[k % 3])
-        else:
-            iir.step(fo, fwd[(k - 2) % 3], fwd[(k - 1) % 3], f_out=fwd[k % 3], y_out=y)
+        dev.chain_zp_step(fir, iir, ring[k % 3], out=ys[k % 4][:, :CHUNK - lag], tail=ys[(k - 1) % 4][:, CHUNK - lag:])
+        if k >= 2:
+            dev.chain_zp_seal(fir, iir, ys[(k - 2) % 4], (k - 2) * CHUNK, 0, CHUNK)
 
-    for k in range(4):
-        step(k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(4, 4 + steps):
-        step(k)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = timed(step, steps, warm)
     fir.close()
     iir.close()
-    return {"channels": C, "chunksize": CHUNK, "ms_per_chunk": dt * 1e3,
-            "Gsamples_s": C * CHUNK / dt / 1e9, "chain_TBps": 48 * C * CHUNK / dt / 1e12}
+    return dt, 48
+
+
+def fir_only(C, steps=24, warm=6):
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev
+    h = sps.firwin(1024, 0.2)
+    ring = [dev.synth_normal(C, CHUNK, seed=0, n0=k * CHUNK) for k in range(3)]
+    fir = dev.FirStream(h, C)
+    out = torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda")
+    dt = timed(lambda k: fir.push(ring[k % 3], 0, out=out), steps, warm)
+    fir.close()
+    return dt, 16
+
+
+def welch(C, steps=24, warm=6):
+    import scipy.signal as sps
+    from openseize_amd import _device as dev
+    from openseize_amd import _lib
+    win = sps.get_window("hann", 4096)
+    ring = [dev.synth_normal(C, CHUNK, seed=0, n0=k * CHUNK) for k in range(3)]
+    spec = dev.SpecStream(4096, 4096, 2048, win, 1.0 / (4096.0 * float((win ** 2).sum())), "constant",
+                          _lib.SPEC_PSD_MEAN, C)
+    dt = timed(lambda k: spec.push(ring[k % 3]), steps, warm)
+    spec.close()
+    return dt, 8
 
 
 if __name__ == "__main__":
-    for C, CHUNK in ((16, 1 << 20), (32, 1 << 20), (64, 1 << 20), (128, 1 << 20), (256, 1 << 20),
-                     (512, 1 << 20), (1024, 1 << 19), (256, 1 << 18), (256, 1 << 16), (256, 1 << 22)):
-        print(json.dumps(run(C, CHUNK)), flush=True)
+    rows = []
+    for name, fn in (("chain", chain), ("fir", fir_only), ("welch", welch)):
+        for C in (4, 8, 16, 32, 64, 128, 256):
+            try:
+                dt, bps = fn(C)
+            except Exception as exc:      # a workload this build does not offer in that form
+                print(json.dumps({"workload": name, "channels": C, "error": str(exc)[:200]}), flush=True)
+                continue
+            rows.append({"workload": name, "channels": C, "chunksize": CHUNK, "ms_per_chunk": dt * 1e3,
+                         "Gsamples_s": C * CHUNK / dt / 1e9, "algorithmic_TBps": bps * C * CHUNK / dt / 1e12})
+    base = {r["workload"]: r["Gsamples_s"] for r in rows if r["channels"] == 256}
+    for r in rows:
+        r["rel_256"] = r["Gsamples_s"] / base[r["workload"]] if r["workload"] in base else None
+        print(json.dumps(r), flush=True)

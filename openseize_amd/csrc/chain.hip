@@ -223,7 +223,6 @@ static int chain_forward_impl(osz_fir_t fir, osz_sos_t sos, const double *x, int
         const int64_t npairs = n / pair;
         const int64_t pre = (sos->warm_len + wm1 + pair - 1) / pair;
         int64_t nruns = 512 / fir->nch;
-        if (const char *e = getenv("OSZ_CHAIN_WGS")) nruns = atoi(e) / fir->nch;   // tuning knob
         if (nruns < 1) nruns = 1;
         if (pre > 0 && nruns > npairs / (4 * pre)) nruns = npairs / (4 * pre);
         if (nruns < 1) nruns = 1;
@@ -232,10 +231,8 @@ static int chain_forward_impl(osz_fir_t fir, osz_sos_t sos, const double *x, int
             int rc = sos_tables_for(sos, 2 * nr, &dsec);
             if (rc) return rc;
             const double *ltab = nullptr;
-            if (!(getenv("OSZ_CHAIN_V2") && atoi(getenv("OSZ_CHAIN_V2")) == 0)) {
-                rc = sos_lane_table_for(sos, 2 * nr, &ltab);
-                if (rc) return rc;
-            }
+            rc = sos_lane_table_for(sos, 2 * nr, &ltab);     // null for more than 8 sections
+            if (rc) return rc;
             // an even head keeps the 16-byte alignment of the rows
             head = n - npairs * pair;
             if (head & 1) head = 0;

@@ -301,7 +301,6 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
     // and its seam) as long as about 3/4 of the 512 workgroup slots stay busy --
     // measured at 16..256 channels, runs of an even number of blocks
     int64_t R = (nblocks * h->nch) / 384;
-    if (const char *e = getenv("OSZ_FIR_R")) R = atoi(e);   // tuning knob: blocks per run
     if (R > 32) R = 32;
     if (R < 2) R = 2;
     R &= ~1LL;
@@ -386,16 +385,10 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
         // (benchmarks/check_async_regions.py on the assembly of THIS build;
         // tests/test_fir_async.py fails when the table and the assembly disagree).
         static const int kDefaultPf[8] = OSZ_FIR_PF_TABLE;
-        static int pf_env = -2;
-        if (pf_env == -2) {
-            const char *e = getenv("OSZ_FIR_PF");
-            pf_env = e ? atoi(e) : -1;
-        }
         const int nr = pt.step / 256;
-        const int pf = pf_env >= 0 ? pf_env : kDefaultPf[nr - 8];
+        const int pf = kDefaultPf[nr - 8];
         const kern_t *kerns = pf == 2 ? kerns2 : pf == 1 ? kerns1 : kerns0;
         size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS;
-        if (const char *e = getenv("OSZ_FIR_LDS_PAD")) lds += (size_t)atoi(e) * 1024;   // occupancy experiments
         OSZ_DYN_LDS(kerns[nr - 8], lds);
         KernelTimer kt("fir_oa", st);
         hipLaunchKernelGGL(kerns[nr - 8], dim3((unsigned)nruns, h->nch), dim3(256), lds, st, a);

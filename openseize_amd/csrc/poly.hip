@@ -389,11 +389,7 @@ int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n, int fin
             static const kern_t kerns2[2][2] = {
                 {poly_block_kernel<true, 128, 2>, poly_block_kernel<true, 64, 2>},
                 {poly_block_kernel<true, 128, 4>, poly_block_kernel<true, 64, 4>}};
-            static int eg_on = -1;
-            if (eg_on < 0) {
-                const char *e = getenv("OSZ_POLY_EG");
-                eg_on = e ? atoi(e) : 2;
-            }
+            const int eg_on = 2;        // two phase groups per workgroup (four measured no faster)
             const int eg = (h->L == 1 && h->nt <= 128) ? (eg_on >= 4 && h->M >= 4 ? 4 : eg_on >= 2 && h->M >= 2 ? 2 : 1) : 1;
             const bool split = eg > 1;
             const kern_t kern = split ? kerns2[eg == 4 ? 1 : 0][h->nt == 128 ? 0 : 1]

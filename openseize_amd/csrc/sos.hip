@@ -893,25 +893,10 @@ __global__ __launch_bounds__(NW * 64, 3) void sos_dual2_kernel(
 // OSZ_SOS_PF=1: request the next tile's first half into registers between the two
 // output halves (A/B knob; measured SLOWER, 1.88 ms against 1.76 ms for the dual
 // launch: the 32 extra live registers push the kernel into scratch spills)
-static bool sos_pf() {
-    static int pf = -1;
-    if (pf < 0) {
-        const char *e = getenv("OSZ_SOS_PF");
-        pf = (e && atoi(e) == 1) ? 1 : 0;
-    }
-    return pf == 1;
-}
+static constexpr bool sos_pf() { return false; }
 
-// OSZ_SOS_NANFIX=0: time segments as they were before the NaN reach was handled
 // (sos_tile.h) -- A/B knob for tests/test_gpu_nonfinite.py, which fails with it
-bool sos_nanfix() {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("OSZ_SOS_NANFIX");
-        on = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return on == 1;
-}
+bool sos_nanfix() { return true; }
 
 static bool sos_rows_aligned16(const SosArgs &a) {
     auto ok = [](const void *p, int64_t ld) {
@@ -1135,14 +1120,7 @@ static int sos_launch_one(const SosArgs &a, hipStream_t st) {
 // lean bodies (no register prefetch, half-tile staging) at three workgroups
 // per CU: default on (measured 3-5 % faster); OSZ_SOS_LEAN=0 selects the
 // prefetching bodies at two workgroups per CU
-static bool sos_lean() {
-    static int lean = -1;
-    if (lean < 0) {
-        const char *e = getenv("OSZ_SOS_LEAN");
-        lean = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return lean == 1;
-}
+static constexpr bool sos_lean() { return true; }
 
 // whole-tile pass, cut into time segments when there are too few channels to
 // fill the chip (see sos_split_kernel)
@@ -1150,11 +1128,7 @@ static bool sos_lean() {
 static int64_t sos_plan_segments(const SosArgs &a, int64_t tile, int64_t warm_len) {
     const int64_t ntiles = a.n / tile, pre_tiles = warm_len / tile;
     int64_t nseg = 1;
-    static int target_wgs = 0;   // tuning knob OSZ_SOS_WGS (default: 2 or, lean, 3 workgroups per CU)
-    if (!target_wgs) {
-        const char *e = getenv("OSZ_SOS_WGS");
-        target_wgs = (e && atoi(e) > 0) ? atoi(e) : (sos_lean() ? 768 : 512);
-    }
+    const int target_wgs = sos_lean() ? 768 : 512;   // three (lean bodies) or two workgroups per CU
     // in place (y aliases x) the pre-roll of segment s would read what segment
     // s - 1 is writing: one workgroup per channel then (it reads a tile before
     // it writes it)
@@ -1326,12 +1300,8 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     OSZ_REQUIRE(nch >= 1, "osz_sos_create: nch=%d must be positive", nch);
     for (int s = 0; s < nsec; ++s)
         OSZ_REQUIRE(sos[6 * s + 3] == 1.0, "sos[:, 3] should be all ones (section %d)", s);
-    // kernel geometry (tuning knobs: OSZ_SOS_T = 16|32, OSZ_SOS_NW = 4|8|16)
-    int T = kSosT, NW = kSosNW;
-    if (const char *e = getenv("OSZ_SOS_T")) T = atoi(e);
-    if (const char *e = getenv("OSZ_SOS_NW")) NW = atoi(e);
-    OSZ_REQUIRE((T == 32 && (NW == 4 || NW == 8)) || (T == 16 && (NW == 8 || NW == 4)),
-                "osz_sos_create: unsupported OSZ_SOS_T=%d / OSZ_SOS_NW=%d", T, NW);
+    // kernel geometry: 32 samples per lane, four waves per workgroup
+    const int T = kSosT, NW = kSosNW;
     std::vector<SosSection> secs(nsec);
     for (int s = 0; s < nsec; ++s) build_section(sos + 6 * s, secs[s], T);
     osz_sos_s *p = new osz_sos_s();
@@ -1363,12 +1333,9 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     p->spec = nullptr;
     p->zp = nullptr;
     p->touch = 0;
-    if (const char *e = getenv("OSZ_SOS_TOUCH")) p->touch = atoi(e);
     {
-        // the trimmed lean body (sos_body2): T = 32, NW = 4, up to 8 sections;
-        // OSZ_SOS_V2=0 keeps the first lean body (A/B runs)
-        const char *e = getenv("OSZ_SOS_V2");
-        if (T == 32 && NW == 4 && nsec <= kSos2MaxSec && !(e && atoi(e) == 0)) {
+        // the trimmed lean body (sos_body2): T = 32, NW = 4, up to 8 sections
+        if (T == 32 && NW == 4 && nsec <= kSos2MaxSec) {
             std::vector<double> tab((size_t)nsec * 4 * kSos2Tab);
             for (int s = 0; s < nsec; ++s) build_lane_table(sos + 6 * s, T, tab.data() + (size_t)s * 4 * kSos2Tab);
             OSZ_HIP(hipMalloc(&p->dtab2, tab.size() * sizeof(double)));
@@ -1628,7 +1595,6 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
         // two-workgroups-per-CU body and lost 7 %)
         int nseg = (768 + 2 * h->nch - 1) / (2 * h->nch);
         if (nseg < 4) nseg = 4;
-        if (const char *e = getenv("OSZ_SOS_DUAL_SEGS")) nseg = atoi(e);   // tuning knob
         const int64_t tmin = (nx < na ? nx : na) / tile;
         if (nseg > tmin / 4) nseg = (int)(tmin / 4);
         if (nseg >= 2) {

@@ -886,7 +886,6 @@ static int specmix_launch_nt(osz_spec_s *h, const mix::Args &a, hipStream_t st) 
 static int specmix_run(osz_spec_s *h, const double *src, int64_t ld, void *out, int64_t nseg,
                        hipStream_t st) {
     int64_t R = (nseg * h->nch) / 2048;   // segments per run
-    if (const char *e = getenv("OSZ_SPEC_R")) R = atoi(e);
     if (R > 64) R = 64;
     if (R < 1) R = 1;
     const int64_t nruns = (nseg + R - 1) / R;
@@ -952,7 +951,6 @@ static int spec8_run(osz_spec_s *h, const double *src, int64_t ld, void *out, in
     // runs: enough workgroups for a few rounds of the chip, long enough that the
     // per-run set-up (twiddles, window, partial sums) stays small
     int64_t R = (npairs * h->nch) / 2048;
-    if (const char *e = getenv("OSZ_SPEC_R")) R = atoi(e);
     if (R > 64) R = 64;
     if (R < 1) R = 1;
     const int64_t nruns = (npairs + R - 1) / R;
@@ -1165,7 +1163,6 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
         // run length: long runs (a workgroup reloads its twiddles and window and
         // publishes partial sums once per run) while ~512 workgroups remain
         int64_t R = (npairs * h->nch) / 512;
-        if (const char *e = getenv("OSZ_SPEC_R")) R = atoi(e);   // tuning knob: pairs per run
         if (R > 32) R = 32;
         if (R < 1) R = 1;
         const int64_t nruns = (npairs + R - 1) / R;
