@@ -21,9 +21,10 @@
 //     -nu backwards from its first sample + 4095      (the wrapped left tail leaves the window)
 //     +nu backwards from its first sample - 1         (and lands in front of the block)
 // The last one reaches into rows the PREVIOUS block has produced: the last R rows of
-// block b of a pair wait in registers for the next pair's fit, a run ends with one more
-// pair (and starts one early, as in chain_spec.hip), and a chunk's last 256 R samples
-// wait in `held` for the next chunk: the output stream runs L = 256 R samples late
+// block b of a pair wait in registers for the next pair's fit; a run starts one pair early
+// (as in chain_spec.hip) and stores the last R rows of that pair -- its block b depends on
+// nothing before it -- for the run before it; a chunk's last 256 R samples wait in `held`
+// for the next chunk: the output stream runs L = 256 R samples late
 // (osz_chain_zp_lag).  Nothing else crosses a chunk: `carry` is the same kind of sequence
 // as in chain_spec.hip (what the outputs behind the chunk would be if the input stopped).
 //
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     const int64_t p0 = ((int64_t)run * g.W) / g.nruns;
     const int64_t p1 = ((int64_t)(run + 1) * g.W) / g.nruns;
     const int64_t first = run == 0 ? 0 : p0 - 1;
-    const int64_t lastf = run < g.nruns - 1 ? p1 : p1 - 1;
+    const int64_t lastf = p1 - 1;
 
     FirPair<NR, 16> P{a, t, a.wlen - 1, xr, yr, 0, cube_lds};
     fft::cube::tw_load(t, a.tb, P.tw1, P.tw2);
@@ -282,7 +283,9 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
                 }
         } else if (p > first) {
             // the previous pair's last R rows of block b, complete now
-            if (p - 1 >= p0 && p - 1 < p1) {
+            // (also those of the pair a run starts early with: that pair's block b depends on
+            // nothing before it, and the run before this one leaves its last R rows to us)
+            {
                 const int64_t ob = o - S + tt;
                 if (o - S + L >= n0) {
 #pragma unroll
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     if (g.nruns > 1 && g.segcnt) {
         const int64_t pairlen = 2 * (int64_t)S, Wp = g.W;
         const int nr_ = g.nruns;
-        // the last stored sample of run q: its last pair's held rows, L samples late
+        // the last stored sample of run q: row NR - R - 1 of its last pair's block b, L samples late
         __syncthreads();
         int last = 0;
         if (threadIdx.x == 0) {
@@ -429,14 +432,14 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             __threadfence();
             int badrun = nr_;
             for (int s = nr_ - 2; s >= 0; --s) {
-                const int64_t e = (((int64_t)(s + 1) * Wp) / nr_) * pairlen + L;
+                const int64_t e = (((int64_t)(s + 1) * Wp) / nr_) * pairlen;
                 const unsigned long long bits = __hip_atomic_load(
                     reinterpret_cast<const unsigned long long *>((e - 1 < n0 ? y0r : yr) + e - 1), __ATOMIC_RELAXED,
                     __HIP_MEMORY_SCOPE_AGENT);
                 if (sos_not_finite(__longlong_as_double((long long)bits))) badrun = s;
             }
             if (badrun < nr_) {
-                const int64_t from = (((int64_t)(badrun + 1) * Wp) / nr_) * pairlen + L;
+                const int64_t from = (((int64_t)(badrun + 1) * Wp) / nr_) * pairlen;
                 if (from < n0) sos_fill_nan(y0r + from, n0 - from);
                 sos_fill_nan(yr + (from < n0 ? n0 : from), n - (from < n0 ? n0 : from));
                 sos_fill_nan(ho, L);

@@ -226,8 +226,8 @@ def tables_zp(exe, taps, sos, forgets=True):
 class ModelZp:
     """The dataflow of chain_zp_kernel on one channel with the tables of the C++ build:
     whole pairs (overlap add, four forward and four backward bursts, the last R rows of
-    block b held back until the next pair's block a has been fitted), runs with a pre-roll
-    and a post-roll pair, the opening pair (carry, held samples of the previous chunk), the
+    block b held back until the next pair's block a has been fitted), runs that start one
+    pair early and store that pair's held rows for the run before, the opening pair (carry, held samples of the previous chunk), the
     generic closing pair, outputs delayed by L = 256 R samples."""
 
     def __init__(self, T):
@@ -285,7 +285,7 @@ class ModelZp:
         for run in range(nruns):
             p0, p1 = run * W // nruns, (run + 1) * W // nruns
             first = p0 if run == 0 else p0 - 1
-            lastf = p1 if run < nruns - 1 else p1 - 1
+            lastf = p1 - 1
             cr = np.zeros((D, 256))
             mu_pb = nu_pb = np.zeros(self.NM, complex)
             held = None
@@ -312,10 +312,11 @@ class ModelZp:
                     A += ci[:S].reshape(NR, 256)
                     B += ci[S:].reshape(NR, 256)
                 if held is not None:
+                    # (also the rows of the pair a run starts early with: its block b depends
+                    # on nothing before it, and the run before leaves them to this one)
                     for r in range(R):
                         held[r] += Bk(nu_a, r)
-                        if p0 <= p - 1 < p1:
-                            put((p - 1) * pair + S + 256 * (NR - 1 - r) + t, held[r])
+                        put((p - 1) * pair + S + 256 * (NR - 1 - r) + t, held[r])
                 elif p == 0:
                     for rr in range(R):
                         y[256 * rr + t] = held_in[256 * rr + t] + Bk(nu_a, R - 1 - rr)
