@@ -51,7 +51,7 @@ struct ZpArgs {
     int64_t W;                 // whole pairs on the fast path
     int nruns;
     int la, lb;                // lengths of the closing pair's two blocks
-    int R, nh;                 // burst rows; fit samples at either end of row 15
+    int R, Rf, nh;             // burst rows backwards (and table stride) / forwards; fit samples at either end of row 15
     const double *M;           // [4 NM][2 nh]
     const double *P;           // [20][NM][2]
     const double *Lrow;        // [R][NM][2]
@@ -135,7 +135,7 @@ template <int NR, int NM>
 __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     constexpr int D = 16 - NR, S = 256 * NR;
     extern __shared__ fft::cube::C2 cube_lds[];
-    const int R = g.R, nh = g.nh, ns = 2 * nh;
+    const int R = g.R, Rf = g.Rf, nh = g.nh, ns = 2 * nh;
     double *xl = reinterpret_cast<double *>(cube_lds) + 2 * fft::cube::SLOTS;   // behind the cube
     double *fitbuf = xl;                               // [2 blk][2 nh]
     double *kapA = fitbuf + 2 * ns;                    // [4 amp][R][NM][2]: this pair's mu_a mu_b nu_a nu_b
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             zp_powers<NM>(ptab, tt, Pr, Pi);
 #pragma unroll
             for (int r = 0; r < kSpecRMax; ++r) {
-                if (r < R && r < D) {
+                if (r < Rf && r < D) {
                     const double ca = zp_dot<NM>(kap + ((0 * R + r) * NM) * 2, Pr, Pi);   // mu_a
                     const double cb = zp_dot<NM>(kap + ((1 * R + r) * NM) * 2, Pr, Pi);   // mu_b
                     re[r] -= ca;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
                                    bad ? spec_qnan() : held[r] + zp_dot<NM>(tab + (r * NM) * 2, Pbr, Pbi));
                 continue;
             }
-            for (int r = 0; r < R; ++r) {
+            for (int r = 0; r < (fwd ? Rf : R); ++r) {
                 const double cs = sg * (fwd ? zp_dot<NM>(tab + (r * NM) * 2, Pfr, Pfi)
                                             : zp_dot<NM>(tab + (r * NM) * 2, Pbr, Pbi));
                 const int i = fwd ? off + 256 * r + tt : off - 256 * r - (255 - tt);
@@ -486,7 +486,7 @@ struct ChainZp {
     osz_fir_s *fir = nullptr;
     osz_sos_s *sos = nullptr;
     bool eligible = false, open = false;
-    int NR = 0, NM = 0, R = 0, nh = 0;
+    int NR = 0, NM = 0, R = 0, Rf = 0, nh = 0;
     double *dH = nullptr, *dM = nullptr, *dP = nullptr, *dL = nullptr;
     double *dcarry[2] = {nullptr, nullptr}, *dheld[2] = {nullptr, nullptr};
     int cur = 0;
@@ -569,6 +569,7 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
                 s->NR = T.NR;
                 s->NM = T.NM;
                 s->R = T.R;
+                s->Rf = T.Rf;
                 s->nh = T.nh;
                 s->eligible = true;
             }
@@ -621,6 +622,7 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
     g.la = (int)std::min<int64_t>(nlast, S);
     g.lb = (int)(nlast - g.la);
     g.R = s->R;
+    g.Rf = s->Rf;
     g.nh = s->nh;
     g.M = s->dM;
     g.P = s->dP;

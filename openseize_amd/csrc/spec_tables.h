@@ -293,19 +293,27 @@ inline Tables build(const double *taps, int wlen, const double *sos, int nsec, b
 //         l = 0 .. nh-1, then 256-nh .. 255 of row 15
 //   P     [20][NM][2]  lambda^(32 i), i < 8; lambda^(4 i), i < 8; lambda^i, i < 4
 //   L     [5][NM][2]   lambda^(256 r)
-//   R     burst rows, from both tails of the two-sided composite impulse response
-// NR is the largest block height whose guard rows hold the bursts (R <= D, D + R <= NR).
+//   R, Rf burst rows backwards / forwards: over how many rows of 256 samples the left / right
+//         tail of the two-sided composite impulse response exceeds kTailTol of its norm.
+//         The truncation is then an order of magnitude below the rounding noise of the
+//         4096-point transform itself (1e-14 of the output scale, measured); the right tail
+//         has the window's guard rows in front of it and is the shorter one (Rf <= R).
+// NR is the largest block height whose guard rows hold the bursts (R <= D, D + Rf <= NR).
+constexpr ld_t kTailTol = 1e-15L;
+
 struct TablesZp {
     bool eligible = false;
-    int NR = 0, NM = 0, nm = 0, R = 0, nh = 0;
+    int NR = 0, NM = 0, nm = 0, R = 0, Rf = 0, nh = 0;
     double fit_ratio = 0.0;
     std::vector<double> H, M, P, L;
 };
 
-// lds_budget: bytes the kernel may use behind the cube (two workgroups per CU); the fit
-// reads as many samples as its matrix then leaves room for
+// lds_budget: bytes the kernel may use behind the cube; the fit reads as many samples as its
+// matrix then leaves room for.  Two workgroups share a CU's 160 KB only up to 80 896 bytes
+// each (measured: at 81 152 the second one no longer fits and the kernel takes 2.4 instead of
+// 1.8 ms), i.e. 15 360 behind the 64 KB cube.
 inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int nsec, bool forgets,
-                         int lds_budget = 16384) {
+                         int lds_budget = 15360) {
     TablesZp T;
     if (wlen < 2 || !forgets) return T;
     std::vector<Mode> modes;
@@ -355,19 +363,20 @@ inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int ns
     const ld_t tot = sqrtl(right2[0]);
     int NRmax = (3841 - wlen) / 256;
     if (NRmax > 15) NRmax = 15;
-    int NR = 0, R = 0;
+    int NR = 0, R = 0, Rf = 0;
     for (int cand = NRmax; cand >= 8 && !NR; --cand) {
         const int S = 256 * cand, D = 16 - cand;
-        for (int r = 1; r <= kRMax; ++r) {
+        int rb = 0, rf = 0;
+        for (int r = 1; r <= kRMax && !(rb && rf); ++r) {
             const int ir = Lg + kN + 256 * r - S + 1, il = Lg - 256 * r;
             if (ir >= 2 * Lg || il < 0) break;
-            if (sqrtl(right2[ir]) <= 3e-18L * tot && sqrtl(left2[il]) <= 3e-18L * tot) {
-                if (r <= D && D + r <= cand) {
-                    NR = cand;
-                    R = r;
-                }
-                break;
-            }
+            if (!rf && sqrtl(right2[ir]) <= kTailTol * tot) rf = r;
+            if (!rb && sqrtl(left2[il]) <= kTailTol * tot) rb = r;
+        }
+        if (rb && rf && rf <= rb && rb <= D && D + rf <= cand) {
+            NR = cand;
+            R = rb;
+            Rf = rf;
         }
     }
     if (!NR) return T;
@@ -459,6 +468,7 @@ inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int ns
     T.NM = NM;
     T.nm = nm;
     T.R = R;
+    T.Rf = Rf;
     T.nh = nh;
     T.eligible = true;
     return T;

@@ -23,8 +23,8 @@ int main(int argc, char **argv) {
         const osz::spec::TablesZp T = osz::spec::build_zp(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0);
         f = fopen(argv[2], "wb");
         if (!f) return 2;
-        const int32_t out[6] = {T.eligible, T.NR, T.NM, T.nm, T.R, T.nh};
-        fwrite(out, sizeof(int32_t), 6, f);
+        const int32_t out[8] = {T.eligible, T.NR, T.NM, T.nm, T.R, T.nh, T.Rf, 0};
+        fwrite(out, sizeof(int32_t), 8, f);
         fwrite(&T.fit_ratio, sizeof(double), 1, f);
         for (const std::vector<double> *v : {&T.H, &T.M, &T.P, &T.L}) {
             const int64_t n = (int64_t)v->size();

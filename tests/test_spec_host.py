@@ -212,14 +212,14 @@ def tables_zp(exe, taps, sos, forgets=True):
             f.write(sos.tobytes())
         subprocess.check_call([exe, fin, fout, "zp"])
         raw = open(fout, "rb").read()
-    elig, NR, NM, nm, R, nh = struct.unpack_from("<iiiiii", raw, 0)
-    ratio, = struct.unpack_from("<d", raw, 24)
-    pos, arrs = 32, []
+    elig, NR, NM, nm, R, nh, Rf, _ = struct.unpack_from("<iiiiiiii", raw, 0)
+    ratio, = struct.unpack_from("<d", raw, 32)
+    pos, arrs = 40, []
     for _ in range(4):
         n, = struct.unpack_from("<q", raw, pos)
         arrs.append(np.frombuffer(raw, np.float64, n, pos + 8).copy())
         pos += 8 + 8 * n
-    return dict(eligible=bool(elig), NR=NR, NM=NM, nm=nm, R=R, nh=nh, ratio=ratio, H=arrs[0], M=arrs[1],
+    return dict(eligible=bool(elig), NR=NR, NM=NM, nm=nm, R=R, Rf=Rf, nh=nh, ratio=ratio, H=arrs[0], M=arrs[1],
                 P=arrs[2], L=arrs[3])
 
 
@@ -231,7 +231,7 @@ class ModelZp:
     generic closing pair, outputs delayed by L = 256 R samples."""
 
     def __init__(self, T):
-        self.NR, self.NM, self.R, self.nh = T["NR"], T["NM"], T["R"], T["nh"]
+        self.NR, self.NM, self.R, self.Rf, self.nh = T["NR"], T["NM"], T["R"], T["Rf"], T["nh"]
         self.S, self.D, self.L = 256 * self.NR, 16 - self.NR, 256 * T["R"]
         H = T["H"].reshape(N, 2)
         self.Hc = (H[:, 0] + 1j * H[:, 1]) * N
@@ -255,13 +255,13 @@ class ModelZp:
         y = win[3840 + self.lsel]
         return self.Mmu @ y, self.Mnu @ y
 
-    def burst(self, amp, e):
-        ok = (e >= 0) & (e < 256 * self.R)
+    def burst(self, amp, e, rows):
+        ok = (e >= 0) & (e < 256 * rows)
         ee = np.where(ok, e, 0)
         return np.where(ok, np.real((self.Lr[ee >> 8] * self.P[ee & 255]) @ amp), 0.0)
 
     def chunk(self, x, carry_in, held_in, nruns):
-        n, S, NR, D, R, L = len(x), self.S, self.NR, self.D, self.R, self.L
+        n, S, NR, D, R, L, Rf = len(x), self.S, self.NR, self.D, self.R, self.L, self.Rf
         pair = 2 * S
         npw = n // pair
         rem = n - npw * pair
@@ -278,8 +278,8 @@ class ModelZp:
             m2 = (~m) & (i < n)
             held_out[q[m2] - n] = v[m2]
 
-        F = lambda amp, r: self.burst(amp, 256 * r + t)             # forward burst, row r
-        Bk = lambda amp, r: self.burst(amp, 256 * r + 255 - t)      # backward burst, r-th row down
+        F = lambda amp, r: self.burst(amp, 256 * r + t, Rf)            # forward burst, row r (Rf rows)
+        Bk = lambda amp, r: self.burst(amp, 256 * r + 255 - t, R)      # backward burst, r-th row down (R rows)
         nruns = max(1, min(nruns, W))
         carry_out = None
         for run in range(nruns):
@@ -341,9 +341,9 @@ class ModelZp:
                 acc[:N] += wa
                 acc[la:la + N] += wb
                 for amp, off in ((mu_pb, 256 * D), (-mu_a, 0), (-mu_b, la), (mu_a, N), (mu_b, la + N)):
-                    acc += self.burst(amp, i - off)
+                    acc += self.burst(amp, i - off, Rf)
                 for amp, e0 in ((-nu_pb, 256 * D - 1), (-nu_a, N - 1), (-nu_b, la + N - 1), (nu_b, la - 1)):
-                    acc += self.burst(amp, e0 - i)
+                    acc += self.burst(amp, e0 - i, R)
                 put(o + i[:lc], acc[:lc])
                 carry_out = np.zeros(7680)
                 seg = acc[lc:]
@@ -367,8 +367,8 @@ def test_zero_phase_tables_and_block_algorithm(exe, name, ntaps, sos):
     taps = sps.firwin(ntaps, 0.2)
     T = tables_zp(exe, taps, sos)
     assert T["eligible"], name
-    NR, R = T["NR"], T["R"]
-    assert 8 <= NR <= min((3841 - ntaps) // 256, 15) and 1 <= R <= min(16 - NR, 2 * NR - 16, 5)
+    NR, R, Rf = T["NR"], T["R"], T["Rf"]
+    assert 8 <= NR <= min((3841 - ntaps) // 256, 15) and 1 <= Rf <= R <= min(16 - NR, 5) and 16 - NR + Rf <= NR
     w, h = sps.sosfreqz(sos, worN=N, whole=True)
     Hc = np.fft.fft(taps, N) * np.abs(h) ** 2 / N
     H = T["H"].reshape(N, 2)
