@@ -87,8 +87,10 @@ def main():
                 traffic["fir_oa"] = hbm
             elif "sos_kernel" in name and "false, false" in name and hbm > 1e9:
                 traffic["sos_fwd"] = hbm
-            elif "chain_kernel" in name and hbm > 1e9:
+            elif ("chain_kernel" in name or "chain_spec_kernel" in name) and hbm > 1e9:
                 traffic["chain_fwd"] = hbm
+            elif "chain_zp_kernel" in name and hbm > 1e9:
+                traffic["chain_zp"] = hbm
             elif "sos_split2_kernel<32, 4, true" in name and hbm > 1e9:
                 traffic["sos_bwd_split"] = hbm
     if "chain_fwd" in traffic and "sos_bwd_split" in traffic:
