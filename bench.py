@@ -293,12 +293,18 @@ def roofline_of(kernels, samples_per_step):
 def run_chain(args, R, h, sos):
     torch = R.torch
     if R.dry:
+        # no kernels: the partition of the channels, the barriers and the max-over-ranks timing
+        C, ch0 = chain_channels(args, R)
+        blocks = torch.zeros(R.world, 2, dtype=torch.int64)
+        blocks[R.rank, 0], blocks[R.rank, 1] = ch0, ch0 + C
+        if R.dist is not None:
+            R.dist.all_reduce(blocks)
         R.barrier()
         t0 = time.perf_counter()
         time.sleep(1e-3 * args.steps)
         elapsed = R.max_over_ranks(time.perf_counter() - t0)
         R.barrier()
-        return elapsed, {}, None, None
+        return elapsed, {}, None, {"channel_blocks": blocks.tolist()}
     from openseize_amd import _device as dev
     from openseize_amd import _lib
     lib = _lib.load()

@@ -175,6 +175,19 @@ def test_host_chain_stays_on_the_device_between_stages():
     y2 = np.concatenate(list(nm.oaconvolve(producer(y1, cs, -1), taps, -1, "same")), -1)
     y3 = np.concatenate(list(nm.polyphase_resample(producer(y2, cs, -1), 1, 5, fs, Kaiser, -1)), -1)
     assert got.shape == y3.shape and np.max(np.abs(got - y3)) < 1e-12 * np.max(np.abs(y3))
+    # OSZ_HOST_CHAIN=0: every stage hands ndarrays on, as the reference's generators do -- one
+    # upload per stage and chunk, the same numbers
+    import os
+    uploads.clear()
+    os.environ["OSZ_HOST_CHAIN"] = "0"
+    dev.HostPipe.upload = counting
+    try:
+        apart = np.concatenate(list(chain(x)[3]), -1)
+    finally:
+        dev.HostPipe.upload = plain_upload
+        del os.environ["OSZ_HOST_CHAIN"]
+    assert len(uploads) > 2 * -(-x.shape[1] // cs)
+    assert apart.shape == got.shape and np.max(np.abs(apart - got)) < 1e-12 * np.max(np.abs(got))
     # all resident
     xd = torch.from_numpy(x).cuda()
     res = torch.cat(list(chain(xd)[3]), -1)

@@ -119,6 +119,18 @@ def test_bench_launcher_world2_dry():
     assert out["config"]["parallelism"] == "channel-shard x2"
 
 
+def test_bench_strong_scaling_world3_dry():
+    """`bench.py --scaling strong`: the metric's 256 channels split channel_block-wise over the
+    ranks (32 per GPU at 8 ranks) instead of 256 per rank; `value` is the job's 256
+    channels over the slowest rank's time.  Three ranks on CPU (gloo), no kernels."""
+    out = _run_bench("--gpus", "3", "--steps", "2", "--warmup", "1", "--dry", "--scaling", "strong")
+    assert out["n_gpus"] == 3 and out["rccl_ranks"] == 3 and out["scaling"] == "strong"
+    assert out["channel_blocks"] == [[0, 86], [86, 171], [171, 256]]
+    assert abs(out["value"] - 256 * (1 << 20) * 2 / (out["ms_per_step"] * 2e-3) / 1e6) < 1e-6 * out["value"]
+    weak = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry")
+    assert weak["scaling"] == "weak" and weak["channel_blocks"] == [[0, 256], [256, 512]]
+
+
 def test_bench_under_torchrun_world2_dry():
     """The driver's launch line: torch.distributed.run starts the ranks."""
     import json
