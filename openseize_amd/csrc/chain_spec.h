@@ -2,7 +2,10 @@
 // forward cascade; chain_zp.hip: FIR -> forward -> backward cascade).
 #pragma once
 
+#include <vector>
+
 #include "common.h"
+#include "fft4096.h"
 #include "sos_tile.h"
 #include "spec_tables.h"
 
@@ -42,6 +45,18 @@ __device__ __forceinline__ void spec_seal(int *__restrict__ segcnt, double *__re
     const int64_t from = end_of(bad);
     sos_fill_nan(y + from, n - from);
     sos_fill_nan(carry_row, kSpecLdc);
+}
+
+// the composite spectrum in the order fft::cube2 leaves the bins in: [r][t] = H[bin(t, r)]
+inline std::vector<double> spec_permuted_spectrum(const std::vector<double> &H) {
+    std::vector<double> P(H.size());
+    for (int r = 0; r < 16; ++r)
+        for (int t = 0; t < 256; ++t) {
+            const int k = fft::cube2::bin(t, r);
+            P[2 * (256 * r + t)] = H[2 * k];
+            P[2 * (256 * r + t) + 1] = H[2 * k + 1];
+        }
+    return P;
 }
 
 }  // namespace osz

@@ -101,13 +101,13 @@ __global__ __launch_bounds__(256, 2) void chain_spec_kernel(SpecArgs g) {
     const int64_t p1 = ((int64_t)(run + 1) * g.W) / g.nruns;
     const int64_t ps = run == 0 ? 0 : p0 - 1;
 
-    FirPair<NR, HP> P{a, t, a.wlen - 1, xr, yr, 0, cube_lds};
-    fft::cube::tw_load(t, a.tb, P.tw1, P.tw2);
+    FirPair<NR, HP, 0, true> P{a, t, a.wlen - 1, xr, yr, 0, cube_lds};
+    fft::cube2::tw_load(t, a.tb, P.tw1, P.tw2);
     if (HP < 0) {
         // the composite spectrum resident in registers (else: requested per pair, FirPair::transform)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int k = t + 256 * fft::dr(r);
+            const int k = 256 * r + t;          // the spectrum is stored in cube2's bin order
             P.Hr[HP < 0 ? r : 0] = a.H[2 * k];
             P.Hi[HP < 0 ? r : 0] = a.H[2 * k + 1];
         }
@@ -440,7 +440,7 @@ static int spec_build(ChainSpec *s) {
         return OSZ_OK;
     };
     int rcu;
-    if ((rcu = up(&s->dH, T.H)) || (rcu = up(&s->dM, T.M)) || (rcu = up(&s->dP, T.P)) || (rcu = up(&s->dL, T.L)))
+    if ((rcu = up(&s->dH, spec_permuted_spectrum(T.H))) || (rcu = up(&s->dM, T.M)) || (rcu = up(&s->dP, T.P)) || (rcu = up(&s->dL, T.L)))
         return rcu;
     const size_t cb = sizeof(double) * (size_t)fir->nch * kSpecLdc;
     for (int q = 0; q < 2; ++q) {

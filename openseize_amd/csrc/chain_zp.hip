@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     const int64_t first = run == 0 ? 0 : p0 - 1;
     const int64_t lastf = p1 - 1;
 
-    FirPair<NR, 16> P{a, t, a.wlen - 1, xr, yr, 0, cube_lds};
-    fft::cube::tw_load(t, a.tb, P.tw1, P.tw2);
+    FirPair<NR, 16, 0, true> P{a, t, a.wlen - 1, xr, yr, 0, cube_lds};
+    fft::cube2::tw_load(t, a.tb, P.tw1, P.tw2);
 #pragma unroll
     for (int j = 0; j < D; ++j) P.cr[j] = 0.0;
     for (int i = t; i < R * NM * 2; i += 256) lrow[i] = g.Lrow[i];
@@ -564,7 +564,7 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
                     return OSZ_OK;
                 };
                 int rc;
-                if ((rc = up(&s->dH, T.H)) || (rc = up(&s->dM, T.M)) || (rc = up(&s->dP, T.P)) ||
+                if ((rc = up(&s->dH, spec_permuted_spectrum(T.H))) || (rc = up(&s->dM, T.M)) || (rc = up(&s->dP, T.P)) ||
                     (rc = up(&s->dL, T.L)))
                     return rc;
                 const int nch = fir->nch;

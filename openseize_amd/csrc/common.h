@@ -78,6 +78,14 @@ __device__ __forceinline__ double wave_sum63(double v) {
     return v;
 }
 
+// wave-private LDS hand-offs need no workgroup barrier: LDS executes one
+// wave's instructions in order; this only stops the compiler reordering them
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // rccl.hip: in-place all-reduce(sum) of `count` float64 / int64 elements over
 // the ranks of an ncclComm_t; RCCL is bound at run time (dlopen)
 int rccl_allreduce_sum(void *buf, size_t count, bool is_f64, void *comm, hipStream_t st);

@@ -289,5 +289,110 @@ OSZ_HD void i1(int t, double *re, double *im, const TwPow &w1, const C2 *L) {
 
 }  // namespace cube
 
+// ---- cube2: the same cube with the SECOND exchange inside a 16-lane row --------------
+// In `cube` a thread changes both of its coordinates at each exchange, so both exchanges
+// cross waves and cost a workgroup barrier.  Here the thread index keeps one coordinate
+// per exchange:
+//   pass 1  t = n0 + 16 n1   registers n2 -> k0      (as in cube: coalesced loads)
+//   pass 2  t = n0 + 16 k0   registers n1 -> k1      exchange 1: register <-> HIGH half of t
+//   pass 3  t = k1 + 16 k0   registers n0 -> k2      exchange 2: register <-> LOW half of t
+// Exchange 2 moves data among the 16 lanes that share t >> 4: one DPP row of one wave.  A wave
+// executes in lockstep, so its LDS writes are done for all its lanes once it has waited for
+// them: no workgroup barrier, and the four waves of a workgroup stop marching in step.  The
+// inverse mirrors it (exchange 2 first).  Two barriers per forward + inverse instead of four.
+// After pass 3 register r of thread t holds bin  k = (t >> 4) + 16 (t & 15) + 256 dr(r):
+// a caller that multiplies by a spectrum stores it in that order ([r][t], see bin()).
+//   slot(k0, m, l) = 256 k0 + 16 m + (l ^ m)
+// with views A (l = n0, m = n1 | k0 = 0..15), B (k0, l = n0 | m = n1, k1), C (k0, m = k1 | l = n0,
+// k2): lanes walk l in A and B (16 consecutive slots), m in C (l ^ m distinct): conflict free for
+// the b128 lane groups (tests/host/fft_host_check.cpp).
+namespace cube2 {
+
+using cube::C2;
+using cube::TwPow;
+using cube::tw_mul;
+constexpr int SLOTS = 4096;
+
+OSZ_HD int slot(int k0, int m, int l) { return 256 * k0 + 16 * m + (l ^ m); }
+OSZ_HD int slot_a(int t, int k0) { return slot(k0, t >> 4, t & 15); }          // t = n0 + 16 n1
+OSZ_HD int slot_b(int t, int m) { return slot(t >> 4, m, t & 15); }            // t = n0 + 16 k0
+OSZ_HD int slot_c(int t, int l) { return slot(t >> 4, t & 15, l); }            // t = k1 + 16 k0
+// bin held by register r of thread t after f3 (and expected there by i3)
+OSZ_HD int bin(int t, int r) { return (t >> 4) + 16 * (t & 15) + 256 * dr(r); }
+
+OSZ_HD void tw_load(int t, const Tables &tb, TwPow &w1, TwPow &w2) {
+    const int n0 = t & 15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = 1 << q;
+        w1.r[q] = tb.t1[(k * 256 + t) * 2];
+        w1.i[q] = tb.t1[(k * 256 + t) * 2 + 1];
+        w2.r[q] = tb.t2[(n0 * 16 + k) * 2];
+        w2.i[q] = tb.t2[(n0 * 16 + k) * 2 + 1];
+    }
+}
+
+OSZ_HD void f1(int t, double *re, double *im, const TwPow &w1, C2 *L) {
+    fwd16(re, im);
+    tw_mul<false>(re, im, w1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L[slot_a(t, dr(r))] = C2{re[r], im[r]};
+}
+
+OSZ_HD void f2(int t, double *re, double *im, const TwPow &w2, C2 *L) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const C2 v = L[slot_b(t, j)];
+        re[j] = v.re;
+        im[j] = v.im;
+    }
+    fwd16(re, im);
+    tw_mul<false>(re, im, w2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L[slot_b(t, dr(r))] = C2{re[r], im[r]};
+}
+
+OSZ_HD void f3(int t, double *re, double *im, const C2 *L) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const C2 v = L[slot_c(t, j)];
+        re[j] = v.re;
+        im[j] = v.im;
+    }
+    fwd16(re, im);
+}
+
+OSZ_HD void i3(int t, double *re, double *im, C2 *L) {
+    inv16(re, im);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) L[slot_c(t, j)] = C2{re[j], im[j]};
+}
+
+OSZ_HD void i2(int t, double *re, double *im, const TwPow &w2, C2 *L) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const C2 v = L[slot_b(t, dr(r))];
+        re[r] = v.re;
+        im[r] = v.im;
+    }
+    tw_mul<true>(re, im, w2);
+    inv16(re, im);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) L[slot_b(t, j)] = C2{re[j], im[j]};
+}
+
+OSZ_HD void i1(int t, double *re, double *im, const TwPow &w1, const C2 *L) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const C2 v = L[slot_a(t, dr(r))];
+        re[r] = v.re;
+        im[r] = v.im;
+    }
+    tw_mul<true>(re, im, w1);
+    inv16(re, im);
+}
+
+}  // namespace cube2
+
 }  // namespace fft
 }  // namespace osz

@@ -75,7 +75,10 @@ __host__ __device__ __forceinline__ int64_t fir_run_start(int64_t r, int64_t nbl
 // registers, -3.4 % --, twiddles loaded from the tables per pass (+13 %),
 // running the FIR of chunk k+1 beside the IIR step of chunk k on a second
 // stream (+5 %, benchmarks/overlap_probe.py).
-template <int NR, int HPRE, int PF = 0>
+// CUBE2: the transform on fft::cube2 -- its second exchange stays inside a 16-lane row, so two
+// of the four barriers per pair are wave-level fences -- with the spectrum stored in the
+// order that layout leaves the bins in ([r][t]: fft::cube2::bin).
+template <int NR, int HPRE, int PF = 0, bool CUBE2 = false>
 struct FirPair {
     static constexpr bool PF2 = PF == 2;   // PF = 1: samples ahead only; 2: spectrum ahead as well
     using C2 = fft::cube::C2;
@@ -181,28 +184,32 @@ struct FirPair {
         // thread index: hoisted out of the loop they would pin 33 registers
         int t = this->t;
         asm volatile("" : "+v"(t));
-        fft::cube::f1(t, re, im, tw1, L);
+        if (CUBE2) fft::cube2::f1(t, re, im, tw1, L);
+        else fft::cube::f1(t, re, im, tw1, L);
         OSZ_FSTAMP(1);   // sample loads landed + pass 1 + stores
         __syncthreads();
         OSZ_FSTAMP(2);   // barrier 1
-        fft::cube::f2(t, re, im, tw2, L);
+        if (CUBE2) fft::cube2::f2(t, re, im, tw2, L);
+        else fft::cube::f2(t, re, im, tw2, L);
         // HPRE > 0: that many filter-spectrum bins are requested before the barrier
         double hr[HPRE > 0 ? HPRE : 1], hi[HPRE > 0 ? HPRE : 1];
 #pragma unroll
         for (int r = 0; r < ((HPRE > 0 && !(PF2 && REQ)) ? HPRE : 0); ++r) {
-            const int k = t + 256 * fft::dr(r);
+            const int k = CUBE2 ? 256 * r + t : t + 256 * fft::dr(r);
             hr[r] = a.H[2 * k];
             hi[r] = a.H[2 * k + 1];
         }
         OSZ_FSTAMP(3);   // pass 2
-        __syncthreads();
+        if (CUBE2) wave_lds_fence();
+        else __syncthreads();
         OSZ_FSTAMP(4);   // barrier 2
-        fft::cube::f3(t, re, im, L);
+        if (CUBE2) fft::cube2::f3(t, re, im, L);
+        else fft::cube::f3(t, re, im, L);
         OSZ_FSTAMP(5);   // pass 3
         if (PF2 && REQ) wait_spectrum();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int k = t + 256 * fft::dr(r);
+            const int k = CUBE2 ? 256 * r + t : t + 256 * fft::dr(r);
             if (PF2 && REQ) fft::cube::cmul(re[r], im[r], Hn[PF2 ? r : 0].x, Hn[PF2 ? r : 0].y);
             else if (HPRE < 0) fft::cube::cmul(re[r], im[r], Hr[HPRE < 0 ? r : 0], Hi[HPRE < 0 ? r : 0]);
             else if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
@@ -211,15 +218,19 @@ struct FirPair {
         // unconditional requests: nx must be dead above this line
         if (PF && REQ) request_next(next_blk);
         OSZ_FSTAMP(6);   // filter spectrum: loads + multiply
-        fft::cube::i3(t, re, im, L);
+        if (CUBE2) fft::cube2::i3(t, re, im, L);
+        else fft::cube::i3(t, re, im, L);
         OSZ_FSTAMP(7);   // inverse pass 3
-        __syncthreads();
+        if (CUBE2) wave_lds_fence();
+        else __syncthreads();
         OSZ_FSTAMP(8);   // barrier 3
-        fft::cube::i2(t, re, im, tw2, L);
+        if (CUBE2) fft::cube2::i2(t, re, im, tw2, L);
+        else fft::cube::i2(t, re, im, tw2, L);
         OSZ_FSTAMP(9);   // inverse pass 2
         __syncthreads();
         OSZ_FSTAMP(10);  // barrier 4
-        fft::cube::i1(t, re, im, tw1, L);
+        if (CUBE2) fft::cube2::i1(t, re, im, tw1, L);
+        else fft::cube::i1(t, re, im, tw1, L);
     }
 
     // a pair of whole blocks: no predication anywhere.  FROM_NX: the samples were

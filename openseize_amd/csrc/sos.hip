@@ -74,13 +74,6 @@ __device__ unsigned long long *g_sos_stamps = nullptr;   // [waves][8] cycle sum
 #define OSZ_STAMP(slot) do { } while (0)
 #endif
 
-// wave-private LDS hand-offs need no workgroup barrier: LDS executes one
-// wave's instructions in order; this only stops the compiler reordering them
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // NaN reach across time segments: see sos_tile.h
 // backward pass: is channel c's pass NaN throughout?  (workgroup-uniform)

@@ -20,6 +20,18 @@ def test_fft4096_host_replay():
     assert "OK" in out.stdout
 
 
+def test_fft4096_cube2_host_replay():
+    """fft::cube2, the layout of the spectral chain kernels: bijective, conflict-free views, the
+    second exchange inside a 16-lane row, forward / inverse against a direct DFT."""
+    src = os.path.join(ROOT, "tests", "host", "fft_cube2_check.cpp")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "fft_cube2_check")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "exchange 2 row-local: yes" in out.stdout and "OK" in out.stdout
+
+
 def test_fft8_host_replay():
     """fft8.h (N = 512 ... 8192, 8 points per thread): forward against a naive
     long-double DFT, inverse(forward) = N x, the digit-reversal map, the LDS
