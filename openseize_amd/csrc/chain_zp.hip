@@ -108,41 +108,154 @@ __device__ __forceinline__ double zp_dot(const double *kk, const double *pr, con
 // last lane, and that lane writes kappa[r] = amplitude * lambda^(256 r), r < R:
 //   kapA[amp][r][q]   amp = 0 mu_a, 1 mu_b, 2 nu_a, 3 nu_b              (this pair)
 //   kapN[k][r][q]     k = 0 mu_b, 1 nu_b: what the NEXT pair meets as mu_pb, nu_pb
-template <int NM>
-__device__ __forceinline__ void zp_fit_kappa(int tt, int nh, int R, const double *fitbuf, const double *mtab,
-                                             const double *lrow, double *kapA, double *kapN) {
-    const int ns = 2 * nh, per = nh >> 1;
+template <int NM, int PER>
+__device__ __forceinline__ void zp_fit_kappa_n(int tt, int R, const double *fitbuf, const double *mtab,
+                                               const double *lrow, double *kapA, double *kapN) {
+    constexpr int ns = 4 * PER;
     const int qd = tt >> 2, p4 = tt & 3;
     const bool valid = qd < 4 * NM;
     const int blk = valid ? qd / (2 * NM) : 0, kind = valid ? (qd / NM) % 2 : 0, q = valid ? qd % NM : 0;
-    const double *yb = fitbuf + ns * blk + per * p4;
-    const double *mr = mtab + ns * ((2 * kind) * NM + q) + per * p4;
-    const double *mi = mtab + ns * ((2 * kind + 1) * NM + q) + per * p4;
-    double sr = 0.0, si = 0.0;
-    for (int k = 0; k < per; ++k) {
-        const double y = yb[k];
-        sr = fma(mr[k], y, sr);
-        si = fma(mi[k], y, si);
+    const double *yb = fitbuf + ns * blk + PER * p4;
+    const double *mr = mtab + ns * ((2 * kind) * NM + q) + PER * p4;
+    const double *mi = mtab + ns * ((2 * kind + 1) * NM + q) + PER * p4;
+    // all the operands first, then four independent chains: the stage is a string of LDS
+    // round trips otherwise (it took 12 % of the kernel's time as a rolled loop)
+    // (in batches of four samples: more operands at once and the data registers spill)
+    double sr0 = 0.0, sr1 = 0.0, si0 = 0.0, si1 = 0.0;
+#pragma unroll
+    for (int k0 = 0; k0 < PER; k0 += 4) {
+        double y[4], a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            y[k] = yb[k0 + k];
+            a[k] = mr[k0 + k];
+            b[k] = mi[k0 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {
+            sr0 = fma(a[k], y[k], sr0);
+            sr1 = fma(a[k + 1], y[k + 1], sr1);
+            si0 = fma(b[k], y[k], si0);
+            si1 = fma(b[k + 1], y[k + 1], si1);
+        }
     }
-    if (!valid) sr = si = 0.0;
+    double sr = valid ? sr0 + sr1 : 0.0, si = valid ? si0 + si1 : 0.0;
     sr += dpp_row_shr0<1>(sr);
     si += dpp_row_shr0<1>(si);
     sr += dpp_row_shr0<2>(sr);
     si += dpp_row_shr0<2>(si);
     if (p4 == 3 && valid) {
         const int amp = kind * 2 + blk;
-        for (int r = 0; r < R; ++r) {
-            const double lr = lrow[(r * NM + q) * 2 + 0], li = lrow[(r * NM + q) * 2 + 1];
-            const double kr = sr * lr - si * li, ki = sr * li + si * lr;
-            kapA[((amp * R + r) * NM + q) * 2 + 0] = kr;
-            kapA[((amp * R + r) * NM + q) * 2 + 1] = ki;
-            if (blk == 1) {
-                kapN[((kind * R + r) * NM + q) * 2 + 0] = kr;
-                kapN[((kind * R + r) * NM + q) * 2 + 1] = ki;
+        double lr[kSpecRMax], li[kSpecRMax];
+#pragma unroll
+        for (int r = 0; r < kSpecRMax; ++r) {
+            lr[r] = r < R ? lrow[(r * NM + q) * 2 + 0] : 0.0;
+            li[r] = r < R ? lrow[(r * NM + q) * 2 + 1] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < kSpecRMax; ++r) {
+            if (r < R) {
+                const double kr = sr * lr[r] - si * li[r], ki = sr * li[r] + si * lr[r];
+                kapA[((amp * R + r) * NM + q) * 2 + 0] = kr;
+                kapA[((amp * R + r) * NM + q) * 2 + 1] = ki;
+                if (blk == 1) {
+                    kapN[((kind * R + r) * NM + q) * 2 + 0] = kr;
+                    kapN[((kind * R + r) * NM + q) * 2 + 1] = ki;
+                }
             }
         }
     }
 }
+
+// nh is 16, 24 or 32 (spec::build_zp)
+template <int NM>
+__device__ __forceinline__ void zp_fit_kappa(int tt, int nh, int R, const double *fitbuf, const double *mtab,
+                                             const double *lrow, double *kapA, double *kapN) {
+    if (nh == 24) zp_fit_kappa_n<NM, 12>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+    else if (nh == 32) zp_fit_kappa_n<NM, 16>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+    else zp_fit_kappa_n<NM, 8>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+}
+
+// Three bursts of one row at once: every operand first, two chains per burst.
+template <int NM>
+__device__ __forceinline__ void zp_dot3(const double *k0, const double *k1, const double *k2, const double *pr,
+                                        const double *pi, double &d0, double &d1, double &d2) {
+    // (one mode at a time: six operands in flight; more at once and the data registers spill)
+    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0, cr = 0.0, ci = 0.0;
+#pragma unroll
+    for (int q = 0; q < NM; ++q) {
+        ar = fma(k0[2 * q], pr[q], ar);
+        ai = fma(k0[2 * q + 1], pi[q], ai);
+        br = fma(k1[2 * q], pr[q], br);
+        bi = fma(k1[2 * q + 1], pi[q], bi);
+        cr = fma(k2[2 * q], pr[q], cr);
+        ci = fma(k2[2 * q + 1], pi[q], ci);
+    }
+    d0 = ar - ai;
+    d1 = br - bi;
+    d2 = cr - ci;
+}
+
+// The forward bursts of a pair (RF rows): mu_a leaves row r of block a and arrives in row
+// D + r of block b; mu_b leaves row r of block b; mu_pb arrives in row D + r of block a.
+template <int NR, int NM, int RF>
+__device__ __forceinline__ void zp_fwd_bursts(double *re, double *im, const double *kapA, const double *kpb, int R,
+                                              const double *Pr, const double *Pi, double &first_a, double &first_b) {
+    constexpr int D = 16 - NR;
+#pragma unroll
+    for (int r = 0; r < RF; ++r) {
+        if (r < D) {
+            double ca, cb, cp;
+            zp_dot3<NM>(kapA + ((0 * R + r) * NM) * 2, kapA + ((1 * R + r) * NM) * 2, kpb + ((0 * R + r) * NM) * 2,
+                        Pr, Pi, ca, cb, cp);
+            re[r] -= ca;
+            im[(D + r) & 15] += ca;
+            im[r] -= cb;
+            re[(D + r) & 15] += cp;
+            if (r == 0) {
+                first_a = ca;
+                first_b = cb;
+            }
+        }
+    }
+}
+
+// The backward bursts (RB rows): nu_a leaves row D-1-r of block b and arrives in the rows the
+// previous block b holds back (c7); nu_b arrives in row NR-1-r of block a; nu_pb leaves row
+// D-1-r of block a.
+template <int NR, int NM, int RB>
+__device__ __forceinline__ void zp_bwd_bursts(double *re, double *im, double *c7, const double *kapA,
+                                              const double *kpb, int R, const double *Pr, const double *Pi) {
+    constexpr int D = 16 - NR;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        if (r < D) {
+            double na, nb, np;
+            zp_dot3<NM>(kapA + ((2 * R + r) * NM) * 2, kapA + ((3 * R + r) * NM) * 2, kpb + ((1 * R + r) * NM) * 2,
+                        Pr, Pi, na, nb, np);
+            im[(D - 1 - r) & 15] -= na;
+            c7[r] = na;
+            re[(NR - 1 - r) & 15] += nb;
+            re[(D - 1 - r) & 15] -= np;
+        }
+    }
+}
+
+// In-kernel phase stamps for the diagnostic build only (benchmarks/zp_stamps.hip defines
+// OSZ_FIR_STAMPS); the library build has none.  Slots 0-11: FirPair's; 12-15: this kernel's.
+#ifdef OSZ_FIR_STAMPS
+#define OSZ_ZSTAMP(slot)                                                             \
+    do {                                                                             \
+        unsigned long long now_;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        zst[slot] += now_ - P.stamp_last;                                            \
+        P.stamp_last = now_;                                                         \
+    } while (0)
+#else
+#define OSZ_ZSTAMP(slot) do { } while (0)
+#endif
 
 template <int NR, int NM>
 __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
@@ -196,6 +309,12 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         else ho[q_ - n] = (v_);                 \
     } while (0)
 
+#ifdef OSZ_FIR_STAMPS
+    unsigned long long zst[16];
+    for (int q = 0; q < 16; ++q) zst[q] = 0;
+    for (int q = 0; q < 12; ++q) P.stamp_acc[q] = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.stamp_last)::"memory");
+#endif
     for (int64_t p = first; p <= lastf; ++p) {
         const int64_t o = p * (2 * S);
         double re[16], im[16];
@@ -209,7 +328,9 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
                 im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
             }
         }
+        OSZ_ZSTAMP(0);    // previous pair's stores + this pair's loads issued
         P.transform(re, im);
+        OSZ_ZSTAMP(11);   // inverse pass 1
         // thread -> role indices, recomputed per pair from an opaque copy of t
         int tt = t;
         asm volatile("" : "+v"(tt));
@@ -226,51 +347,52 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             im[j] += re[j + NR];
             P.cr[j] = im[j + NR];
         }
+        OSZ_ZSTAMP(12);   // fit samples to LDS, overlap add
         __syncthreads();
+        OSZ_ZSTAMP(13);   // barrier
         // fit and amplitudes: this pair's into kapA, block b's also into the other half of
         // kapP for the next pair
         zp_fit_kappa<NM>(tt, nh, R, fitbuf, mtab, lrow, kapA, kapP + (par ^ 1) * (2 * R * NM * 2));
         __syncthreads();
+        OSZ_ZSTAMP(14);   // fit + amplitudes + barrier
         const double *kap = kapA, *kpb = kapP + par * (2 * R * NM * 2);
         // Six burst evaluations per row index r serve the eight places a burst lands: the
         // wrapped right tail of block a leaves its row r and arrives, one window on, in row
         // D + r of block b with the same values (mu_a), and so do the left tail of block a
         // in row D-1-r of block b and in the rows the previous block b holds back (nu_a).
         double c7[kSpecRMax];
+#pragma unroll
+        for (int r = 0; r < kSpecRMax; ++r) c7[r] = 0.0;
         {
             // forward bursts with lambda^t, then (the same registers) backward ones with
-            // lambda^(255 - t): both sets of powers at once do not fit beside the data
+            // lambda^(255 - t): both sets of powers at once do not fit beside the data.  The
+            // row counts are compile-time inside (a switch): every operand of a row is
+            // requested before the first product, three bursts run as six chains.
             double Pr[NM], Pi[NM];
             zp_powers<NM>(ptab, tt, Pr, Pi);
-#pragma unroll
-            for (int r = 0; r < kSpecRMax; ++r) {
-                if (r < Rf && r < D) {
-                    const double ca = zp_dot<NM>(kap + ((0 * R + r) * NM) * 2, Pr, Pi);   // mu_a
-                    const double cb = zp_dot<NM>(kap + ((1 * R + r) * NM) * 2, Pr, Pi);   // mu_b
-                    re[r] -= ca;
-                    im[(D + r) & 15] += ca;
-                    im[r] -= cb;
-                    re[(D + r) & 15] += zp_dot<NM>(kpb + ((0 * R + r) * NM) * 2, Pr, Pi); // mu_pb
-                    if (r == 0 && !bad && (sos_not_finite(ca) || sos_not_finite(cb))) {
-                        bad = true;
-                        bad_at = o;
-                    }
-                }
+            double ca = 0.0, cb = 0.0;
+            switch (Rf) {
+                case 1: zp_fwd_bursts<NR, NM, 1>(re, im, kap, kpb, R, Pr, Pi, ca, cb); break;
+                case 2: zp_fwd_bursts<NR, NM, 2>(re, im, kap, kpb, R, Pr, Pi, ca, cb); break;
+                case 3: zp_fwd_bursts<NR, NM, 3>(re, im, kap, kpb, R, Pr, Pi, ca, cb); break;
+                case 4: zp_fwd_bursts<NR, NM, 4>(re, im, kap, kpb, R, Pr, Pi, ca, cb); break;
+                default: zp_fwd_bursts<NR, NM, 5>(re, im, kap, kpb, R, Pr, Pi, ca, cb); break;
+            }
+            if (!bad && (sos_not_finite(ca) || sos_not_finite(cb))) {
+                bad = true;
+                bad_at = o;
             }
             __builtin_amdgcn_sched_barrier(0);
             zp_powers<NM>(ptab, 255 - tt, Pr, Pi);
-#pragma unroll
-            for (int r = 0; r < kSpecRMax; ++r) {
-                c7[r] = 0.0;
-                if (r < R && r < D) {
-                    const double na = zp_dot<NM>(kap + ((2 * R + r) * NM) * 2, Pr, Pi);   // nu_a
-                    im[(D - 1 - r) & 15] -= na;
-                    c7[r] = na;
-                    re[(NR - 1 - r) & 15] += zp_dot<NM>(kap + ((3 * R + r) * NM) * 2, Pr, Pi);  // nu_b
-                    re[(D - 1 - r) & 15] -= zp_dot<NM>(kpb + ((1 * R + r) * NM) * 2, Pr, Pi);   // nu_pb
-                }
+            switch (R) {
+                case 1: zp_bwd_bursts<NR, NM, 1>(re, im, c7, kap, kpb, R, Pr, Pi); break;
+                case 2: zp_bwd_bursts<NR, NM, 2>(re, im, c7, kap, kpb, R, Pr, Pi); break;
+                case 3: zp_bwd_bursts<NR, NM, 3>(re, im, c7, kap, kpb, R, Pr, Pi); break;
+                case 4: zp_bwd_bursts<NR, NM, 4>(re, im, c7, kap, kpb, R, Pr, Pi); break;
+                default: zp_bwd_bursts<NR, NM, 5>(re, im, c7, kap, kpb, R, Pr, Pi); break;
             }
         }
+        OSZ_ZSTAMP(15);   // bursts
         const double qn = spec_qnan();
         const bool own = p >= p0 && p < p1;
         const bool edge = p == g.W - 1;        // its samples may be among the chunk's last L
@@ -335,6 +457,15 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         par ^= 1;
     }
 
+#ifdef OSZ_FIR_STAMPS
+    if (g_fir_stamps && (t & 63) == 0) {
+        unsigned long long *so = g_fir_stamps + (((int64_t)c * g.nruns + run) * 4 + (t >> 6)) * 16;
+        for (int q = 1; q <= 10; ++q) so[q] = P.stamp_acc[q];
+        so[0] = zst[0];
+        so[11] = zst[11];
+        for (int q = 12; q < 16; ++q) so[q] = zst[q];
+    }
+#endif
     if (run == g.nruns - 1) {
         // ---- the closing pair: blocks of la and lb samples (lb > 0 only behind a whole
         // block a), accumulated in LDS over the idle cube: acc[i], i = samples from its start

@@ -383,7 +383,7 @@ inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int ns
     // LDS behind the cube: fit samples [2][2 nh], kappa [8][R][NM][2], L [R][NM][2],
     // P [20][NM][2], M [4 NM][2 nh]
     int nh = 0;
-    for (int cand = 32; cand >= 12 && !nh; cand -= 4) {
+    for (int cand = 32; cand >= 16 && !nh; cand -= 8) {     // 32, 24, 16: the kernel unrolls these
         const int bytes = 8 * (2 * 2 * cand + 8 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 +
                                4 * NM * 2 * cand);
         if (bytes <= lds_budget) nh = cand;
