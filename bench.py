@@ -453,7 +453,8 @@ def full_stream_leg(R, ring, h, sos):
             "seconds": secs, "Msamples_s": C * total / secs / 1e6,
             "path": "producer(gen) -> oaconvolve('same') -> GenProducer -> sosfiltfilt (the public "
                     "generators; sosfiltfilt recognises the FIR producer and runs one "
-                    "osz_chain_step per chunk, OSZ_CHAIN_API=0: the two generators apart), "
+                    "osz_chain_zp_step per chunk, the stream's last two chunks on the separate kernels; "
+                    "OSZ_CHAIN_ZP=0: osz_chain_step, OSZ_CHAIN_API=0: the two generators apart), "
                     "device-resident ring of 3 synthesised chunks"}
 
 
