@@ -153,15 +153,20 @@ def pull_resident(iterable, pro):
     """Iterate ``iterable`` -- chunks drawn from the producer ``pro`` -- as a consumer that
     takes CUDA tensors (the estimators and other non-generator consumers of a chain)."""
     it = iter(iterable)
-    while True:
-        token = _PULL.set(pro)
-        try:
-            item = next(it, _END)
-        finally:
-            _PULL.reset(token)
-        if item is _END:
-            return
-        yield item
+    try:
+        while True:
+            token = _PULL.set(pro)
+            try:
+                item = next(it, _END)
+            finally:
+                _PULL.reset(token)
+            if item is _END:
+                return
+            yield item
+    finally:
+        close = getattr(it, "close", None)       # an abandoned consumer releases its source
+        if close is not None:
+            close()
 
 
 def relay_pull(outer, inner):
@@ -254,6 +259,13 @@ def chain_aware(fn):
                 if item is _END:
                     break
                 if outer or not (is_tensor(item) and item.is_cuda):
+                    # results leave in the order they were produced: whatever is still on
+                    # its way down goes first (a generator that hands out an ndarray behind
+                    # CUDA tensors, e.g. a tail assembled on the host)
+                    while flying:
+                        out, done = flying.popleft()
+                        done.synchronize()
+                        yield out.numpy()
                     yield item
                     continue
                 # the caller's stage: back to the host, two transfers in flight

@@ -312,10 +312,9 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
         return None
     chunks = dev.pull_resident(source, source)         # a source of this library hands CUDA tensors
     first = next(chunks, None)
-    if first is None or first.shape[axis] != cs:
-        return None
-    resident = dev.is_tensor(first) and first.is_cuda
-    if dev.is_tensor(first) and not resident:
+    resident = first is not None and dev.is_tensor(first) and first.is_cuda
+    if first is None or first.shape[axis] != cs or (dev.is_tensor(first) and not resident):
+        chunks.close()                                 # (a reader behind the source is released)
         return None
 
     def run():
@@ -440,6 +439,7 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
     ok = next(gen)                                     # handles exist, the plan holds?
     if ok is None:
         gen.close()
+        chunks.close()
         return None
     return gen
 
