@@ -36,6 +36,9 @@
 #include <functional>
 #include <vector>
 
+#ifndef OSZ_ZP_TURN_BIT
+#define OSZ_ZP_TURN_BIT 18
+#endif
 #include "chain_spec.h"
 #include "fft4096.h"
 #include "fir_pair.h"
@@ -64,19 +67,21 @@ struct ZpArgs {
     int *segcnt;
     long long *nanpos;         // (nch): stream position at which the forward stream went bad
     long long pos;             // stream position of this chunk's first sample
+    int wclose;                // what closing the chunk costs its last run, in pairs
 };
 
 // First pair of run r (r = nruns: one past the last).  The runs of a channel do not cost the
 // same: every run but the first starts one pair early, and the last one closes the chunk (a
-// generic path worth about two pairs); with balanced costs the last run gets fewer pairs of its
+// generic path, `wclose` pairs' worth); with balanced costs the last run gets fewer pairs of its
 // own and the launch does not wait for it (256 channels, two runs each: 94.5 : 94.5 instead
 // of 93 : 96).  Short runs keep the even split.
-__host__ __device__ __forceinline__ int64_t zp_run_start(int64_t r, int64_t W, int nruns) {
+__host__ __device__ __forceinline__ int64_t zp_run_start(int64_t r, int64_t W, int nruns, int wclose) {
     if (r <= 0) return 0;
     if (r >= nruns) return W;
     if (W < 8 * (int64_t)nruns) return (r * W) / nruns;
-    const int64_t V = W + (nruns - 1) + 2;             // pairs, pre-roll pairs, the closing pair
-    return (r * V) / nruns - (r - 1);
+    const int64_t V = W + (nruns - 1) + wclose;        // pairs, pre-roll pairs, the closing pair
+    const int64_t s = (r * V) / nruns - (r - 1);
+    return s < W - (nruns - r) ? s : W - (nruns - r);  // every later run keeps a pair of its own
 }
 
 // lambda^e for e = 0..255 from the three-level table [20][NM][2]
@@ -257,8 +262,46 @@ __device__ __forceinline__ void zp_bwd_bursts(double *re, double *im, double *c7
 #define OSZ_ZSTAMP(slot) do { } while (0)
 #endif
 
+// The two workgroups of a CU do not get equal shares by themselves: the issue arbiter serves
+// the older wave first, the workgroup placed second runs ~20 % behind and then finishes alone
+// on a half-empty CU (benchmarks/zp_timeline.hip).  Each wave therefore raises and drops its
+// priority in turn with the other wave of its SIMD (they differ in the lowest bit of their
+// wave slot), switching on a bit of the clock.
+__device__ __forceinline__ void zp_take_turns() {
+    unsigned slot;
+    unsigned long long now;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 1)" : "=s"(slot));
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+    if ((((unsigned)(now >> OSZ_ZP_TURN_BIT)) ^ slot) & 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
+// Absolute time marks of a workgroup (diagnostic build only: benchmarks/zp_timeline.hip defines
+// OSZ_ZP_MARKS): entry, tables in LDS, whole pairs done, chunk closed, exit.
+#ifdef OSZ_ZP_MARKS
+__device__ unsigned long long *g_zp_marks = nullptr;   // [nch][nruns][8]
+#define OSZ_ZMARK(k)                                                                            \
+    do {                                                                                        \
+        if (g_zp_marks && threadIdx.x == 0) {                                                   \
+            unsigned long long now_;                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");        \
+            g_zp_marks[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = now_;        \
+        }                                                                                       \
+    } while (0)
+#else
+#define OSZ_ZMARK(k) do { } while (0)
+#endif
+
 template <int NR, int NM>
 __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
+    OSZ_ZMARK(0);
+#ifdef OSZ_ZP_MARKS
+    if (g_zp_marks && threadIdx.x == 0) {
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        g_zp_marks[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = rt;
+    }
+#endif
     constexpr int D = 16 - NR, S = 256 * NR;
     extern __shared__ fft::cube::C2 cube_lds[];
     const int R = g.R, Rf = g.Rf, nh = g.nh, ns = 2 * nh;
@@ -278,8 +321,8 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     double *y0r = g.y0 ? g.y0 + (int64_t)c * g.ldy0 : nullptr;
     double *yr = a.y + (int64_t)c * a.ldy - n0;
     double *ho = g.held_out + (int64_t)c * L;
-    const int64_t p0 = zp_run_start(run, g.W, g.nruns);
-    const int64_t p1 = zp_run_start(run + 1, g.W, g.nruns);
+    const int64_t p0 = zp_run_start(run, g.W, g.nruns, g.wclose);
+    const int64_t p1 = zp_run_start(run + 1, g.W, g.nruns, g.wclose);
     const int64_t first = run == 0 ? 0 : p0 - 1;
     const int64_t lastf = p1 - 1;
 
@@ -287,9 +330,13 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     fft::cube2::tw_load(t, a.tb, P.tw1, P.tw2);
 #pragma unroll
     for (int j = 0; j < D; ++j) P.cr[j] = 0.0;
-    for (int i = t; i < R * NM * 2; i += 256) lrow[i] = g.Lrow[i];
-    for (int i = t; i < 20 * NM * 2; i += 256) ptab[i] = g.P[i];
-    for (int i = t; i < 4 * NM * ns; i += 256) mtab[i] = g.M[i];
+    {
+        // lrow | ptab | mtab are one table on the device too (g.Lrow): every request of the
+        // sweep is out before the first answer is needed
+        const int ntab = R * NM * 2 + 20 * NM * 2 + 4 * NM * ns;
+#pragma unroll 8
+        for (int i = t; i < ntab; i += 256) lrow[i] = g.Lrow[i];
+    }
     for (int i = t; i < 4 * R * NM * 2; i += 256) kapP[i] = 0.0;
     double held[kSpecRMax];          // rows NR-1-r of the previous pair's block b, one burst short
 #pragma unroll
@@ -298,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     int64_t bad_at = -1;             // chunk position of the pair that went bad
     int par = 0;
     __syncthreads();
+    OSZ_ZMARK(1);
 
     // a sample of the chunk (position i, value v) goes to the output, L samples late, or,
     // the chunk's last L samples, to `held`
@@ -318,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     for (int64_t p = first; p <= lastf; ++p) {
         const int64_t o = p * (2 * S);
         double re[16], im[16];
+        zp_take_turns();
         {
             int64_t off = o + t;
             asm volatile("" : "+v"(off));   // per pair: hoisted, 2 NR row addresses would spill
@@ -466,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         for (int q = 12; q < 16; ++q) so[q] = zst[q];
     }
 #endif
+    OSZ_ZMARK(2);
     if (run == g.nruns - 1) {
         // ---- the closing pair: blocks of la and lb samples (lb > 0 only behind a whole
         // block a), accumulated in LDS over the idle cube: acc[i], i = samples from its start
@@ -558,6 +608,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         }
     }
 #undef OSZ_ZP_PUT
+    OSZ_ZMARK(3);
     // where the forward stream of this channel first went bad (the caller's NaN reach)
     if (bad && t == 0 && g.nanpos) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
     if (g.nruns > 1 && g.segcnt) {
@@ -572,18 +623,27 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         }
         last = __syncthreads_or(last);
         if (last) {
-            if (threadIdx.x == 0) atomicExch(g.segcnt + c, 0);
+            // the earliest run that ended bad: a thread per run (one channel alone has 512)
+            int *sbad = reinterpret_cast<int *>(xl);
+            if (threadIdx.x == 0) {
+                atomicExch(g.segcnt + c, 0);
+                *sbad = nr_;
+            }
             __threadfence();
-            int badrun = nr_;
-            for (int s = nr_ - 2; s >= 0; --s) {
-                const int64_t e = zp_run_start(s + 1, Wp, nr_) * pairlen;
+            __syncthreads();
+            int mine = nr_;
+            for (int s = t; s < nr_ - 1; s += 256) {
+                const int64_t e = zp_run_start(s + 1, Wp, nr_, g.wclose) * pairlen;
                 const unsigned long long bits = __hip_atomic_load(
                     reinterpret_cast<const unsigned long long *>((e - 1 < n0 ? y0r : yr) + e - 1), __ATOMIC_RELAXED,
                     __HIP_MEMORY_SCOPE_AGENT);
-                if (sos_not_finite(__longlong_as_double((long long)bits))) badrun = s;
+                if (sos_not_finite(__longlong_as_double((long long)bits)) && s < mine) mine = s;
             }
+            if (mine < nr_) atomicMin(sbad, mine);
+            __syncthreads();
+            const int badrun = *sbad;
             if (badrun < nr_) {
-                const int64_t from = zp_run_start(badrun + 1, Wp, nr_) * pairlen;
+                const int64_t from = zp_run_start(badrun + 1, Wp, nr_, g.wclose) * pairlen;
                 if (from < n0) sos_fill_nan(y0r + from, n0 - from);
                 sos_fill_nan(yr + (from < n0 ? n0 : from), n - (from < n0 ? n0 : from));
                 sos_fill_nan(ho, L);
@@ -591,6 +651,17 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             }
         }
     }
+    OSZ_ZMARK(4);
+#ifdef OSZ_ZP_MARKS
+    if (g_zp_marks && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        g_zp_marks[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        g_zp_marks[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = rt;
+    }
+#endif
 }
 
 // NaN reach of sosfiltfilt (sos_tile.h): a chunk of the reference's output is NaN as a
@@ -631,7 +702,8 @@ struct ChainZp {
     osz_sos_s *sos = nullptr;
     bool eligible = false, open = false;
     int NR = 0, NM = 0, R = 0, Rf = 0, nh = 0;
-    double *dH = nullptr, *dM = nullptr, *dP = nullptr, *dL = nullptr;
+    double *dH = nullptr, *dT = nullptr;   // dT: burst rows | mode powers | fit matrix, as the kernel's LDS holds them
+    double *dM = nullptr, *dP = nullptr, *dL = nullptr;   // (views into dT)
     double *dcarry[2] = {nullptr, nullptr}, *dheld[2] = {nullptr, nullptr};
     int cur = 0;
     int64_t pos = 0;               // stream position of the next chunk's first sample
@@ -646,9 +718,7 @@ struct ChainZp {
 
 static void zp_free(ChainZp *s) {
     (void)hipFree(s->dH);
-    (void)hipFree(s->dM);
-    (void)hipFree(s->dP);
-    (void)hipFree(s->dL);
+    (void)hipFree(s->dT);
     for (int q = 0; q < 2; ++q) {
         (void)hipFree(s->dcarry[q]);
         (void)hipFree(s->dheld[q]);
@@ -695,9 +765,17 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
                     return OSZ_OK;
                 };
                 int rc;
-                if ((rc = up(&s->dH, spec_permuted_spectrum(T.H))) || (rc = up(&s->dM, T.M)) || (rc = up(&s->dP, T.P)) ||
-                    (rc = up(&s->dL, T.L)))
-                    return rc;
+                // one table, in the order of the kernel's LDS: a workgroup fetches it in one sweep
+                const size_t nl = (size_t)T.R * T.NM * 2, np = (size_t)20 * T.NM * 2, nm = (size_t)4 * T.NM * 2 * T.nh;
+                if (T.L.size() < nl || T.P.size() != np || T.M.size() != nm)
+                    return fail(OSZ_ERR_STATE, "zero-phase tables: %zu %zu %zu", T.L.size(), T.P.size(), T.M.size());
+                std::vector<double> cat(T.L.begin(), T.L.begin() + nl);
+                cat.insert(cat.end(), T.P.begin(), T.P.end());
+                cat.insert(cat.end(), T.M.begin(), T.M.end());
+                if ((rc = up(&s->dH, spec_permuted_spectrum(T.H))) || (rc = up(&s->dT, cat))) return rc;
+                s->dL = s->dT;
+                s->dP = s->dL + nl;
+                s->dM = s->dP + np;
                 const int nch = fir->nch;
                 for (int q = 0; q < 2; ++q) {
                     OSZ_HIP(hipMalloc(&s->dcarry[q], sizeof(double) * (size_t)nch * kSpecLdc));
@@ -778,6 +856,7 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
     g.segcnt = sos_nanfix() ? sos->dsegcnt : nullptr;
     g.nanpos = s->dnanpos;
     g.pos = s->pos;
+    g.wclose = 4;   // measured: 2 ... 12 pairs, 32 and 256 channels (profiles/README.md)
     if (n >= s->hist_cap) {
         g.hist = s->dhist[s->hcur];
         g.hist_len = s->hist_cap;

@@ -294,12 +294,15 @@ inline Tables build(const double *taps, int wlen, const double *sos, int nsec, b
 //   P     [20][NM][2]  lambda^(32 i), i < 8; lambda^(4 i), i < 8; lambda^i, i < 4
 //   L     [5][NM][2]   lambda^(256 r)
 //   R, Rf burst rows backwards / forwards: over how many rows of 256 samples the left / right
-//         tail of the two-sided composite impulse response exceeds kTailTol of its norm.
-//         The truncation is then an order of magnitude below the rounding noise of the
-//         4096-point transform itself (1e-14 of the output scale, measured); the right tail
-//         has the window's guard rows in front of it and is the shorter one (Rf <= R).
+//         tail of the two-sided composite impulse response exceeds kTailTol of its norm; the
+//         right tail has the window's guard rows in front of it and is the shorter one
+//         (Rf <= R).  What is cut off is the error the kernel adds to the transform's own
+//         rounding (1e-14 of the output scale): for the headline filters the tails are
+//         7.6e-13 / 7.3e-13 at R, Rf = 2, 1 and 3.8e-16 / 3.6e-16 at 3, 2 -- measured against
+//         SciPy 5e-13 and 7e-15, the step 1.53 and 1.66 ms.  The contract of the path is 1e-6
+//         (BASELINE.json), the tests hold 1e-9: the tolerance buys the 8 %.
 // NR is the largest block height whose guard rows hold the bursts (R <= D, D + Rf <= NR).
-constexpr ld_t kTailTol = 1e-15L;
+constexpr ld_t kTailTol = 1e-12L;
 
 struct TablesZp {
     bool eligible = false;
