@@ -62,11 +62,21 @@ int main(int argc, char **argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> m(nm);
     hipMemcpy(m.data(), mk[0], nm * 8, hipMemcpyDeviceToHost);
-    unsigned long long t0 = ~0ull, t4 = 0;
-    for (size_t w = 0; w < nwg; ++w) { t0 = std::min(t0, m[w * 8]); t4 = std::max(t4, m[w * 8 + 4]); }
-    auto us = [](double ticks) { return ticks * 0.01; };
-    printf("zero-phase chain, %d ch x 2^20, %d runs per channel: event time %.1f us, first entry -> last exit %.1f us\n",
-           nch, nruns, ms * 1e3, us((double)(t4 - t0)));
+    double fclk = 0.0;   // GHz, mean over the workgroups
+    {
+        // shader clock: s_memtime ticks per s_memrealtime tick (100 MHz), per workgroup
+        double lo = 1e30, hi = 0, sm = 0; unsigned long long r0 = ~0ull, r1 = 0;
+        for (size_t w = 0; w < nwg; ++w) {
+            const double f = (double)(m[w * 8 + 4] - m[w * 8]) / (double)(m[w * 8 + 7] - m[w * 8 + 6]) * 0.1;
+            lo = std::min(lo, f); hi = std::max(hi, f); sm += f;
+            r0 = std::min(r0, m[w * 8 + 6]); r1 = std::max(r1, m[w * 8 + 7]);
+        }
+        fclk = sm / nwg;
+        printf("  shader clock while the kernel ran: mean %.3f GHz (min %.3f, max %.3f); first entry -> last exit by the 100 MHz clock %.1f us\n",
+               sm / nwg, lo, hi, (double)(r1 - r0) * 0.01);
+    }
+    auto us = [&](double ticks) { return ticks / (fclk * 1e3); };   // shader-clock ticks -> us at the measured clock
+    printf("zero-phase chain, %d ch x 2^20, %d runs per channel: event time %.1f us\n", nch, nruns, ms * 1e3);
     auto stat = [&](const char *name, auto fn, int only_run) {
         double sm = 0, mn = 1e30, mx = 0; size_t cnt = 0;
         for (int c = 0; c < nch; ++c)
@@ -78,28 +88,15 @@ int main(int argc, char **argv) {
             }
         if (cnt) printf("  %-46s mean %8.1f  min %8.1f  max %8.1f us  (%zu workgroups)\n", name, us(sm / cnt), us(mn), us(mx), cnt);
     };
-    stat("entry after the first workgroup's", [&](const unsigned long long *p) { return (double)(p[0] - t0); }, -1);
     stat("tables + twiddles (entry -> ready)", [&](const unsigned long long *p) { return (double)(p[1] - p[0]); }, -1);
     stat("whole pairs, first run (opens the chunk)", [&](const unsigned long long *p) { return (double)(p[2] - p[1]); }, 0);
     stat("whole pairs, middle runs", [&](const unsigned long long *p) { return (double)(p[2] - p[1]); }, -2);
     stat("whole pairs, last run", [&](const unsigned long long *p) { return (double)(p[2] - p[1]); }, nruns - 1);
     stat("closing pair + carry export (last run)", [&](const unsigned long long *p) { return (double)(p[3] - p[2]); }, nruns - 1);
     stat("seal check + exit", [&](const unsigned long long *p) { return (double)(p[4] - p[3]); }, -1);
-    stat("exit before the last workgroup's", [&](const unsigned long long *p) { return (double)(t4 - p[4]); }, -1);
     stat("entry -> exit, first run", [&](const unsigned long long *p) { return (double)(p[4] - p[0]); }, 0);
     stat("entry -> exit, middle runs", [&](const unsigned long long *p) { return (double)(p[4] - p[0]); }, -2);
     stat("entry -> exit, last run", [&](const unsigned long long *p) { return (double)(p[4] - p[0]); }, nruns - 1);
-    {
-        // shader clock: s_memtime ticks per s_memrealtime tick (100 MHz), per workgroup
-        double lo = 1e30, hi = 0, sm = 0; unsigned long long r0 = ~0ull, r1 = 0;
-        for (size_t w = 0; w < nwg; ++w) {
-            const double f = (double)(m[w * 8 + 4] - m[w * 8]) / (double)(m[w * 8 + 7] - m[w * 8 + 6]) * 0.1;
-            lo = std::min(lo, f); hi = std::max(hi, f); sm += f;
-            r0 = std::min(r0, m[w * 8 + 6]); r1 = std::max(r1, m[w * 8 + 7]);
-        }
-        printf("  shader clock while the kernel ran: mean %.3f GHz (min %.3f, max %.3f); first entry -> last exit by the 100 MHz clock %.1f us\n",
-               sm / nwg, lo, hi, (double)(r1 - r0) * 0.01);
-    }
     // where the workgroups ran: duration by XCD and by CU (the two workgroups of a CU)
     {
         double xs[16] = {0}; int xn[16] = {0}; double xmin[16], xmax[16];

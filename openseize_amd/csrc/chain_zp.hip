@@ -36,9 +36,6 @@
 #include <functional>
 #include <vector>
 
-#ifndef OSZ_ZP_TURN_BIT
-#define OSZ_ZP_TURN_BIT 18
-#endif
 #include "chain_spec.h"
 #include "fft4096.h"
 #include "fir_pair.h"
@@ -262,20 +259,6 @@ __device__ __forceinline__ void zp_bwd_bursts(double *re, double *im, double *c7
 #define OSZ_ZSTAMP(slot) do { } while (0)
 #endif
 
-// The two workgroups of a CU do not get equal shares by themselves: the issue arbiter serves
-// the older wave first, the workgroup placed second runs ~20 % behind and then finishes alone
-// on a half-empty CU (benchmarks/zp_timeline.hip).  Each wave therefore raises and drops its
-// priority in turn with the other wave of its SIMD (they differ in the lowest bit of their
-// wave slot), switching on a bit of the clock.
-__device__ __forceinline__ void zp_take_turns() {
-    unsigned slot;
-    unsigned long long now;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 1)" : "=s"(slot));
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-    if ((((unsigned)(now >> OSZ_ZP_TURN_BIT)) ^ slot) & 1) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-}
-
 // Absolute time marks of a workgroup (diagnostic build only: benchmarks/zp_timeline.hip defines
 // OSZ_ZP_MARKS): entry, tables in LDS, whole pairs done, chunk closed, exit.
 #ifdef OSZ_ZP_MARKS
@@ -366,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     for (int64_t p = first; p <= lastf; ++p) {
         const int64_t o = p * (2 * S);
         double re[16], im[16];
-        zp_take_turns();
+        take_turns();
         {
             int64_t off = o + t;
             asm volatile("" : "+v"(off));   // per pair: hoisted, 2 NR row addresses would spill

@@ -86,6 +86,27 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The two workgroups of a CU (the 256-thread kernels that fill it with two: one wave of each
+// per SIMD) do not get equal shares by themselves: the issue arbiter serves the older wave
+// first, the workgroup placed second runs ~20 % behind and then finishes alone on a half-empty
+// CU (benchmarks/zp_timeline.hip).  Each wave therefore raises and drops its priority in turn
+// with the other wave of its SIMD (they differ in the lowest bit of their wave slot),
+// switching on bit 18 of the shader clock (~130 us; 12 ... 20 measured).  Long launches at
+// full width gain nothing (the chip runs at the clock its power allows either way), short and
+// narrow ones do: the zero-phase chain at 32 channels 297 -> 266 us (the overlap-add FIR and
+// the Welch kernel measured no different with it and stay without).
+__device__ __forceinline__ void take_turns() {
+#ifdef OSZ_NO_TURNS   // diagnostic builds only: the arbiter's own order
+    return;
+#endif
+    unsigned slot;
+    unsigned long long now;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 1)" : "=s"(slot));
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+    if ((((unsigned)(now >> 18)) ^ slot) & 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 // rccl.hip: in-place all-reduce(sum) of `count` float64 / int64 elements over
 // the ranks of an ncclComm_t; RCCL is bound at run time (dlopen)
 int rccl_allreduce_sum(void *buf, size_t count, bool is_f64, void *comm, hipStream_t st);
