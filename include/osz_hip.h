@@ -240,7 +240,11 @@ int osz_chain_wait(osz_sos_t sos, void *stream);
  *                           before; the first lag outputs of a stream mean nothing) go to
  *                           y0[0, n0) and y[0, n - n0): a caller that cuts the output into
  *                           chunks of its own passes the tail of the previous chunk and
- *                           the head of the current one (n0 = 0: everything to y)
+ *                           the head of the current one (n0 = 0: everything to y).
+ *                           Non-finite input: the step records where the forward stream
+ *                           went bad, every later step writes NaN only, and
+ *                           osz_chain_zp_seal settles the chunk it happened in and the one
+ *                           before -- outputs are final once sealed
  *   osz_chain_zp_seal       NaN reach of sosfiltfilt: y holds output samples [s0, s0 + n)
  *                           of a stream cut into chunks of cs samples from `origin` on; a
  *                           chunk is NaN as a whole when the forward stream went bad in it

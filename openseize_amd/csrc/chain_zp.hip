@@ -61,7 +61,6 @@ struct ZpArgs {
     double *held_out;
     double *hist;              // (nch, hist_len): the chunk's last input samples, or null
     int hist_len;
-    int *segcnt;
     long long *nanpos;         // (nch): stream position at which the forward stream went bad
     long long pos;             // stream position of this chunk's first sample
     int wclose;                // what closing the chunk costs its last run, in pairs
@@ -324,8 +323,8 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     double held[kSpecRMax];          // rows NR-1-r of the previous pair's block b, one burst short
 #pragma unroll
     for (int r = 0; r < kSpecRMax; ++r) held[r] = 0.0;
-    bool bad = false;
-    int64_t bad_at = -1;             // chunk position of the pair that went bad
+    bool bad = g.nanpos[c] != 0x7fffffffffffffffLL;   // the stream went bad in an earlier chunk
+    int64_t bad_at = 0;              // chunk position of the pair that went bad
     int par = 0;
     __syncthreads();
     OSZ_ZMARK(1);
@@ -592,48 +591,13 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     }
 #undef OSZ_ZP_PUT
     OSZ_ZMARK(3);
-    // where the forward stream of this channel first went bad (the caller's NaN reach)
-    if (bad && t == 0 && g.nanpos) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
-    if (g.nruns > 1 && g.segcnt) {
-        const int64_t pairlen = 2 * (int64_t)S, Wp = g.W;
-        const int nr_ = g.nruns;
-        // the last stored sample of run q: row NR - R - 1 of its last pair's block b, L samples late
-        __syncthreads();
-        int last = 0;
-        if (threadIdx.x == 0) {
-            __threadfence();
-            last = atomicAdd(g.segcnt + c, 1) == nr_ - 1;
-        }
-        last = __syncthreads_or(last);
-        if (last) {
-            // the earliest run that ended bad: a thread per run (one channel alone has 512)
-            int *sbad = reinterpret_cast<int *>(xl);
-            if (threadIdx.x == 0) {
-                atomicExch(g.segcnt + c, 0);
-                *sbad = nr_;
-            }
-            __threadfence();
-            __syncthreads();
-            int mine = nr_;
-            for (int s = t; s < nr_ - 1; s += 256) {
-                const int64_t e = zp_run_start(s + 1, Wp, nr_, g.wclose) * pairlen;
-                const unsigned long long bits = __hip_atomic_load(
-                    reinterpret_cast<const unsigned long long *>((e - 1 < n0 ? y0r : yr) + e - 1), __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT);
-                if (sos_not_finite(__longlong_as_double((long long)bits)) && s < mine) mine = s;
-            }
-            if (mine < nr_) atomicMin(sbad, mine);
-            __syncthreads();
-            const int badrun = *sbad;
-            if (badrun < nr_) {
-                const int64_t from = zp_run_start(badrun + 1, Wp, nr_, g.wclose) * pairlen;
-                if (from < n0) sos_fill_nan(y0r + from, n0 - from);
-                sos_fill_nan(yr + (from < n0 ? n0 : from), n - (from < n0 ? n0 : from));
-                sos_fill_nan(ho, L);
-                sos_fill_nan(g.carry_out + (int64_t)c * kSpecLdc, kSpecLdc);
-            }
-        }
-    }
+    // where the forward stream of this channel first went bad: every later launch starts bad
+    // (above), and osz_chain_zp_seal makes the chunks the reference loses NaN as a whole --
+    // this chunk (also the runs behind this one, which do not see it) and the one before.
+    // (No sealing of the later runs in here: overwriting what workgroups on other XCDs have
+    // written wants an agent-scope release from each of them, a write-back of the XCD's L2 --
+    // 12 us per workgroup on average, 50 at the worst, benchmarks/zp_timeline.hip.)
+    if (bad && t == 0) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
     OSZ_ZMARK(4);
 #ifdef OSZ_ZP_MARKS
     if (g_zp_marks && threadIdx.x == 0) {
@@ -797,7 +761,6 @@ static zp_kern_t zp_kernel_for(int nr) {
 static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double *y0, int64_t ldy0,
                      int64_t n0, double *y, int64_t ldy, hipStream_t st) {
     osz_fir_s *fir = s->fir;
-    osz_sos_s *sos = s->sos;
     const int NR = s->NR, S = 256 * NR;
     const int64_t pair = 2 * (int64_t)S;
     const int64_t npw = n / pair, rem = n - npw * pair;
@@ -836,7 +799,6 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
     g.carry_out = s->dcarry[s->cur ^ 1];
     g.held_in = s->dheld[s->cur];
     g.held_out = s->dheld[s->cur ^ 1];
-    g.segcnt = sos_nanfix() ? sos->dsegcnt : nullptr;
     g.nanpos = s->dnanpos;
     g.pos = s->pos;
     g.wclose = 4;   // measured: 2 ... 12 pairs, 32 and 256 channels (profiles/README.md)
