@@ -41,7 +41,6 @@ struct ChainArgs {
     const double *lane_tab;      // [nsec][4][kSos2Tab] for T = 2 NR, or null (first scan variant)
     int64_t npairs;              // whole pairs of blocks in this call
     int nruns, pre_pairs;
-    int *segcnt;                 // (nch) arrival counters of the runs (sos_fwd_seal)
 };
 
 template <int NR, bool V2>
@@ -159,15 +158,6 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(ChainArgs g,
             g.sos_state_out[((int64_t)t * gridDim.y + c) * 2 + 1] = sst[(parity * kSosMaxSec + t) * 2 + 1];
         }
     }
-    // NaN reach (sos_tile.h): a run that started from zero states knows nothing of a
-    // NaN the cascade met before its pre-roll
-    if (g.nruns > 1 && g.segcnt) {
-        const int64_t pairlen = 2 * (int64_t)a.step, np = g.npairs;
-        const int nr_ = g.nruns;
-        sos_fwd_seal(g.segcnt, yr, np * pairlen, nr_,
-                     [=](int q) { return (((int64_t)(q + 1) * np) / nr_) * pairlen; },
-                     g.sos_state_out, g.nsec, (int)gridDim.y, c);
-    }
 }
 
 }  // namespace osz
@@ -264,7 +254,6 @@ static int chain_forward_impl(osz_fir_t fir, osz_sos_t sos, const double *x, int
             g.npairs = npairs;
             g.nruns = (int)nruns;
             g.pre_pairs = (int)pre;
-            g.segcnt = sos_nanfix() ? sos->dsegcnt : nullptr;
             using kern_t = void (*)(ChainArgs, const SosSection *);
             static const kern_t kerns1[8] = {chain_kernel<8, false>,  chain_kernel<9, false>,
                                              chain_kernel<10, false>, chain_kernel<11, false>,
@@ -285,6 +274,13 @@ static int chain_forward_impl(osz_fir_t fir, osz_sos_t sos, const double *x, int
                                    st, g, dsec);
             }
             OSZ_HIP(hipGetLastError());
+            {
+                // NaN reach (sos_tile.h): a run that started from zero states knows nothing of
+                // a NaN the cascade met before its pre-roll
+                int rcs = sos_seal_launch(f + head, ldf, npairs * pair, (int)nruns, npairs, nruns, pair,
+                                          g.sos_state_out, sos->nsec, fir->nch, nullptr, 0, 0, st);
+                if (rcs) return rcs;
+            }
             pt.cur ^= 1;
             std::swap(sos->dstate, sos->dstate_alt);
             whole = npairs * pair;

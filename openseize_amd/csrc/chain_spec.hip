@@ -72,7 +72,6 @@ struct SpecArgs {
     double *carry_out;
     double *hist;              // (nch, hist_len): the chunk's last hist_len input samples, or null
     int hist_len;
-    int *segcnt;               // (nch) arrival counters of the runs
 };
 
 // A workgroup walks a run of whole pairs of blocks of one channel (fast path);
@@ -357,14 +356,6 @@ __global__ __launch_bounds__(256, 2) void chain_spec_kernel(SpecArgs g) {
             for (int i = t; i < g.hist_len; i += 256) hr[i] = src[i];
         }
     }
-    if (g.nruns > 1 && g.segcnt) {
-        const int64_t pairlen = 2 * (int64_t)S, Wp = g.W;
-        const int nr_ = g.nruns;
-        const int64_t ntot = g.n;
-        spec_seal(g.segcnt, yr, ntot, nr_,
-                  [=](int q) { return q == nr_ - 1 ? ntot : (((int64_t)(q + 1) * Wp) / nr_) * pairlen; },
-                  g.carry_out + (int64_t)c * kSpecLdc, c);
-    }
 }
 
 // A NaN never leaves the cascade (sos_tile.h, "NaN reach"); the replay of spec_settle
@@ -608,7 +599,6 @@ int spec_try_forward(osz_fir_s *fir, osz_sos_s *sos, const double *x, int64_t ld
     g.Lrow = s->dL;
     g.carry_in = s->dcarry[s->cur];
     g.carry_out = s->dcarry[s->cur ^ 1];
-    g.segcnt = sos_nanfix() ? sos->dsegcnt : nullptr;
     // the input a later spec_settle replays: the kernel's last run copies the chunk's
     // last hist_cap samples; shorter chunks are appended here
     if (n >= s->hist_cap) {
@@ -643,6 +633,13 @@ int spec_try_forward(osz_fir_s *fir, osz_sos_s *sos, const double *x, int64_t ld
         hipLaunchKernelGGL(kern, dim3((unsigned)nruns, fir->nch), dim3(256), lds, st, g);
     }
     OSZ_HIP(hipGetLastError());
+    {
+        // NaN reach of the forward pass across runs (sos_tile.h): from the first run whose last
+        // output is not finite the rest of the chunk and the carry are NaN
+        int rcs = sos_seal_launch(g.f.y, g.f.ldy, n, (int)nruns, W, nruns, 2 * (int64_t)S, nullptr, 0, fir->nch,
+                                  g.carry_out, kSpecLdc, kSpecLdc, st);
+        if (rcs) return rcs;
+    }
     s->cur ^= 1;
     s->true_valid = false;
     *taken = true;

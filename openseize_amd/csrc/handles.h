@@ -55,8 +55,6 @@ struct osz_sos_s {
     double *dtmp;       // device (nsec, nch, 2): warm-up state of sosfiltfilt
     double *dcarry;     // device (nsec, nch, 2): state between the main and remainder launches
     double *dzi;        // device (nsec, 2): sosfilt_zi of this cascade
-    int *dsegcnt;       // device (nch): arrival counters of a forward pass's time segments
-                        // (sos_fwd_seal; zero between launches)
     int touch;          // tuning knob OSZ_SOS_TOUCH: touch-prefetch of the next tile
     double *dtab2;      // device [nsec][4][66]: A^(T k) per section for sos_body2, or null
     // osz_chain_step: the backward pass runs beside the fused forward kernel on a
@@ -75,6 +73,9 @@ struct osz_sos_s {
 namespace osz {
 // false under OSZ_SOS_NANFIX=0 (A/B knob, sos.hip)
 bool sos_nanfix();
+// NaN reach of a forward pass cut into runs (sos.hip): a small launch behind the pass
+int sos_seal_launch(double *y, int64_t ldy, int64_t n, int nseg, int64_t A, int64_t B, int64_t C, double *state,
+                    int nsec, int nch, double *carry, int64_t ldcarry, int64_t ncarry, hipStream_t st);
 // process-wide twiddle tables on the device (fir.hip)
 int get_fft_tables(fft::Tables &out);
 // per-section tables of a cascade for a tile of T samples per lane, built on

@@ -50,11 +50,10 @@ struct SosArgs {
     const double *prex;
     int64_t ldprex, npre;
     // Non-finite samples (see "NaN reach" below).  probe: backward passes, one sample per
-    // channel (row pitch ldprobe) whose being non-finite makes the whole pass NaN;
-    // segcnt: forward passes in time segments, one arrival counter per channel.
+    // channel (row pitch ldprobe) whose being non-finite makes the whole pass NaN
+    // (forward passes in time segments: sos_seal_launch behind the pass).
     const double *probe;
     int64_t ldprobe;
-    int *segcnt;
 };
 
 // In-kernel phase stamps for the diagnostic build only
@@ -812,9 +811,6 @@ __device__ __forceinline__ void sos_segment(const SosArgs &a, const SosSection *
         return;
     }
     sos_body<T, NW, REV, false, LEAN>(b, sec, c, s > 0, p / ((int64_t)NW * 64 * T));
-    if (!REV && a.segcnt)
-        sos_fwd_seal(a.segcnt, a.y + (int64_t)c * a.ldy, a.n, nseg,
-                     [seglen](int q) { return (int64_t)(q + 1) * seglen; }, a.state_out, a.nsec, a.nch, c);
 }
 
 // One pass, grid (nch, nseg): fills the chip when there are few channels.
@@ -859,9 +855,6 @@ __device__ __forceinline__ void sos_segment2(const SosArgs &a, const SosSection 
         return;
     }
     sos_body2<T, NW, REV, AL16, PF>(b, sec, gtab, c, s > 0, p / ((int64_t)NW * 64 * T));
-    if (!REV && a.segcnt)
-        sos_fwd_seal(a.segcnt, a.y + (int64_t)c * a.ldy, a.n, nseg,
-                     [seglen](int q) { return (int64_t)(q + 1) * seglen; }, a.state_out, a.nsec, a.nch, c);
 }
 
 template <int T, int NW, bool REV, bool AL16, bool PF>
@@ -890,6 +883,51 @@ static constexpr bool sos_pf() { return false; }
 
 // (sos_tile.h) -- A/B knob for tests/test_gpu_nonfinite.py, which fails with it
 bool sos_nanfix() { return true; }
+
+// NaN reach of a forward pass cut into runs (sos_tile.h): run q ends before sample
+// ((q + 1) A / B) C of the channel's row; from the first run whose last output is not finite
+// the rest of the row, the carried section states and / or a carried row become NaN.
+struct SealArgs {
+    double *y;
+    int64_t ldy, n;
+    int nseg;
+    int64_t A, B, C;
+    double *state;       // (nsec, nch, 2) or null
+    int nsec, nch;
+    double *carry;       // (nch, ldcarry) or null
+    int64_t ldcarry, ncarry;
+};
+
+__global__ void sos_seal_kernel(SealArgs g) {
+    __shared__ int sbad;
+    const int c = blockIdx.x, t = threadIdx.x;
+    double *yr = g.y + (int64_t)c * g.ldy;
+    if (t == 0) sbad = g.nseg;
+    __syncthreads();
+    for (int s = t; s < g.nseg - 1; s += blockDim.x) {
+        const int64_t e = (((int64_t)(s + 1) * g.A) / g.B) * g.C;
+        if (sos_not_finite(yr[e - 1])) {
+            atomicMin(&sbad, s);
+            break;
+        }
+    }
+    __syncthreads();
+    const int bad = sbad;
+    if (bad == g.nseg) return;
+    const int64_t from = (((int64_t)(bad + 1) * g.A) / g.B) * g.C;
+    sos_fill_nan(yr + from, g.n - from);
+    sos_state_nan(g.state, g.nsec, g.nch, c);
+    if (g.carry) sos_fill_nan(g.carry + (int64_t)c * g.ldcarry, g.ncarry);
+}
+
+int sos_seal_launch(double *y, int64_t ldy, int64_t n, int nseg, int64_t A, int64_t B, int64_t C, double *state,
+                    int nsec, int nch, double *carry, int64_t ldcarry, int64_t ncarry, hipStream_t st) {
+    if (!sos_nanfix() || nseg < 2 || !y) return OSZ_OK;
+    SealArgs g{y, ldy, n, nseg, A, B, C, state, nsec, nch, carry, ldcarry, ncarry};
+    hipLaunchKernelGGL(sos_seal_kernel, dim3(nch), dim3(nseg > 65 ? 256 : 64), 0, st, g);
+    OSZ_HIP(hipGetLastError());
+    return OSZ_OK;
+}
 
 static bool sos_rows_aligned16(const SosArgs &a) {
     auto ok = [](const void *p, int64_t ld) {
@@ -1158,6 +1196,9 @@ static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
                                    a.tab2, (int)nseg, seg_tiles * tile, warm_len);
             }
             OSZ_HIP(hipGetLastError());
+            if (!REV)
+                return sos_seal_launch(a.y, a.ldy, a.n, (int)nseg, 1, 1, seg_tiles * tile, a.state_out, a.nsec,
+                                       a.nch, nullptr, 0, 0, st);
             return OSZ_OK;
         }
     }
@@ -1171,6 +1212,9 @@ static int sos_launch_main(const SosArgs &a, int64_t warm_len, hipStream_t st) {
                            (int)nseg, seg_tiles * tile, warm_len);
     }
     OSZ_HIP(hipGetLastError());
+    if (!REV)
+        return sos_seal_launch(a.y, a.ldy, a.n, (int)nseg, 1, 1, seg_tiles * tile, a.state_out, a.nsec, a.nch,
+                               nullptr, 0, 0, st);
     return OSZ_OK;
 }
 
@@ -1312,8 +1356,6 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     OSZ_HIP(hipMalloc(&p->dstate_alt, sb));
     OSZ_HIP(hipMalloc(&p->dtmp, sb));
     OSZ_HIP(hipMalloc(&p->dcarry, sb));
-    OSZ_HIP(hipMalloc(&p->dsegcnt, sizeof(int) * (size_t)nch));
-    OSZ_HIP(hipMemset(p->dsegcnt, 0, sizeof(int) * (size_t)nch));
     OSZ_HIP(hipMalloc(&p->dzi, sizeof(double) * nsec * 2));
     OSZ_HIP(hipMemcpy(p->dsec, secs.data(), sizeof(SosSection) * nsec, hipMemcpyHostToDevice));
     OSZ_HIP(hipMemset(p->dstate, 0, sb));
@@ -1388,7 +1430,6 @@ int osz_sos_destroy(osz_sos_t h) {
     (void)hipFree(h->dstate_alt);
     (void)hipFree(h->dtmp);
     (void)hipFree(h->dcarry);
-    (void)hipFree(h->dsegcnt);
     (void)hipFree(h->dzi);
     (void)hipFree(h->dtab2);
     (void)hipFree(h->dtmp_side);
@@ -1489,7 +1530,6 @@ int osz::sos_forward_raw(osz_sos_s *h, const double *x, int64_t ldx, double *y, 
     a.nch = h->nch;
     a.tab2 = h->dtab2;
     a.touch = h->touch;
-    a.segcnt = sos_nanfix() ? h->dsegcnt : nullptr;
     int rc = sos_launch<false>(a, h->dcarry, h->T, h->NW, h->warm_len, as_stream(stream));
     if (rc) return rc;
     std::swap(h->dstate, h->dstate_alt);
@@ -1546,7 +1586,6 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
     w.zi_unit = fw.zi_unit = bw.zi_unit = h->dzi;
     w.tab2 = fw.tab2 = bw.tab2 = h->dtab2;
     w.touch = fw.touch = bw.touch = h->touch;
-    fw.segcnt = sos_nanfix() ? h->dsegcnt : nullptr;
     // NaN reach of the backward pass: the last sample of what it is initialised from
     w.probe = bw.probe = !sos_nanfix() ? nullptr : fb ? fb + (nb - 1) : fa + (na - 1);
     w.ldprobe = bw.ldprobe = fb ? ldfb : ldfa;
@@ -1614,6 +1653,11 @@ int osz_sosfiltfilt_step(osz_sos_t h, const double *x, int64_t ldx, int64_t nx, 
                                    h->dsec, nseg, sf, sb, h->warm_len);
             }
             OSZ_HIP(hipGetLastError());
+            {
+                int rcs = sos_seal_launch(fw.y, fw.ldy, fw.n, nseg, 1, 1, sf, fw.state_out, fw.nsec, fw.nch, nullptr,
+                                          0, 0, st);
+                if (rcs) return rcs;
+            }
             std::swap(h->dstate, h->dstate_alt);
             return OSZ_OK;
         }

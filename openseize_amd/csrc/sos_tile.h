@@ -290,10 +290,12 @@ __device__ __forceinline__ void sos_tile_full2(double *v, const SosSection *__re
 //    and the reference warms up over the whole of chunk i + 1).  Every workgroup
 //    reads that one sample (`probe`) first and, if so, writes NaN instead of
 //    filtering;
-//  * forward pass: the workgroup of a channel that finishes LAST (arrival counter,
-//    device-scope fence) looks at the final output sample of every earlier segment;
-//    from the first one that is not finite, the rest of the chunk and the carried
-//    state are overwritten with NaN.
+//  * forward pass: a small launch behind the pass (`sos_seal_launch`, sos.hip) looks at
+//    the final output sample of every segment but the last; from the first one that is
+//    not finite, the rest of the chunk and the carried state are overwritten with NaN.
+//    (It used to be the workgroup of a channel that finished last, behind an arrival
+//    counter: every workgroup then pays an agent-scope release -- a write-back of its
+//    XCD's L2 -- on its way out, 5 % of a dual launch.)
 __device__ __forceinline__ bool sos_not_finite(double v) { return !(fabs(v) <= 1.79769313486231570815e308); }
 
 __device__ __forceinline__ void sos_fill_nan(double *__restrict__ y, int64_t n) {
@@ -307,36 +309,6 @@ __device__ __forceinline__ void sos_state_nan(double *__restrict__ state_out, in
         state_out[((int64_t)threadIdx.x * nch + c) * 2 + 0] = qnan;
         state_out[((int64_t)threadIdx.x * nch + c) * 2 + 1] = qnan;
     }
-}
-
-// forward pass of `n` samples in `nseg` segments, segment q ending before sample
-// end_of(q): called by every segment's workgroup after its last store.  y: the
-// channel's row.
-template <class EndOf>
-__device__ __forceinline__ void sos_fwd_seal(int *__restrict__ segcnt, double *__restrict__ y,
-                                             int64_t n, int nseg, EndOf end_of,
-                                             double *__restrict__ state_out, int nsec, int nch, int c) {
-    __syncthreads();
-    int last = 0;
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(segcnt + c, 1) == nseg - 1;
-    }
-    last = __syncthreads_or(last);
-    if (!last) return;
-    if (threadIdx.x == 0) atomicExch(segcnt + c, 0);     // ready for the next launch
-    __threadfence();
-    int bad = nseg;
-    for (int s = nseg - 2; s >= 0; --s) {
-        const unsigned long long bits = __hip_atomic_load(
-            reinterpret_cast<const unsigned long long *>(y + end_of(s) - 1),
-            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (sos_not_finite(__longlong_as_double((long long)bits))) bad = s;
-    }
-    if (bad == nseg) return;
-    const int64_t from = end_of(bad);
-    sos_fill_nan(y + from, n - from);
-    sos_state_nan(state_out, nsec, nch, c);
 }
 
 }  // namespace osz
