@@ -107,6 +107,26 @@ __device__ __forceinline__ void take_turns() {
     else __builtin_amdgcn_s_setprio(0);
 }
 
+// Buffer addressing for rows of one channel: the base (a uniform pointer) and the row's byte
+// offset travel in scalar registers, a lane contributes one 32-bit offset -- no 64-bit vector
+// arithmetic per access, which is what `p[256 * j + t]` costs once the immediate field (4 KB)
+// is exceeded.  Raw buffer, stride 0; word 3 as gfx90a / gfx942 / gfx950 want it.
+typedef unsigned buf_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned buf_u4 __attribute__((ext_vector_type(4)));
+typedef double buf_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, row_bytes, 0));
+}
+__device__ __forceinline__ buf_d2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes) {
+    return __builtin_bit_cast(buf_d2, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, row_bytes, 0));
+}
+__device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_u2, v), r, lane_bytes, row_bytes, 0);
+}
+
 // rccl.hip: in-place all-reduce(sum) of `count` float64 / int64 elements over
 // the ranks of an ncclComm_t; RCCL is bound at run time (dlopen)
 int rccl_allreduce_sum(void *buf, size_t count, bool is_f64, void *comm, hipStream_t st);

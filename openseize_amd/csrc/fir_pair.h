@@ -193,11 +193,16 @@ struct FirPair {
         else fft::cube::f2(t, re, im, tw2, L);
         // HPRE > 0: that many filter-spectrum bins are requested before the barrier
         double hr[HPRE > 0 ? HPRE : 1], hi[HPRE > 0 ? HPRE : 1];
+        // (a bin's byte offset from a 32-bit, provably small lane index: the loads take the
+        // spectrum's address from scalar registers and need no 64-bit vector arithmetic)
+        const unsigned tu = (unsigned)t & 255u;
+        const d2_t *H2 = reinterpret_cast<const d2_t *>(a.H);
 #pragma unroll
         for (int r = 0; r < ((HPRE > 0 && !(PF2 && REQ)) ? HPRE : 0); ++r) {
-            const int k = CUBE2 ? 256 * r + t : t + 256 * fft::dr(r);
-            hr[r] = a.H[2 * k];
-            hi[r] = a.H[2 * k + 1];
+            const unsigned k = CUBE2 ? 256u * r + tu : tu + 256u * fft::dr(r);
+            const d2_t h = H2[k];
+            hr[r] = h.x;
+            hi[r] = h.y;
         }
         OSZ_FSTAMP(3);   // pass 2
         if (CUBE2) wave_lds_fence();
@@ -209,11 +214,11 @@ struct FirPair {
         if (PF2 && REQ) wait_spectrum();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int k = CUBE2 ? 256 * r + t : t + 256 * fft::dr(r);
+            const unsigned k = CUBE2 ? 256u * r + tu : tu + 256u * fft::dr(r);
             if (PF2 && REQ) fft::cube::cmul(re[r], im[r], Hn[PF2 ? r : 0].x, Hn[PF2 ? r : 0].y);
             else if (HPRE < 0) fft::cube::cmul(re[r], im[r], Hr[HPRE < 0 ? r : 0], Hi[HPRE < 0 ? r : 0]);
             else if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
-            else fft::cube::cmul(re[r], im[r], a.H[2 * k], a.H[2 * k + 1]);
+            else fft::cube::cmul(re[r], im[r], H2[k].x, H2[k].y);
         }
         // unconditional requests: nx must be dead above this line
         if (PF && REQ) request_next(next_blk);
