@@ -111,7 +111,7 @@ __device__ __forceinline__ double zp_dot(const double *kk, const double *pr, con
 //   kapN[k][r][q]     k = 0 mu_b, 1 nu_b: what the NEXT pair meets as mu_pb, nu_pb
 template <int NM, int PER>
 __device__ __forceinline__ void zp_fit_kappa_n(int tt, int R, const double *fitbuf, const double *mtab,
-                                               const double *lrow, double *kapA, double *kapN, int *badflag) {
+                                               const double *lrow, double *kapA, double *kapN) {
     constexpr int ns = 4 * PER;
     const int qd = tt >> 2, p4 = tt & 3;
     const bool valid = qd < 4 * NM;
@@ -146,9 +146,6 @@ __device__ __forceinline__ void zp_fit_kappa_n(int tt, int R, const double *fitb
     sr += dpp_row_shr0<2>(sr);
     si += dpp_row_shr0<2>(si);
     if (p4 == 3 && valid) {
-        // non-finite samples anywhere in the pair are non-finite everywhere behind the
-        // transform: every amplitude sees them
-        if (sos_not_finite(sr) || sos_not_finite(si)) *badflag = 1;
         const int amp = kind * 2 + blk;
         double lr[kSpecRMax], li[kSpecRMax];
 #pragma unroll
@@ -174,10 +171,10 @@ __device__ __forceinline__ void zp_fit_kappa_n(int tt, int R, const double *fitb
 // nh is 16, 24 or 32 (spec::build_zp)
 template <int NM>
 __device__ __forceinline__ void zp_fit_kappa(int tt, int nh, int R, const double *fitbuf, const double *mtab,
-                                             const double *lrow, double *kapA, double *kapN, int *badflag) {
-    if (nh == 24) zp_fit_kappa_n<NM, 12>(tt, R, fitbuf, mtab, lrow, kapA, kapN, badflag);
-    else if (nh == 32) zp_fit_kappa_n<NM, 16>(tt, R, fitbuf, mtab, lrow, kapA, kapN, badflag);
-    else zp_fit_kappa_n<NM, 8>(tt, R, fitbuf, mtab, lrow, kapA, kapN, badflag);
+                                             const double *lrow, double *kapA, double *kapN) {
+    if (nh == 24) zp_fit_kappa_n<NM, 12>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+    else if (nh == 32) zp_fit_kappa_n<NM, 16>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+    else zp_fit_kappa_n<NM, 8>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
 }
 
 // Three bursts of one row at once: every operand first, two chains per burst.
@@ -297,7 +294,6 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     double *lrow = kapP + 4 * R * NM * 2;              // [R][NM][2]
     double *ptab = lrow + R * NM * 2;                  // [20][NM][2]
     double *mtab = ptab + 20 * NM * 2;                 // [4 NM][2 nh]
-    int *badflag = reinterpret_cast<int *>(mtab + 4 * NM * ns);
     const FirArgs &a = g.f;
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
     const int L = 256 * R;
@@ -327,12 +323,12 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     double held[kSpecRMax];          // rows NR-1-r of the previous pair's block b, one burst short
 #pragma unroll
     for (int r = 0; r < kSpecRMax; ++r) held[r] = 0.0;
-    // `bad` is uniform (a scalar): the stream went bad in an earlier chunk, or a fit of this run
-    // met non-finite samples (the fit lanes raise badflag; sticky)
+    // `bad` is uniform (a scalar), and sticky: the stream went bad in an earlier chunk, or a pair
+    // of this run held non-finite samples -- behind the transform they are everywhere, every
+    // amplitude of the fit and with it every lane's burst values are non-finite
     bool bad = g.nanpos[c] != 0x7fffffffffffffffLL;
     int64_t bad_at = 0;              // chunk position of the pair that went bad
     int par = 0;
-    if (t == 0) *badflag = 0;
     const unsigned lane8 = 8u * (unsigned)t;   // a lane's byte offset inside a row of 256 samples
     __syncthreads();
     OSZ_ZMARK(1);
@@ -390,13 +386,9 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         OSZ_ZSTAMP(13);   // barrier
         // fit and amplitudes: this pair's into kapA, block b's also into the other half of
         // kapP for the next pair
-        zp_fit_kappa<NM>(tt, nh, R, fitbuf, mtab, lrow, kapA, kapP + (par ^ 1) * (2 * R * NM * 2), badflag);
+        zp_fit_kappa<NM>(tt, nh, R, fitbuf, mtab, lrow, kapA, kapP + (par ^ 1) * (2 * R * NM * 2));
         __syncthreads();
         OSZ_ZSTAMP(14);   // fit + amplitudes + barrier
-        if (!bad && __builtin_amdgcn_readfirstlane(*badflag)) {
-            bad = true;
-            bad_at = o;
-        }
         const double *kap = kapA, *kpb = kapP + par * (2 * R * NM * 2);
         // Six burst evaluations per row index r serve the eight places a burst lands: the
         // wrapped right tail of block a leaves its row r and arrives, one window on, in row
@@ -419,6 +411,10 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
                 case 3: zp_fwd_bursts<NR, NM, 3>(re, im, kap, kpb, R, Pr, Pi, ca, cb); break;
                 case 4: zp_fwd_bursts<NR, NM, 4>(re, im, kap, kpb, R, Pr, Pi, ca, cb); break;
                 default: zp_fwd_bursts<NR, NM, 5>(re, im, kap, kpb, R, Pr, Pi, ca, cb); break;
+            }
+            if (!bad && __builtin_amdgcn_readfirstlane((int)(sos_not_finite(ca) || sos_not_finite(cb)))) {
+                bad = true;
+                bad_at = o;
             }
             __builtin_amdgcn_sched_barrier(0);
             zp_powers<NM>(ptab, 255 - tt, Pr, Pi);
@@ -530,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             fitbuf[ns + tt - 256 + ns] = im[15];
         }
         __syncthreads();     // also: every thread is done reading the cube
-        zp_fit_kappa<NM>(tt, nh, R, fitbuf, mtab, lrow, kapA, kapP + (par ^ 1) * (2 * R * NM * 2), badflag);
+        zp_fit_kappa<NM>(tt, nh, R, fitbuf, mtab, lrow, kapA, kapP + (par ^ 1) * (2 * R * NM * 2));
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             acc[256 * j + t] = re[j] + (j < D ? P.cr[j < D ? j : 0] : 0.0);
@@ -539,8 +535,15 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[la + 256 * j + t] += im[j];
-        // (non-finite amplitudes poison the rest of the stream: badflag, read behind the barrier
-        // below)
+        {
+            // non-finite amplitudes poison the rest of the stream
+            bool nf = false;
+            for (int i = 0; i < 4 * NM * 2; ++i) nf = nf || sos_not_finite(kapA[((i / (NM * 2)) * R) * NM * 2 + i % (NM * 2)]);
+            if (!bad && __builtin_amdgcn_readfirstlane((int)nf)) {
+                bad = true;
+                bad_at = o;
+            }
+        }
         double Pfr[NM], Pfi[NM], Pbr[NM], Pbi[NM];
         zp_powers<NM>(ptab, tt, Pfr, Pfi);
         zp_powers<NM>(ptab, 255 - tt, Pbr, Pbi);
@@ -549,10 +552,6 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         // "next" entries from the other half of kapP
         const double *kpb = kapP + par * (2 * R * NM * 2), *kpn = kapP + (par ^ 1) * (2 * R * NM * 2);
         __syncthreads();
-        if (!bad && __builtin_amdgcn_readfirstlane(*badflag)) {
-            bad = true;
-            bad_at = o;
-        }
         for (int s = 0; s < 10; ++s) {
             const double *tab = s == 0 ? kpb : s == 1 ? kapA : s == 2 ? kpn : s == 3 ? kapA : s == 4 ? kpn
                               : s == 5 ? kpb + R * NM * 2 : s == 6 ? kapA + 2 * R * NM * 2 : s == 7 ? kapA + 2 * R * NM * 2
@@ -692,7 +691,7 @@ void zp_unlink(ChainZp *s) {
 static size_t zp_lds_bytes(const ChainZp *s) {
     const int NM = s->NM, R = s->R, ns = 2 * s->nh;
     return sizeof(fft::cube::C2) * fft::cube::SLOTS +
-           sizeof(double) * (2 * ns + 8 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * ns + 2);   // + badflag
+           sizeof(double) * (2 * ns + 8 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * ns);
 }
 
 static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
@@ -709,7 +708,7 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
         fir->zp = sos->zp = s;
         if (fir->parts.size() == 1 && fir->nch == sos->nch) {
             const spec::TablesZp T = spec::build_zp(fir->htaps.data(), fir->ntaps, sos->coef, sos->nsec,
-                                                    sos->warm_len <= (1 << 20), 15360 - 16);   // 16: badflag
+                                                    sos->warm_len <= (1 << 20));
             if (T.eligible) {
                 auto up = [](double **d, const std::vector<double> &v) -> int {
                     OSZ_HIP(hipMalloc(d, v.size() * sizeof(double)));

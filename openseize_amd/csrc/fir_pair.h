@@ -195,12 +195,13 @@ struct FirPair {
         double hr[HPRE > 0 ? HPRE : 1], hi[HPRE > 0 ? HPRE : 1];
         // (a bin's byte offset from a 32-bit, provably small lane index: the loads take the
         // spectrum's address from scalar registers and need no 64-bit vector arithmetic)
-        const unsigned tu = (unsigned)t & 255u;
-        const d2_t *H2 = reinterpret_cast<const d2_t *>(a.H);
+        // (buffer addressing, common.h: the spectrum's address and a bin row's offset in scalar
+        // registers, one 32-bit lane offset)
+        const unsigned lane16 = 16u * ((unsigned)t & 255u);
+        const __amdgpu_buffer_rsrc_t rh = buf_rsrc(a.H);
 #pragma unroll
         for (int r = 0; r < ((HPRE > 0 && !(PF2 && REQ)) ? HPRE : 0); ++r) {
-            const unsigned k = CUBE2 ? 256u * r + tu : tu + 256u * fft::dr(r);
-            const d2_t h = H2[k];
+            const buf_d2 h = buf_load2(rh, lane16, 4096u * (CUBE2 ? r : fft::dr(r)));
             hr[r] = h.x;
             hi[r] = h.y;
         }
@@ -214,11 +215,13 @@ struct FirPair {
         if (PF2 && REQ) wait_spectrum();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const unsigned k = CUBE2 ? 256u * r + tu : tu + 256u * fft::dr(r);
             if (PF2 && REQ) fft::cube::cmul(re[r], im[r], Hn[PF2 ? r : 0].x, Hn[PF2 ? r : 0].y);
             else if (HPRE < 0) fft::cube::cmul(re[r], im[r], Hr[HPRE < 0 ? r : 0], Hi[HPRE < 0 ? r : 0]);
             else if (r < HPRE) fft::cube::cmul(re[r], im[r], hr[r < HPRE ? r : 0], hi[r < HPRE ? r : 0]);
-            else fft::cube::cmul(re[r], im[r], H2[k].x, H2[k].y);
+            else {
+                const buf_d2 h = buf_load2(rh, lane16, 4096u * (CUBE2 ? r : fft::dr(r)));
+                fft::cube::cmul(re[r], im[r], h.x, h.y);
+            }
         }
         // unconditional requests: nx must be dead above this line
         if (PF && REQ) request_next(next_blk);
@@ -247,7 +250,8 @@ struct FirPair {
     __device__ __forceinline__ void fast_pair(int64_t blk) {
         const int64_t start_a = blk * a.step;
         double re[16], im[16];
-        const double *pa = xr + start_a + t;
+        const unsigned lane8 = 8u * (unsigned)t;
+        const __amdgpu_buffer_rsrc_t rx = buf_rsrc(xr + start_a);
         // first whole pair of the run: its spectrum goes out ahead of its (compiler
         // tracked) sample loads -- older than them, landed when they have
         if (PF2 && !FROM_NX) request_spectrum();
@@ -257,8 +261,8 @@ struct FirPair {
                 re[j] = j < NR ? nx[PF ? (j < NR ? j : 0) : 0] : 0.0;
                 im[j] = j < NR ? nx[PF ? (j < NR ? NR + j : 0) : 0] : 0.0;
             } else {
-                re[j] = j < NR ? pa[256 * j] : 0.0;
-                im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
+                re[j] = j < NR ? buf_load(rx, lane8, 2048u * j) : 0.0;
+                im[j] = j < NR ? buf_load(rx, lane8, 2048u * (j + NR)) : 0.0;
             }
         }
         if (PF2 && !FROM_NX) {
@@ -288,10 +292,11 @@ struct FirPair {
                 qa[256 * (j + NR)] += im[j];
             }
         } else {
+            const __amdgpu_buffer_rsrc_t ry = buf_rsrc(yr + (start_a - a.skip));
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
-                qa[256 * j] = re[j];
-                qa[256 * (j + NR)] = im[j];
+                buf_store(re[j], ry, lane8, 2048u * j);
+                buf_store(im[j], ry, lane8, 2048u * (j + NR));
             }
         }
         OSZ_FSTAMP(11);  // inverse pass 1 + overlap add + stores issued
