@@ -113,6 +113,9 @@ template <int NM, int PER>
 __device__ __forceinline__ void zp_fit_kappa_n(int tt, int R, const double *fitbuf, const double *mtab,
                                                const double *lrow, double *kapA, double *kapN) {
     constexpr int ns = 4 * PER;
+    // 16 NM lanes have an amplitude to work on: the waves behind them skip the stage (whole
+    // waves: the DPP steps below want their quads complete)
+    if ((tt & ~63) >= 16 * NM) return;
     const int qd = tt >> 2, p4 = tt & 3;
     const bool valid = qd < 4 * NM;
     const int blk = valid ? qd / (2 * NM) : 0, kind = valid ? (qd / NM) % 2 : 0, q = valid ? qd % NM : 0;
