@@ -367,6 +367,14 @@ int osz_rccl_comm_destroy(void *comm);
 int osz_rccl_comm_size(void *comm, int *nranks);
 int osz_welch_reduce(osz_spec_t h, void *comm, void *stream);
 
+/* ---- host side of host-fed streams -------------------------------------- */
+/* dst[r][0, row_bytes) = src[r][0, row_bytes), r < rows; rows dst_pitch / src_pitch bytes
+ * apart, host memory both: packs a chunk of a host ndarray -- a column range of a C-ordered
+ * array, what the reference's ArrayProducer slices (core/producer.py:289-295) -- into a
+ * pinned staging buffer over a few persistent threads; returns when the rows are in place. */
+int osz_host_copy2d(void *dst, int64_t dst_pitch, const void *src, int64_t src_pitch,
+                    int64_t rows, int64_t row_bytes);
+
 /* ---- K7: mask compaction ---------------------------------------------- */
 /* y[c, j] = x[c, idx[j]], j < nidx: np.take(arr, np.flatnonzero(mask), axis)
  * of MaskedProducer.__iter__ (core/producer.py:432). idx: device int64. */

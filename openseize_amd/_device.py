@@ -76,7 +76,12 @@ def require_gpu():
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The calling thread's current stream, asked per call (a caller may switch streams
+    between chunks); the raw query costs a fraction of building a torch.cuda.Stream."""
+    try:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:   # pragma: no cover - other torch builds
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def ptr(t):
@@ -348,8 +353,16 @@ def _threaded_copy(dst, src):
     """dst[...] = src for 2-D arrays, split over a few threads (numpy releases
     the GIL in the copy): one core moves ~10 GB/s, PCIe wants more."""
     rows, cols = dst.shape
-    if dst.size < (1 << 18):
+    if dst.size < (1 << 16):
         np.copyto(dst, src)
+        return
+    if (src.ndim == 2 and src.dtype == dst.dtype and src.shape == dst.shape and cols > 0
+            and src.strides[1] == src.itemsize and dst.strides[1] == dst.itemsize
+            and src.strides[0] >= cols * src.itemsize and dst.strides[0] >= cols * dst.itemsize):
+        # a column range of a C-ordered array: rows a pitch apart -- the library's own threads
+        # (Python's pool spends most of a 4 MB copy waking its workers)
+        _lib.check(_lib.load().osz_host_copy2d(dst.ctypes.data, dst.strides[0], src.ctypes.data, src.strides[0],
+                                               rows, cols * src.itemsize))
         return
     parts = 8
     if rows >= parts:

@@ -146,6 +146,7 @@ SIGNATURES = {
     "osz_magphase": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "osz_simpson": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_i64, ctypes.c_double,
                                    c_vp, c_vp]),
+    "osz_host_copy2d": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "osz_take": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp,
                                 c_i64, c_vp]),
     "osz_edf_decode": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp,

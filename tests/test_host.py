@@ -497,3 +497,48 @@ def test_arraytools_extensions():
         at.even_extend(x, 4, axis=-1)
     assert np.array_equal(np.flatnonzero(at.filter1D(12, [slice(1, 3), [5, 7], 10])), [1, 2, 5, 7, 10])
     assert at.nearest1D(np.linspace(0, 1, 11), 0.33) == 3
+
+
+def test_host_copy2d_packs_column_ranges():
+    """osz_host_copy2d (hostpool.hip) -- the staging copy of host-fed streams: a column range
+    of a C-ordered array (what ArrayProducer slices, core/producer.py:289-295) into a packed or
+    pitched destination, bit for bit, for shapes on both sides of its splitting rules (few
+    rows of many bytes: split inside the rows; many rows; below the threshold: one memcpy
+    loop), from two Python threads at once (jobs are serialised inside), and its argument
+    checks.  Host code only: runs without a GPU."""
+    import threading
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((37, 300_000))
+
+    def check(r0, r1, c0, c1, pad=0):
+        src = base[r0:r1, c0:c1]
+        rows, cols = src.shape
+        dst = np.full((rows, cols + pad), -7.0)
+        rc = lib.osz_host_copy2d(dst.ctypes.data, dst.strides[0], src.ctypes.data, src.strides[0], rows, cols * 8)
+        assert rc == 0, lib.osz_last_error()
+        assert np.array_equal(dst[:, :cols], src)
+        assert pad == 0 or np.all(dst[:, cols:] == -7.0)
+
+    check(0, 16, 1000, 31000)            # cfg-1: 16 x 30 000
+    check(0, 2, 5, 290_005)              # two long rows: cut inside the rows
+    check(0, 37, 0, 300_000, pad=3)      # everything, into a pitched destination
+    check(3, 4, 17, 18)                  # one double
+    check(0, 37, 11, 4111)               # many short rows
+    check(5, 5, 0, 10)                   # no rows
+    errs = []
+
+    def worker(k):
+        try:
+            for q in range(20):
+                check(k, k + 16, 1000 * q + k, 1000 * q + k + 70_000)
+        except AssertionError as e:      # pragma: no cover - reported below
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in (0, 9)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    d = np.zeros((2, 8))
+    assert lib.osz_host_copy2d(d.ctypes.data, 32, base.ctypes.data, base.strides[0], 2, 64) != 0   # pitch < row
+    assert b"osz_host_copy2d" in lib.osz_last_error()
