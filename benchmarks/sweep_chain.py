@@ -9,6 +9,9 @@ tutorials run 4 channels.  One JSON line per (workload, channels):
   chain  FIR(1024) -> sosfiltfilt(6 sections), one osz_chain_zp_step (+ seal) per 2^20-sample chunk
   fir    FIR(1024) overlap-add alone (osz_fir_push)
   welch  Welch PSD nperseg 4096, 50 % overlap, segment average (osz_spec_push)
+  sosfiltfilt  the 6-section cascade alone, zero phase: one osz_chain_zp_step per chunk with the
+         identity as its FIR (what numerical.sosfiltfilt runs on long streams; `dual_ms`: the
+         separate kernels' osz_sosfiltfilt_step on the same box)
 `rel_256` is the rate relative to the same workload at 256 channels (printed last)."""
 import json
 import os
@@ -57,6 +60,34 @@ def chain(C, steps=24, warm=6):
     return dt, 48
 
 
+def sosfiltfilt(C, steps=24, warm=6):
+    import numpy as np
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    ring = [dev.synth_normal(C, CHUNK, seed=0, n0=k * CHUNK) for k in range(3)]
+    fir, iir = dev.FirStream(np.array([1.0, 0.0]), C), dev.SosStream(sos, C)
+    lag = dev.chain_zp_lag(fir, iir)
+    ys = [torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda") for _ in range(4)]
+    iir.set_state_scaled(ring[0], 0)
+    dev.chain_zp_open(fir, iir, 0)
+
+    def step(k):
+        dev.chain_zp_step(fir, iir, ring[k % 3], out=ys[k % 4][:, :CHUNK - lag], tail=ys[(k - 1) % 4][:, CHUNK - lag:])
+        if k >= 2:
+            dev.chain_zp_seal(fir, iir, ys[(k - 2) % 4], (k - 2) * CHUNK, 0, CHUNK)
+
+    dt = timed(step, steps, warm)
+    fir.close()
+    iir.close()
+    iir = dev.SosStream(sos, C)
+    iir.set_state_scaled(ring[0], 0)
+    dt2 = timed(lambda k: iir.step(ring[k % 3], ys[(k + 1) % 3], ys[(k + 2) % 3], f_out=ys[k % 3], y_out=ys[3]), steps, warm)
+    iir.close()
+    return dt, 32, {"dual_ms": dt2 * 1e3}
+
+
 def fir_only(C, steps=24, warm=6):
     import scipy.signal as sps
     import torch
@@ -85,15 +116,17 @@ def welch(C, steps=24, warm=6):
 
 if __name__ == "__main__":
     rows = []
-    for name, fn in (("chain", chain), ("fir", fir_only), ("welch", welch)):
+    for name, fn in (("chain", chain), ("fir", fir_only), ("welch", welch), ("sosfiltfilt", sosfiltfilt)):
         for C in (4, 8, 16, 32, 64, 128, 256):
             try:
-                dt, bps = fn(C)
+                dt, bps, *extra = fn(C)
             except Exception as exc:      # a workload this build does not offer in that form
                 print(json.dumps({"workload": name, "channels": C, "error": str(exc)[:200]}), flush=True)
                 continue
             rows.append({"workload": name, "channels": C, "chunksize": CHUNK, "ms_per_chunk": dt * 1e3,
                          "Gsamples_s": C * CHUNK / dt / 1e9, "algorithmic_TBps": bps * C * CHUNK / dt / 1e12})
+            for e in extra:
+                rows[-1].update(e)
     base = {r["workload"]: r["Gsamples_s"] for r in rows if r["channels"] == 256}
     for r in rows:
         r["rel_256"] = r["Gsamples_s"] / base[r["workload"]] if r["workload"] in base else None

@@ -188,3 +188,58 @@ def test_public_generators_take_the_kernel_and_match_the_reference_scheme(dev):
         want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, cs)
         gh = torch.cat(got, -1)[pick].cpu().numpy()
         assert np.max(np.abs(gh - want)) < RTOL * np.max(np.abs(want)), taps_n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fed", ["resident", "host"])
+def test_plain_sosfiltfilt_takes_the_zero_phase_kernel(dev, fed):
+    """sosfiltfilt with NO FIR in front of it (core/numerical.py:338-411) on long streams of
+    long chunks: the zero-phase kernel with the identity as its FIR, chunk for chunk against
+    the separate kernels (OSZ_CHAIN_ZP=0) and against the oracle's chunk-local scheme --
+    resident and host-fed, a ragged last chunk and a stream ending on a chunk boundary, a
+    cascade with a real pole, the sample axis first; a cascade the tables refuse (a narrow
+    band: ringing longer than the guard rows) and a short stream stay on the separate kernels."""
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import producer
+    from openseize_amd.core import numerical as nm
+
+    def run(x, sos, cs, axis):
+        return [c for c in nm.sosfiltfilt(producer(x, cs, axis), sos, axis)]
+
+    narrow = sps.butter(4, [0.01, 0.02], "bandpass", output="sos")
+    for sos, C, cs, total, axis, zp in ((BP, 64, 131072, 131072 * 6 + 4321, -1, True),
+                                        (sps.butter(5, 0.3, output="sos"), 5, 70000, 70000 * 7, 0, True),
+                                        (sps.cheby1(6, 0.5, 0.2, output="sos"), 3, 100001, 100001 * 6 + 17, -1, True),
+                                        (narrow, 4, 131072, 131072 * 6 + 5, -1, False),
+                                        (BP, 4, 131072, 131072 * 5, -1, False)):
+        xd = dev.synth_normal(C, total, seed=71)
+        if axis == 0:
+            xd = xd.t().contiguous()
+        x = xd.cpu().numpy() if fed == "host" else xd
+        steps, plain_zp = [], dev.chain_zp_step
+        dev.chain_zp_step = lambda *a, **k: (steps.append(1), plain_zp(*a, **k))[1]
+        try:
+            got = run(x, sos, cs, axis)
+        finally:
+            dev.chain_zp_step = plain_zp
+        nchunks = -(-total // cs)
+        assert len(steps) == (nchunks - 2 if zp else 0), (C, cs, len(steps))
+        os.environ["OSZ_CHAIN_ZP"] = "0"
+        try:
+            ref = run(x, sos, cs, axis)
+        finally:
+            del os.environ["OSZ_CHAIN_ZP"]
+        assert [g.shape for g in got] == [r.shape for r in ref]
+        assert all(isinstance(g, np.ndarray) == (fed == "host") for g in got)
+        to_np = (lambda a: a) if fed == "host" else (lambda a: a.cpu().numpy())
+        for k, (a, b) in enumerate(zip(got, ref)):
+            a, b = to_np(a), to_np(b)
+            assert np.max(np.abs(a - b)) < 1e-11 * np.max(np.abs(b)), (C, cs, k)
+        gh = np.concatenate([to_np(g) for g in got], axis)
+        xh = xd.cpu().numpy()
+        if axis == 0:
+            gh, xh = gh.T, xh.T
+        pick = [0, C // 2, C - 1]
+        want = orc.sosfiltfilt(xh[pick], sos, cs)
+        assert np.max(np.abs(gh[pick] - want)) < RTOL * np.max(np.abs(want)), (C, cs)
