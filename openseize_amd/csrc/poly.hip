@@ -82,6 +82,7 @@ struct PolyBlockArgs {
     const double *G;   // [L][M][apad] blocked sub-filters, zero padded
     int apad;          // taps per phase stream, multiple of kPolyBlk
     int se;            // LDS doubles per phase stream
+    int stepw, dqs;    // staging: threads of the workgroup rounded down to a multiple of M, / M
 };
 
 // ONE: L == 1 (decimation), a single class per tile.  NT threads produce
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(NT * EG, 3) void poly_block_kernel(PolyBlockArgs b)
     const int nstream = NJ + b.apad;               // entries per phase stream
     const int wtot = nstream * a.M;
     const int dq = NTH / a.M, dr = NTH - dq * a.M;
+    const int i00 = tw / a.M, e0 = tw - i00 * a.M;      // where a thread's first element goes
     for (int cls = 0; cls < L; ++cls) {
         const int64_t jf = J0 + cls;                    // first output of this class in the tile
         const int r = ONE ? 0 : (int)(jf % L);                  // its residue j mod L
@@ -124,22 +126,39 @@ __global__ __launch_bounds__(NT * EG, 3) void poly_block_kernel(PolyBlockArgs b)
         const int64_t i0 = itop - (msub - 1);           // window: inputs [i0, i0 + wtot)
         // staging walks w = t, t + NT, ...: (i, e) = (w div M, w mod M) advance by
         // (NT div M, NT mod M) with a carry, no division in the loop
-        int i = tw / a.M, e = tw - i * a.M;
-        if (i0 >= a.nin && i0 + wtot <= a.navail) {
-            // the whole window lies in the current chunk: plain coalesced loads,
-            // kPolyBatch in flight per thread, issued back to back, then placed
-            const double *src = xr + (i0 - a.nin);
-            for (int w = tw; w < wtot; w += kPolyBatch * NTH) {
+        int i = i00, e = e0;
+        if (i0 >= a.nin && i0 + wtot <= a.navail && a.M <= NTH) {
+            // The whole window lies in the current chunk: coalesced loads, kPolyBatch in flight
+            // per thread, issued back to back, then placed.  A thread's successive elements
+            // are a multiple of M apart (`stepw`, NTH rounded down), so its phase e never
+            // changes and its stream position advances by a constant: placing an element costs
+            // an add and the padding instead of a division's worth of carries; the NTH - stepw
+            // elements two steps both cover are written twice with the same value.  The loads
+            // go through a buffer descriptor (common.h) that ends with the window: the base and
+            // the step's offset travel in scalar registers, what lies behind the window reads 0.
+            const int stepw = b.stepw, dqs = b.dqs;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xr + (i0 - a.nin)), 0, wtot * 8, 0x00020000);
+            const unsigned lane8 = 8u * (unsigned)tw;
+            double *we = win + e0 * b.se;
+            int iu = i00;
+            for (int w0 = 0; w0 < wtot; w0 += kPolyBatch * stepw) {
                 double v[kPolyBatch];
 #pragma unroll
-                for (int u = 0; u < kPolyBatch; ++u)
-                    v[u] = (w + NTH * u < wtot) ? src[w + NTH * u] : 0.0;
+                for (int u = 0; u < kPolyBatch; ++u)      // (uniform: steps that start behind the window issue nothing)
+                    v[u] = w0 + u * stepw < wtot ? buf_load(rs, lane8, 8u * (unsigned)(w0 + u * stepw)) : 0.0;
+                if (w0 + kPolyBatch * stepw + NTH - stepw <= wtot) {
 #pragma unroll
-                for (int u = 0; u < kPolyBatch; ++u) {
-                    if (w + NTH * u < wtot) win[e * b.se + poly_pad(i)] = v[u];
-                    i += dq;
-                    e += dr;
-                    if (e >= a.M) { e -= a.M; ++i; }
+                    for (int u = 0; u < kPolyBatch; ++u) {
+                        we[poly_pad(iu)] = v[u];
+                        iu += dqs;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kPolyBatch; ++u) {
+                        if (iu < nstream) we[poly_pad(iu)] = v[u];
+                        iu += dqs;
+                    }
                 }
             }
         } else {
@@ -275,7 +294,9 @@ int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M, 
             const int nstream = nt * kPolyR + apad;
             const int se = (nstream + (nstream >> 2) + 2) | 1;   // odd: spreads the staging writes
             const size_t bytes = ((size_t)M * se + (L == 1 ? 0 : (size_t)nt * kPolyR * L)) * sizeof(double);
-            if (bytes <= (nt == 64 ? 64 : 53) * 1024) {
+            // (the smallest tile may take most of a CU's 160 KB: one workgroup per CU then, still
+            // fifty times the rate of the kernel that reads its window through the caches)
+            if (bytes <= (nt == 64 ? 150 : 53) * 1024) {
                 p->nt = nt;
                 p->se = se;
             }
@@ -378,7 +399,7 @@ int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n, int fin
         a.H = h->H;
         a.half = h->half;
         if (h->dG) {
-            PolyBlockArgs b{a, h->dG, h->apad, h->se};
+            PolyBlockArgs b{a, h->dG, h->apad, h->se, 0, 0};
             const size_t blds = sizeof(double) * ((size_t)h->M * h->se +
                                                   (h->L == 1 ? 0 : (size_t)h->nt * kPolyR * h->L));
             using kern_t = void (*)(PolyBlockArgs);
@@ -389,12 +410,16 @@ int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n, int fin
             static const kern_t kerns2[2][2] = {
                 {poly_block_kernel<true, 128, 2>, poly_block_kernel<true, 64, 2>},
                 {poly_block_kernel<true, 128, 4>, poly_block_kernel<true, 64, 4>}};
-            const int eg_on = 2;        // two phase groups per workgroup (four measured no faster)
+            // two phase groups per workgroup (four measured no faster); four when the window
+            // leaves room for one or two workgroups per CU only
+            const int eg_on = blds > 53 * 1024 ? 4 : 2;
             const int eg = (h->L == 1 && h->nt <= 128) ? (eg_on >= 4 && h->M >= 4 ? 4 : eg_on >= 2 && h->M >= 2 ? 2 : 1) : 1;
             const bool split = eg > 1;
             const kern_t kern = split ? kerns2[eg == 4 ? 1 : 0][h->nt == 128 ? 0 : 1]
                                       : kerns[h->L == 1 ? 1 : 0][h->nt == 256 ? 0 : h->nt == 128 ? 1 : 2];
-            OSZ_DYN_LDS(kern, 64 * 1024);
+            b.stepw = eg * h->nt - (eg * h->nt) % h->M;
+            b.dqs = b.stepw / h->M;
+            OSZ_DYN_LDS(kern, blds > 64 * 1024 ? blds : 64 * 1024);
             const int64_t per = (int64_t)h->nt * kPolyR * h->L;
             const int64_t bx = (cnt + per - 1) / per;
             KernelTimer kt("poly_block", st);

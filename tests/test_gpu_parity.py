@@ -1173,3 +1173,34 @@ def test_fir_then_sosfiltfilt_through_the_api_fused(osz):
     finally:
         del os.environ["OSZ_CHAIN_API"]
     assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-11 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_polyphase_large_decimation_stays_on_the_tiled_kernel(osz):
+    """Decimation by 13, 25 (the reference's tutorial: downsample(M=25), docs/tutorials/
+    resampling.ipynb:650) and 40 with the default Kaiser design (293 / 561 / 895 taps): the
+    window of the smallest tile takes 37 ... 113 KB of LDS and the tiled kernel still runs
+    (one or two workgroups per CU) instead of the kernel that reads its window through the
+    caches (60 ms instead of 0.93 per 256 x 2^20 at M = 25).  Ragged pushes against
+    scipy.signal.resample_poly of the whole array (what core/numerical.py:597-632 assembles
+    chunk by chunk)."""
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev
+    from openseize_amd.filtering.fir import Kaiser
+    for M, cuts in ((13, (150001, 400000)), (25, (70000, 70025, 400000)), (40, (399999, 400000))):
+        cut = 5000 / (2 * M)
+        h = Kaiser(cut - cut / 10, cut + cut / 10, 5000, gpass=0.1, gstop=40).coeffs
+        x = dev.synth_normal(5, 400000, seed=2)
+        poly = dev.PolyStream(h, 1, M, 5)
+        try:
+            outs, lo = [], 0
+            for hi in cuts:
+                outs.append(poly.push(x[:, lo:hi].contiguous(), final=hi == cuts[-1]))
+                lo = hi
+        finally:
+            poly.close()
+        got = torch.cat(outs, 1).cpu().numpy()
+        ref = sps.resample_poly(x.cpu().numpy(), 1, M, axis=-1, window=h)
+        assert got.shape == ref.shape, (M, got.shape, ref.shape)
+        assert np.max(np.abs(got - ref)) < 1e-12 * np.max(np.abs(ref)), M
