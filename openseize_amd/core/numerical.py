@@ -370,6 +370,14 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
                 if j % R == R - 1 and shift > off:
                     ring[:, span + off:span + shift].copy_(ring[:, off:shift])
 
+            def seal(y, j):
+                """NaN reach of the backward pass of chunk j (core/numerical.py:397-403: it
+                warms up over ALL of forward chunk j + 1): the step probed the last sample of
+                what it had of that chunk, cs - lcut samples -- the last lcut arrive with the
+                same step's own piece.  Its true last sample is there by now."""
+                col = ((j + 2) * cs - 1 + shift) % span
+                return y.masked_fill_(~torch.isfinite(ring[:, col:col + 1]), float("nan"))
+
             def store(s0, data):                       # host-placed samples (the overhang)
                 n, c0 = data.shape[1], (s0 + shift) % span
                 part = min(n, span - c0)
@@ -402,7 +410,7 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
                     dev.chain_step(fir, iir, x2d, chunk(j, cs), chunk(j + 1, cs - lcut), f_out=dst,
                                    y_out=y, defer=True)
                     if late is not None:
-                        yield from emit(late)              # the previous step's: ours now
+                        yield from emit(seal(late, j - 1))   # the previous step's: ours now
                     late = y
                 else:
                     dev.chain_forward(fir, iir, x2d, out=dst)
@@ -417,7 +425,7 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
                 raise RuntimeError(f"sosfiltfilt after oaconvolve: {produced} of {total} samples")
             dev.chain_wait(iir)
             if late is not None:
-                yield from emit(late)
+                yield from emit(seal(late, k - 3))
             # ---- the chunks the steady state has not reached: plain backward passes
             for j in range(max(k - 2, 0), nchunks):
                 n = min(cs, total - j * cs)

@@ -114,6 +114,10 @@ def test_nonfinite_reach_fused_chain(nm, zero_phase):
     x = dev.synth_normal(C, cs * nchunks, seed=5)
     x[9, 3 * cs + 8000] = float("nan")         # inside the first block pair of chunk 3
     x[30, 5 * cs + cs // 2:] = float("nan")
+    # 400 samples into input chunk 4: the FIR output turns NaN 112 samples before the END of
+    # output chunk 3 ('same' cuts 511) -- inside the part of that chunk a fused step has not
+    # got yet when it probes the chunk for the backward pass of chunk 2
+    x[50, 4 * cs + 400] = float("nan")
     src = producer(x, cs, -1)
     fir = producer(partial(nm.oaconvolve, src, taps, -1, "same"), cs, -1, shape=src.shape)
     import os
@@ -135,7 +139,8 @@ def test_nonfinite_reach_fused_chain(nm, zero_phase):
     assert np.array_equal(nan_chunk, some_nan)            # a chunk is NaN as a whole or not at all
     assert nan_chunk[9].tolist() == [False, False, True, True, True, True, True]
     assert nan_chunk[30].tolist() == [False, False, False, False, True, True, True]
-    clean = [c for c in range(C) if c not in (9, 30)]
+    assert nan_chunk[50].tolist() == [False, False, True, True, True, True, True]
+    clean = [c for c in range(C) if c not in (9, 30, 50)]
     assert not nan_chunk[clean].any()
     pick = [0, 31, 63]
     xh = x[pick].cpu().numpy()
