@@ -103,44 +103,49 @@ __device__ __forceinline__ double zp_dot(const double *kk, const double *pr, con
     return c;
 }
 
-// The fit and the burst amplitudes of a pair in one stage.  Four consecutive lanes share one
-// amplitude (block, causal / anticausal, mode): each takes a quarter of the 2 nh fit samples
-// for the real AND the imaginary row of M, two DPP steps add the quarters up in the quad's
+// The fit and the burst amplitudes of a pair in one stage.  Eight consecutive lanes share one
+// amplitude (block, causal / anticausal, mode): each takes an eighth of the 2 nh fit samples
+// for the real AND the imaginary row of M, three DPP steps add the parts up in the octet's
 // last lane, and that lane writes kappa[r] = amplitude * lambda^(256 r), r < R:
 //   kapA[amp][r][q]   amp = 0 mu_a, 1 mu_b, 2 nu_a, 3 nu_b              (this pair)
 //   kapN[k][r][q]     k = 0 mu_b, 1 nu_b: what the NEXT pair meets as mu_pb, nu_pb
+// (Four lanes per amplitude, two waves at work: the stage is a string of dependent LDS round
+// trips that the other waves wait out at the barrier; eight lanes halve the string.)
 template <int NM, int PER>
 __device__ __forceinline__ void zp_fit_kappa_n(int tt, int R, const double *fitbuf, const double *mtab,
                                                const double *lrow, double *kapA, double *kapN) {
-    constexpr int ns = 4 * PER;
-    // 16 NM lanes have an amplitude to work on: the waves behind them skip the stage (whole
-    // waves: the DPP steps below want their quads complete)
-    if ((tt & ~63) >= 16 * NM) return;
-    const int qd = tt >> 2, p4 = tt & 3;
+    constexpr int ns = 8 * PER;
+    // 32 NM lanes have an amplitude to work on: the waves behind them skip the stage (whole
+    // waves: the DPP steps below want their rows complete)
+    if ((tt & ~63) >= 32 * NM) return;
+    const int qd = tt >> 3, p8 = tt & 7;
     const bool valid = qd < 4 * NM;
     const int blk = valid ? qd / (2 * NM) : 0, kind = valid ? (qd / NM) % 2 : 0, q = valid ? qd % NM : 0;
-    const double *yb = fitbuf + ns * blk + PER * p4;
-    const double *mr = mtab + ns * ((2 * kind) * NM + q) + PER * p4;
-    const double *mi = mtab + ns * ((2 * kind + 1) * NM + q) + PER * p4;
-    // all the operands first, then four independent chains: the stage is a string of LDS
-    // round trips otherwise (it took 12 % of the kernel's time as a rolled loop)
-    // (in batches of four samples: more operands at once and the data registers spill)
+    const double *yb = fitbuf + ns * blk + PER * p8;
+    const double *mr = mtab + ns * ((2 * kind) * NM + q) + PER * p8;
+    const double *mi = mtab + ns * ((2 * kind + 1) * NM + q) + PER * p8;
+    // a batch of operands first, then independent chains (all of them at once and the data
+    // registers spill)
+    constexpr int B = PER % 3 == 0 ? 3 : 4;
     double sr0 = 0.0, sr1 = 0.0, si0 = 0.0, si1 = 0.0;
 #pragma unroll
-    for (int k0 = 0; k0 < PER; k0 += 4) {
-        double y[4], a[4], b[4];
+    for (int k0 = 0; k0 < PER; k0 += B) {
+        double y[B], a[B], b[B];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < B; ++k) {
             y[k] = yb[k0 + k];
             a[k] = mr[k0 + k];
             b[k] = mi[k0 + k];
         }
 #pragma unroll
-        for (int k = 0; k < 4; k += 2) {
-            sr0 = fma(a[k], y[k], sr0);
-            sr1 = fma(a[k + 1], y[k + 1], sr1);
-            si0 = fma(b[k], y[k], si0);
-            si1 = fma(b[k + 1], y[k + 1], si1);
+        for (int k = 0; k < B; ++k) {
+            if (k & 1) {
+                sr1 = fma(a[k], y[k], sr1);
+                si1 = fma(b[k], y[k], si1);
+            } else {
+                sr0 = fma(a[k], y[k], sr0);
+                si0 = fma(b[k], y[k], si0);
+            }
         }
     }
     double sr = valid ? sr0 + sr1 : 0.0, si = valid ? si0 + si1 : 0.0;
@@ -148,7 +153,9 @@ __device__ __forceinline__ void zp_fit_kappa_n(int tt, int R, const double *fitb
     si += dpp_row_shr0<1>(si);
     sr += dpp_row_shr0<2>(sr);
     si += dpp_row_shr0<2>(si);
-    if (p4 == 3 && valid) {
+    sr += dpp_row_shr0<4>(sr);
+    si += dpp_row_shr0<4>(si);
+    if (p8 == 7 && valid) {
         const int amp = kind * 2 + blk;
         double lr[kSpecRMax], li[kSpecRMax];
 #pragma unroll
@@ -175,9 +182,9 @@ __device__ __forceinline__ void zp_fit_kappa_n(int tt, int R, const double *fitb
 template <int NM>
 __device__ __forceinline__ void zp_fit_kappa(int tt, int nh, int R, const double *fitbuf, const double *mtab,
                                              const double *lrow, double *kapA, double *kapN) {
-    if (nh == 24) zp_fit_kappa_n<NM, 12>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
-    else if (nh == 32) zp_fit_kappa_n<NM, 16>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
-    else zp_fit_kappa_n<NM, 8>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+    if (nh == 24) zp_fit_kappa_n<NM, 6>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+    else if (nh == 32) zp_fit_kappa_n<NM, 8>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+    else zp_fit_kappa_n<NM, 4>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
 }
 
 // Three bursts of one row at once: every operand first, two chains per burst.
