@@ -13,6 +13,7 @@
 // poly_block_kernel (LDS window, register-blocked, all practical L/M) and
 // poly_kernel (one thread per output through L1/L2; only for M so large that
 // the window of a 64-thread tile does not fit in LDS).
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -302,6 +303,42 @@ int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M, 
             }
         }
         if (p->nt) {
+            // The stream pitch decides how the staging writes fall on the banks: a ds_write_b64
+            // is served in groups of 16 consecutive lanes, conflict free when their 16 double
+            // addresses e * se + pad(i) differ mod 16 (MI355X_MICROARCH.md, LDS).  Lanes walk
+            // (i, e) = (w div M, w mod M), so the best pitch depends on M: take, among the 16
+            // pitches from the needed one up, the one with the fewest extra LDS cycles over the
+            // first steps of a tile (it was "any odd pitch": 30 % of the LDS cycles were conflicts).
+            const int nth = p->nt * ((L == 1 && p->nt <= 128 && M >= 2) ? 2 : 1);
+            const int stepw = nth - nth % M, dqs = M <= nth ? stepw / M : 0;
+            auto extra_cycles = [&](int se) {
+                long cost = 0;
+                for (int u = 0; u < 8; ++u)
+                    for (int g0 = 0; g0 < nth; g0 += 16) {
+                        int cnt[16] = {0}, worst = 0;
+                        for (int tw = g0; tw < g0 + 16 && tw < nth; ++tw) {
+                            const int i = tw / M + u * dqs, e = tw % M;
+                            const int bank = (int)(((long)e * se + i + (i >> 2)) & 15);
+                            worst = std::max(worst, ++cnt[bank]);
+                        }
+                        cost += worst - 1;
+                    }
+                return cost;
+            };
+            if (M <= nth) {
+                int best = p->se;
+                long best_cost = extra_cycles(best);
+                for (int cand = p->se + 1; cand < p->se + 16 && best_cost > 0; ++cand) {
+                    const size_t bytes = ((size_t)M * cand + (L == 1 ? 0 : (size_t)p->nt * kPolyR * L)) * sizeof(double);
+                    if (bytes > (size_t)(p->nt == 64 ? 150 : 53) * 1024) break;
+                    const long c = extra_cycles(cand);
+                    if (c < best_cost) {
+                        best_cost = c;
+                        best = cand;
+                    }
+                }
+                p->se = best;
+            }
             std::vector<double> G((size_t)L * M * apad, 0.0);
             for (int r = 0; r < L; ++r) {
                 const int phi = (int)(((int64_t)r * M + p->half) % L);
