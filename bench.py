@@ -309,13 +309,15 @@ def run_chain(args, R, h, sos):
     from openseize_amd import _lib
     lib = _lib.load()
     C, ch0 = chain_channels(args, R)
-    ring = [dev.synth_normal(C, CHUNK, seed=0, ch0=ch0, n0=k * CHUNK) for k in range(3)]
+    # host-side setup first (handles, filter tables), the device-side one (the synthesised input
+    # ring, the zero-filled output ring) directly in front of the warm-up steps
     fir = dev.FirStream(h, C)
     iir = dev.SosStream(sos, C)
     zp = not (args.unfused or args.fused or args.two_kernel)
     lag = dev.chain_zp_lag(fir, iir) if zp else -1
     if zp and lag < 0:
         raise RuntimeError("the zero-phase chain kernel refused the benchmark's filters")
+    ring = [dev.synth_normal(C, CHUNK, seed=0, ch0=ch0, n0=k * CHUNK) for k in range(3)]
     # resident buffers with defined contents (zero-filled, so every page of the ring
     # has been written once before the first step reads or overwrites it)
     fir_out = torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda")
