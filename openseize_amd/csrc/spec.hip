@@ -754,7 +754,7 @@ __global__ void spec_head_kernel(const double *carry, int64_t ncap, int64_t ncar
     head[(int64_t)c * ldh + i] = i < ncarry ? carry[(int64_t)c * ncap + i] : x[(int64_t)c * ldx + (i - ncarry)];
 }
 
-// radix plan of the M = nfft / 2 point transform of specmix.h: 10s, 4s, a 2, 3s, 5s
+// radix plan of the M = nfft / 2 point transform of specmix.h: 10s, 4s, a 2, 3s, 5s, 7s
 static bool specmix_plan(int nfft, int *npass, int *radix) {
     if (nfft < 4 || (nfft & 1)) return false;
     int m = nfft / 2, n = 0;
@@ -770,6 +770,7 @@ static bool specmix_plan(int nfft, int *npass, int *radix) {
     take(2);
     take(3);
     take(5);
+    take(7);
     *npass = n;
     return m == 1 && n >= 1;
 }

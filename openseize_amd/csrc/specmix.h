@@ -6,7 +6,7 @@
 // segments of one channel; a segment of nfft real samples is packed into
 // M = nfft / 2 complex points z[j] = y[2j] + i y[2j+1] in LDS (16 B a point,
 // 80 KB at nfft = 10000), transformed IN PLACE by decimation-in-frequency passes
-// of radix 10, 4, 2, 3, 5 (in that order: the even radices run while the butterfly
+// of radix 10, 4, 2, 3, 5, 7 (in that order: the even radices run while the butterfly
 // stride is long, the last passes -- stride 1 ... 25 -- are the odd ones, whose
 // 48- and 80-byte lane strides spread over all banks), one barrier per pass, and
 // untangled into the nfft / 2 + 1 bins of the real transform on the way out:
@@ -107,6 +107,53 @@ __device__ __forceinline__ void dft<5>(C2 *v) {
     v[2] = sub_i(m2, n2);
     v[3] = add_i(m2, n2);
 }
+
+// Radix 7 (fs = 350, 700, 1400 ... Hz at the default resolution), any odd prime in fact: the
+// symmetric form, t_k = v[k] + v[R-k], d_k = v[k] - v[R-k],
+//   X[j], X[R-j] = (v[0] + sum_k cos(2 pi j k / R) t_k)  -/+  i sum_k sin(2 pi j k / R) d_k,
+// with the table index j k mod R folded at compile time (cos is even, sin odd about R / 2).
+// (Radix 11 and 13 passes were tried: 52 + 48 registers of operands spill under the kernel's
+// cap of 128; those lengths stay on the rocFFT route.)
+template <int R>
+struct OddTw;
+template <> struct OddTw<7> {
+    static constexpr double c[3] = {0.6234898018587335305250049, -0.2225209339563144042889026, -0.9009688679024191262361023};
+    static constexpr double s[3] = {0.7818314824680298087084445, 0.9749279121818236070181317, 0.4338837391175581204757683};
+};
+
+template <int R>
+__device__ __forceinline__ void dft_odd(C2 *v) {
+    constexpr int H = (R - 1) / 2;
+    C2 t[H], d[H];
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+        t[k - 1] = cadd(v[k], v[R - k]);
+        d[k - 1] = csub(v[k], v[R - k]);
+    }
+    const C2 v0 = v[0];
+    C2 sum = v0;
+#pragma unroll
+    for (int k = 0; k < H; ++k) sum = cadd(sum, t[k]);
+    v[0] = sum;
+#pragma unroll
+    for (int j = 1; j <= H; ++j) {
+        C2 m = v0, n = C2{0.0, 0.0};
+#pragma unroll
+        for (int k = 1; k <= H; ++k) {
+            const int q = (j * k) % R;                   // compile time
+            const double cq = OddTw<R>::c[(q <= H ? q : R - q) - 1];
+            const double sq = q <= H ? OddTw<R>::s[q - 1] : -OddTw<R>::s[R - q - 1];
+            m.re = fma(cq, t[k - 1].re, m.re);
+            m.im = fma(cq, t[k - 1].im, m.im);
+            n.re = fma(sq, d[k - 1].re, n.re);
+            n.im = fma(sq, d[k - 1].im, n.im);
+        }
+        v[j] = sub_i(m, n);
+        v[R - j] = add_i(m, n);
+    }
+}
+template <>
+__device__ __forceinline__ void dft<7>(C2 *v) { dft_odd<7>(v); }
 
 // 10 = 2 x 5 by the prime-factor mapping: no twiddles inside the butterfly.
 // Inputs n = (5 n1 + 2 n2) mod 10, outputs k = (5 k1 + 6 k2) mod 10.
@@ -281,7 +328,8 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
             else if (r == 4) pass<4, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
             else if (r == 5) pass<5, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
             else if (r == 2) pass<2, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
-            else pass<3, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
+            else if (r == 3) pass<3, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
+            else pass<7, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
             B = S;
         }
         __syncthreads();

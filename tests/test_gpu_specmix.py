@@ -1,10 +1,10 @@
 """GPU parity of the mixed-radix on-chip spectra path (csrc/specmix.h): even
-nfft whose half is a product of 2, 3 and 5 -- what nfft = int(fs / resolution)
-(reference spectra/estimators.py:144) is for fs = 250, 500, 1000, 2500, 5000,
+nfft whose half is a product of 2, 3, 5 and 7 -- what nfft = int(fs / resolution)
+(reference spectra/estimators.py:144) is for fs = 250, 350, 500, 700, 1000, 2500, 5000,
 10 000 Hz at the default 0.5 Hz resolution -- against the CPU oracle,
 whole-array SciPy and the rocFFT route of this library (OSZ_SPEC_MIX=0), for
 PSD mean / PSD segments / STFT segments, both detrends, short windows, any
-overlap, chunked pushes.  Lengths the plan cannot factor (odd, a factor 7,
+overlap, chunked pushes.  Lengths the plan cannot factor (odd, a factor 11,
 above 20 480) stay on rocFFT and are checked to do so by value.
 """
 
@@ -16,7 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-9
-SIZES = (96, 200, 500, 600, 1000, 1500, 2000, 5000, 10000, 20000)
+SIZES = (96, 200, 500, 600, 1000, 1500, 2000, 5000, 10000, 20000, 98, 700, 1400, 4900)
 
 
 def rel_err(a, b):
@@ -132,12 +132,12 @@ def test_short_window_padded_to_nfft():
 
 
 def test_lengths_the_plan_leaves_to_rocfft():
-    """Odd nfft, a factor 7, nfft / 2 above the LDS: the staging route answers,
-    and it matches SciPy."""
+    """Odd nfft, a factor 11, a large prime factor, nfft / 2 above the LDS: the staging
+    route answers, and it matches SciPy."""
     import scipy.signal as sps
     from openseize_amd.core import numerical as nm
     rng = np.random.default_rng(3)
-    for nfft in (1001, 1400, 30000):
+    for nfft in (1001, 2200, 694, 30000):
         x = rng.standard_normal((2, 4 * nfft + 50))
         freqs, pro = nm.welch(producer(x, 2 * nfft + 5, -1), float(nfft), nfft, "hann", 0.5, -1,
                               "constant", "density")
