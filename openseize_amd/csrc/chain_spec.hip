@@ -119,21 +119,23 @@ __global__ __launch_bounds__(256, 2) void chain_spec_kernel(SpecArgs g) {
     for (int i = t; i < 32 * NM * 2; i += 256) ptab[i] = g.P[i];
     for (int i = t; i < 2 * NM * kSpecFit; i += 256) mtab[i] = g.M[i];
     if (t < 2 * 2 * NM * 2) mu[t] = 0.0;
+    // `bad` is uniform (a scalar) and sticky: non-finite samples are everywhere behind the
+    // transform, every amplitude of the fit and with it every lane's burst values see them
     bool bad = false;
     int par = 0;
+    const unsigned lane8 = 8u * (unsigned)t;   // a lane's byte offset inside a row of 256 samples
     __syncthreads();
 
     for (int64_t p = ps; p < p1; ++p) {
         const int64_t o = p * (2 * S);
         double re[16], im[16];
         {
-            int64_t off = o + t;
-            asm volatile("" : "+v"(off));   // per pair: hoisted, 2 NR row addresses would spill
-            const double *pa = xr + off;
+            // rows of the pair: base and row offsets in scalar registers (buf_rsrc, common.h)
+            const __amdgpu_buffer_rsrc_t rx = buf_rsrc(xr + o);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                re[j] = j < NR ? pa[256 * j] : 0.0;
-                im[j] = j < NR ? pa[256 * (j + NR)] : 0.0;
+                re[j] = j < NR ? buf_load(rx, lane8, 2048u * j) : 0.0;
+                im[j] = j < NR ? buf_load(rx, lane8, 2048u * (j + NR)) : 0.0;
             }
         }
         P.transform(re, im);
@@ -218,14 +220,15 @@ __global__ __launch_bounds__(256, 2) void chain_spec_kernel(SpecArgs g) {
                 re[(D + r) & 15] += c1;
                 im[r] += c2;
                 im[(D + r) & 15] += c3;
-                if (r == 0) bad = bad || sos_not_finite(c0) || sos_not_finite(c2);
+                if (r == 0 && !bad) bad = __builtin_amdgcn_readfirstlane((int)(sos_not_finite(c0) || sos_not_finite(c2))) != 0;
             }
         }
         if (run == 0 && p == 0) {
             // the chunk opens: what the stream so far still owes these samples
             const double *ci = g.carry_in + (int64_t)c * kSpecLdc + tt;
             // (a poisoned stream: NaN all the way to where a carry has long died)
-            bad = bad || sos_not_finite(g.carry_in[(int64_t)c * kSpecLdc + 4095 + 256 * R]);
+            if (!bad)
+                bad = __builtin_amdgcn_readfirstlane((int)sos_not_finite(g.carry_in[(int64_t)c * kSpecLdc + 4095 + 256 * R])) != 0;
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 re[j] += ci[256 * j];
@@ -233,14 +236,20 @@ __global__ __launch_bounds__(256, 2) void chain_spec_kernel(SpecArgs g) {
             }
         }
         if (p >= p0) {
-            int64_t off = o + tt;
-            asm volatile("" : "+v"(off));
-            double *q = yr + off;
-            const double qn = spec_qnan();
+            const __amdgpu_buffer_rsrc_t ry = buf_rsrc(yr + o);
+            if (!bad) {
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                q[256 * j] = bad ? qn : re[j];
-                q[256 * (j + NR)] = bad ? qn : im[j];
+                for (int j = 0; j < NR; ++j) {
+                    buf_store(re[j], ry, lane8, 2048u * j);
+                    buf_store(im[j], ry, lane8, 2048u * (j + NR));
+                }
+            } else {
+                const double qn = spec_qnan();
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    buf_store(qn, ry, lane8, 2048u * j);
+                    buf_store(qn, ry, lane8, 2048u * (j + NR));
+                }
             }
         }
         par ^= 1;
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void chain_spec_kernel(SpecArgs g) {
             // non-finite amplitudes poison the rest of the stream
             bool nf = false;
             for (int i = 0; i < 2 * NM * 2; ++i) nf = nf || sos_not_finite(mu[par * (2 * NM * 2) + i]);
-            bad = bad || nf;
+            if (!bad) bad = __builtin_amdgcn_readfirstlane((int)nf) != 0;
         }
         __syncthreads();
         // lambda_q^t = lambda_q^(16 (t >> 4)) lambda_q^(t & 15), formed when needed: held
