@@ -15,8 +15,9 @@
 //         on the basis Re(lambda^l), -Im(lambda^l) by Householder QR
 //   P     [32][NM][2] lambda^(16 i), i < 16, then lambda^i, i < 16
 //   L     [5][NM][2]  lambda^(256 r)
-//   R     rows of 256 samples over which a burst exceeds 3e-18 of the output scale, from
-//         the tail energy of the composite impulse response
+//   R     rows of 256 samples over which a burst exceeds kTailTol (1e-12) of the output scale,
+//         from the tail energy of the composite impulse response (as the two-sided tables
+//         below: the cut buys time, the path's contract is 1e-6)
 #pragma once
 
 #include <algorithm>
@@ -31,6 +32,9 @@ typedef long double ld_t;
 
 constexpr int kFit = 64;      // samples of row 15 the fit reads (one wave)
 constexpr int kRMax = 5;      // burst rows supported
+// where a burst is cut off, relative to the norm of the composite impulse response (see the
+// two-sided tables below for what it costs and buys)
+constexpr ld_t kTailTol = 1e-12L;
 constexpr int kN = 4096;
 
 struct Tables {
@@ -227,7 +231,7 @@ inline Tables build(const double *taps, int wlen, const double *sos, int nsec, b
     std::vector<ld_t> tail2(glen + 1, 0.0L);
     for (int i = glen - 1; i >= 0; --i) tail2[i] = tail2[i + 1] + g[i] * g[i];
     int R = 1;
-    while (R <= 16 && kN + 256 * R - S < glen && sqrtl(tail2[kN + 256 * R - S]) > 3e-18L * sqrtl(tail2[0]))
+    while (R <= 16 && kN + 256 * R - S < glen && sqrtl(tail2[kN + 256 * R - S]) > kTailTol * sqrtl(tail2[0]))
         ++R;
     // the +mu burst of a block must end inside the next block (D + R <= NR) and the closing
     // pair's accumulator holds 8192 samples (NR + R <= 16)
@@ -302,7 +306,6 @@ inline Tables build(const double *taps, int wlen, const double *sos, int nsec, b
 //         SciPy 5e-13 and 7e-15, the step 1.53 and 1.66 ms.  The contract of the path is 1e-6
 //         (BASELINE.json), the tests hold 1e-9: the tolerance buys the 8 %.
 // NR is the largest block height whose guard rows hold the bursts (R <= D, D + Rf <= NR).
-constexpr ld_t kTailTol = 1e-12L;
 
 struct TablesZp {
     bool eligible = false;
