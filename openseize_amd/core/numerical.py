@@ -604,7 +604,11 @@ def sosfiltfilt(pro, sos, axis):
         # over HBM (256 x 2^20: 1.2-1.45 instead of 1.7-1.85 ms per chunk) -- where its tables
         # take the cascade; the stream's two ends on the separate kernels, as behind a FIR.
         cs, total = int(pro.chunksize), int(pro.shape[layout.axis])
-        if (-(-total // cs) >= 6 and cs >= 65536 and first.shape[layout.axis] == cs
+        from openseize_amd.core.producer import MaskedProducer
+        # (a MaskedProducer's shape may name more samples than it yields, core/producer.py:399-408:
+        # the flow below wants the chunk count up front)
+        if (not isinstance(pro, MaskedProducer)
+                and -(-total // cs) >= 6 and cs >= 65536 and first.shape[layout.axis] == cs
                 and (pipe is not None or first.is_cuda) and os.environ.get("OSZ_CHAIN_ZP", "1") != "0"
                 and stream.warm_len <= cs):
             ident = dev.FirStream(np.array([1.0, 0.0]), layout.nch)
