@@ -634,6 +634,312 @@ __global__ __launch_bounds__(N / 8, 4) void spec8_kernel(Spec8Args a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Any other transform length up to 4096 -- odd nfft, prime factors above 7: what
+// nfft = int(fs / resolution) of the reference (spectra/estimators.py:144) is for a sampling
+// rate like 173.61 Hz -- by Bluestein's chirp transform on the transforms of fft8.h:
+//     X[k] = w[k] sum_j (x[j] w[j]) conj(w)[k - j],   w[j] = exp(-i pi j^2 / n),
+// i.e. one circular convolution of length m = 2^L >= 2 n - 1 with a fixed sequence: a forward
+// transform of x w (zero padded), a multiplication with the transformed chirp (host table, in
+// the order the forward transform leaves its bins in, divided by m), an inverse transform,
+// and w[k] on the way out.  One segment per pair of transforms (the chirped input is complex:
+// no two real segments per transform here); detrend, window, scaling, |.|^2, one-sided
+// doubling and the segment sums as in spec8_kernel.  HBM sees each sample once and each
+// output once, where the rocFFT route stages rows at 5-10 times that.
+struct BlueArgs {
+    const double *x;        // one contiguous source: segment s starts at column s * stride
+    const double *window;   // nwin
+    void *out;              // SEGMENTS modes: (nseg, nch, nfreq) f64 / c128
+    double *partial;        // PSD_MEAN: (nch, nruns, nfreq) sums of this launch
+    const double *tab;      // W_8192^j, j < 1024
+    const double *chirp;    // [m][2]: w[j], j < n; zeros behind
+    const double *bperm;    // [8][m / 8][2]: FFT_m(conj w, wrapped) / m at the bin register r of thread t holds
+    int64_t ldx;
+    int64_t nseg;
+    int stride, nwin, nch, nruns, n, nfreq;
+    double scale;
+};
+
+template <int N, int S>
+struct Inv8 {
+    static __device__ __forceinline__ void run(int tid, double *re, double *im,
+                                               const fft8::Twid<N> &tw, fft8::C2 *lds) {
+        double wr = tw.wr[S], wi = tw.wi[S];
+        asm volatile("" : "+v"(tid), "+v"(wr), "+v"(wi));
+        fft8::inv_stage<N, S>(tid, re, im, wr, wi, lds);
+        if constexpr (S > 0) {
+            __syncthreads();
+            Inv8<N, S - 1>::run(tid, re, im, tw, lds);
+        }
+    }
+};
+
+template <int N, int MODE, bool LINEAR>
+__global__ __launch_bounds__(N / 8, 2) void spec_blue_kernel(BlueArgs a) {
+    using fft8::C2;
+    constexpr int NT = N / 8, NWV = (NT + 63) / 64;
+    extern __shared__ C2 lds8[];
+    __shared__ double red[NWV][2];
+    const int t = threadIdx.x;
+    const int run = blockIdx.x;
+    const int c = blockIdx.y;
+    const double *xr = a.x + (int64_t)c * a.ldx;
+    const int64_t s0 = ((int64_t)run * a.nseg) / a.nruns;
+    const int64_t s1 = ((int64_t)(run + 1) * a.nseg) / a.nruns;
+    const double mid = 0.5 * (a.nwin - 1);
+    const double s2 = a.scale * a.scale;
+    const int n = a.n, NF = a.nfreq;
+
+    fft8::Twid<N> tw;
+    fft8::twid_load<N>(t, a.tab, tw);
+    // the window, the chirp and the transformed chirp of a thread's eight points stay in
+    // registers -- except at m = 8192, where 1024 threads leave 128 registers each: there the
+    // two chirps come from L2 where they are used
+    constexpr bool RES = N <= 4096;
+    double win[8], cr[RES ? 8 : 1], ci[RES ? 8 : 1], br[RES ? 8 : 1], bi[RES ? 8 : 1];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = NT * r + t;
+        const double wv = a.window[i < a.nwin ? i : 0];   // clamped address, no branch
+        win[r] = i < a.nwin ? wv : 0.0;                   // zero padding up to nfft
+        if (RES) {
+            cr[RES ? r : 0] = a.chirp[2 * i];
+            ci[RES ? r : 0] = a.chirp[2 * i + 1];
+            br[RES ? r : 0] = a.bperm[2 * i];
+            bi[RES ? r : 0] = a.bperm[2 * i + 1];
+        }
+    }
+    double acc[3] = {0.0, 0.0, 0.0};                      // bins t, NT + t, 2 NT + t (nfreq <= m / 4 + 1)
+
+    for (int64_t s = s0; s < s1; ++s) {
+        const double *pa = xr + s * (int64_t)a.stride + t;
+        double re[8], im[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = NT * r + t;
+            const bool in = i < a.nwin;
+            const double xa = pa[in ? NT * r : -t];       // stays inside the segment
+            re[r] = in ? xa : 0.0;
+        }
+        // ---- trend: block sums over the nwin samples
+        double sum = 0.0, lin = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            sum += re[r];
+            if (LINEAR) lin += (NT * r + t - mid) * re[r];
+        }
+        sum = wave_sum63(sum);
+        if (LINEAR) lin = wave_sum63(lin);
+        if ((t & 63) == 63) {
+            red[t >> 6][0] = sum;
+            red[t >> 6][1] = lin;
+        }
+        __syncthreads();   // also: every LDS read of the previous segment is done
+        double tot = 0.0, tlin = 0.0;
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) {
+            tot += red[q][0];
+            if (LINEAR) tlin += red[q][1];
+        }
+        const double mean = tot / a.nwin;
+        double slope = 0.0;
+        if (LINEAR) {
+            const double nn = (double)a.nwin;
+            const double sxx = nn * (nn * nn - 1.0) / 12.0;
+            slope = sxx > 0.0 ? tlin / sxx : 0.0;
+        }
+        // detrended, windowed, chirped: a[j] = v[j] w[j]
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = NT * r + t;
+            const double v = (LINEAR ? re[r] - mean - slope * (i - mid) : re[r] - mean) * win[r];
+            re[r] = v * (RES ? cr[RES ? r : 0] : a.chirp[2 * i]);
+            im[r] = v * (RES ? ci[RES ? r : 0] : a.chirp[2 * i + 1]);
+        }
+        int tt = t;   // opaque copy: keeps the LDS slot numbers out of loop-invariant registers
+        asm volatile("" : "+v"(tt));
+        Fwd8<N, 0>::run(tt, re, im, tw, lds8);
+        // times the transformed chirp, bin by bin where the forward transform left them
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = NT * r + tt;
+            fft8::cmul(re[r], im[r], RES ? br[RES ? r : 0] : a.bperm[2 * i], RES ? bi[RES ? r : 0] : a.bperm[2 * i + 1]);
+        }
+        __syncthreads();   // the forward transform's last LDS reads are done
+        asm volatile("" : "+v"(tt));
+        Inv8<N, fft8::Plan<N>::NS - 1>::run(tt, re, im, tw, lds8);
+        // ---- X[k] = w[k] conv[k], k = NT r + t < nfreq (r < 3)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int k = NT * r + t;
+            if (k >= NF) continue;
+            double zr = re[r], zi = im[r];
+            fft8::cmul(zr, zi, RES ? cr[RES ? r : 0] : a.chirp[2 * k], RES ? ci[RES ? r : 0] : a.chirp[2 * k + 1]);
+            const bool dbl = k != 0 && !(2 * k == n);
+            if (MODE == OSZ_SPEC_DFT_SEGMENTS) {
+                double *o = (double *)a.out + (((s * a.nch + c) * (int64_t)NF + k) * 2);
+                o[0] = zr * a.scale;
+                o[1] = zi * a.scale;
+            } else {
+                const double pw = (zr * zr + zi * zi) * (dbl ? 2.0 * s2 : s2);
+                if (MODE == OSZ_SPEC_PSD_SEGMENTS) ((double *)a.out)[(s * a.nch + c) * (int64_t)NF + k] = pw;
+                else acc[r] += pw;
+            }
+        }
+    }
+    if (MODE == OSZ_SPEC_PSD_MEAN) {
+        double *o = a.partial + ((int64_t)c * a.nruns + run) * NF;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int k = NT * r + t;
+            if (k < NF) o[k] = acc[r];
+        }
+    }
+}
+
+
+// PSD_MEAN by the chirp transform, TWO real segments per pair of transforms: z = a + i b goes
+// through as one complex sequence, X = A + i B, and the sum over a pair needs no separation:
+//   |A[k]|^2 + |B[k]|^2 = (|X[k]|^2 + |X[n-k]|^2) / 2   (a, b real),
+// so a thread sums |X|^2 of the bins it holds (k = NT r + t < n: r < 4) over its run and the
+// bins meet their mirrors once, after the run (as in spec8_kernel).
+template <int N, bool LINEAR>
+__global__ __launch_bounds__(N / 8, 2) void spec_blue_mean_kernel(BlueArgs a) {
+    using fft8::C2;
+    constexpr int NT = N / 8, NWV = (NT + 63) / 64;
+    extern __shared__ C2 lds8[];
+    __shared__ double red[NWV][4];
+    const int t = threadIdx.x;
+    const int run = blockIdx.x;
+    const int c = blockIdx.y;
+    const double *xr = a.x + (int64_t)c * a.ldx;
+    const int64_t npairs = (a.nseg + 1) / 2;
+    const int64_t p0 = ((int64_t)run * npairs) / a.nruns;
+    const int64_t p1 = ((int64_t)(run + 1) * npairs) / a.nruns;
+    const double mid = 0.5 * (a.nwin - 1);
+    const double s2 = a.scale * a.scale;
+    const int n = a.n, NF = a.nfreq;
+
+    fft8::Twid<N> tw;
+    fft8::twid_load<N>(t, a.tab, tw);
+    constexpr bool RES = N <= 4096;       // (see spec_blue_kernel)
+    double win[8], cr[RES ? 8 : 1], ci[RES ? 8 : 1], br[RES ? 8 : 1], bi[RES ? 8 : 1];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = NT * r + t;
+        const double wv = a.window[i < a.nwin ? i : 0];
+        win[r] = i < a.nwin ? wv : 0.0;
+        if (RES) {
+            cr[RES ? r : 0] = a.chirp[2 * i];
+            ci[RES ? r : 0] = a.chirp[2 * i + 1];
+            br[RES ? r : 0] = a.bperm[2 * i];
+            bi[RES ? r : 0] = a.bperm[2 * i + 1];
+        }
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+
+    for (int64_t p = p0; p < p1; ++p) {
+        const int64_t sa = 2 * p, sb = 2 * p + 1;
+        const bool has_b = sb < a.nseg;
+        const double *pa = xr + sa * (int64_t)a.stride + t;
+        const int64_t db = has_b ? a.stride : 0;
+        double re[8], im[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = NT * r + t;
+            const bool in = i < a.nwin;
+            const int ii = in ? NT * r : -t;              // stays inside the segment
+            const double xa = pa[ii], xb = pa[db + ii];
+            re[r] = in ? xa : 0.0;
+            im[r] = (in && has_b) ? xb : 0.0;
+        }
+        double sum_a = 0.0, sum_b = 0.0, lin_a = 0.0, lin_b = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = NT * r + t;
+            sum_a += re[r];
+            sum_b += im[r];
+            if (LINEAR) {
+                lin_a += (i - mid) * re[r];
+                lin_b += (i - mid) * im[r];
+            }
+        }
+        sum_a = wave_sum63(sum_a);
+        sum_b = wave_sum63(sum_b);
+        if (LINEAR) {
+            lin_a = wave_sum63(lin_a);
+            lin_b = wave_sum63(lin_b);
+        }
+        if ((t & 63) == 63) {
+            red[t >> 6][0] = sum_a;
+            red[t >> 6][1] = sum_b;
+            red[t >> 6][2] = lin_a;
+            red[t >> 6][3] = lin_b;
+        }
+        __syncthreads();   // also: every LDS read of the previous pair is done
+        double tot[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) {
+            tot[0] += red[q][0];
+            tot[1] += red[q][1];
+            if (LINEAR) {
+                tot[2] += red[q][2];
+                tot[3] += red[q][3];
+            }
+        }
+        const double mean_a = tot[0] / a.nwin, mean_b = tot[1] / a.nwin;
+        double slope_a = 0.0, slope_b = 0.0;
+        if (LINEAR) {
+            const double nn = (double)a.nwin;
+            const double sxx = nn * (nn * nn - 1.0) / 12.0;
+            slope_a = sxx > 0.0 ? tot[2] / sxx : 0.0;
+            slope_b = sxx > 0.0 ? tot[3] / sxx : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = NT * r + t;
+            double va = (LINEAR ? re[r] - mean_a - slope_a * (i - mid) : re[r] - mean_a) * win[r];
+            double vb = has_b ? (LINEAR ? im[r] - mean_b - slope_b * (i - mid) : im[r] - mean_b) * win[r] : 0.0;
+            fft8::cmul(va, vb, RES ? cr[RES ? r : 0] : a.chirp[2 * i], RES ? ci[RES ? r : 0] : a.chirp[2 * i + 1]);
+            re[r] = va;
+            im[r] = vb;
+        }
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        Fwd8<N, 0>::run(tt, re, im, tw, lds8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = NT * r + tt;
+            fft8::cmul(re[r], im[r], RES ? br[RES ? r : 0] : a.bperm[2 * i], RES ? bi[RES ? r : 0] : a.bperm[2 * i + 1]);
+        }
+        __syncthreads();   // the forward transform's last LDS reads are done
+        asm volatile("" : "+v"(tt));
+        Inv8<N, fft8::Plan<N>::NS - 1>::run(tt, re, im, tw, lds8);
+        // |X[k]|^2 = |conv[k]|^2 (the chirp on the way out has modulus one)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = fma(re[r], re[r], fma(im[r], im[r], acc[r]));
+    }
+    // fold bin k with its mirror n - k; one-sided doubling and the scale here
+    double *D = reinterpret_cast<double *>(lds8);
+    __syncthreads();       // the last pair's LDS reads are done
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = NT * r + t;
+        if (k < n) D[k] = acc[r];
+    }
+    __syncthreads();
+    double *o = a.partial + ((int64_t)c * a.nruns + run) * NF;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int k = NT * r + t;
+        if (k < NF) {
+            const bool dbl = k != 0 && !(2 * k == n);
+            o[k] = 0.5 * (D[k] + D[k == 0 ? 0 : n - k]) * (dbl ? 2.0 * s2 : s2);
+        }
+    }
+}
+
 // dsum[c][k] += sum over runs of partial[c][run][k] for any nfreq
 __global__ void spec_partial_reduce_n_kernel(const double *partial, double *dsum, int nruns, int nf) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -694,6 +1000,10 @@ struct osz_spec_s {
     bool mixed;          // even nfft = 2 * (product of 2, 3, 5) <= 20480: on-chip path (specmix_kernel)
     int mix_npass, mix_radix[mix::kMaxPass];
     int mix_blkfast[mix::kMaxPass];   // lane map per pass (specmix_lane_maps)
+    bool blue;           // any other nfft <= 4096: Bluestein on the fft8 transforms (spec_blue_kernel)
+    int blue_m;          // its convolution length, a power of two >= 2 nfft - 1 (>= 512)
+    double *dchirp;      // [blue_m][2]: w[j] = exp(-i pi j^2 / nfft), zeros behind nfft
+    double *dbperm;      // [blue_m][2]: the transformed chirp in the forward transform's bin order, / blue_m
     double *dtwn;        // specmix: W_nfft^j, j < nfft
     int *dpos;           // specmix: slot of Z[k] after the in-place passes
     double *dhead;       // fft8 path: carry ++ head of the chunk, (nch, ncap + nwin)
@@ -944,10 +1254,154 @@ static int specmix_run(osz_spec_s *h, const double *src, int64_t ld, void *out, 
     return OSZ_OK;
 }
 
+
+// host tables of the chirp transform (long double; an iterative radix-2 transform for the
+// m-point spectrum of the wrapped conjugate chirp)
+template <int N>
+static void blue_perm(const std::vector<long double> &Br, const std::vector<long double> &Bi, std::vector<double> &out) {
+    constexpr int NT = N / 8, L = fft8::ilog2(N);
+    out.assign((size_t)2 * N, 0.0);
+    for (int r = 0; r < 8; ++r)
+        for (int t = 0; t < NT; ++t) {
+            const int k = fft8::revdigits<L>(fft8::idx_of<0>(t, r));
+            out[2 * ((size_t)NT * r + t)] = (double)(Br[k] / N);
+            out[2 * ((size_t)NT * r + t) + 1] = (double)(Bi[k] / N);
+        }
+}
+
+static int blue_tables(osz_spec_s *h) {
+    const int n = h->nfft, m = h->blue_m;
+    const long double PI = acosl(-1.0L);
+    std::vector<double> chirp((size_t)2 * m, 0.0);
+    std::vector<long double> br(m, 0.0L), bi(m, 0.0L);
+    for (int j = 0; j < n; ++j) {
+        const long long q = ((long long)j * j) % (2LL * n);          // j^2 mod 2 n: the angle stays small
+        const long double ang = PI * (long double)q / (long double)n;
+        const long double cw = cosl(ang), sw = sinl(ang);
+        chirp[2 * (size_t)j] = (double)cw;                            // w = exp(-i ang)
+        chirp[2 * (size_t)j + 1] = (double)(-sw);
+        br[j] = cw;                                                   // conj w at +j and, wrapped, at -j
+        bi[j] = sw;
+        if (j > 0) {
+            br[m - j] = cw;
+            bi[m - j] = sw;
+        }
+    }
+    // in-place decimation-in-time transform of (br, bi), forward sign
+    for (int i = 1, j = 0; i < m; ++i) {
+        int bit = m >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(br[i], br[j]);
+            std::swap(bi[i], bi[j]);
+        }
+    }
+    for (int len = 2; len <= m; len <<= 1) {
+        for (int k = 0; k < len / 2; ++k) {
+            const long double ang = -2.0L * PI * (long double)k / (long double)len;
+            const long double wr = cosl(ang), wi = sinl(ang);
+            for (int i = k; i < m; i += len) {
+                const int j = i + len / 2;
+                const long double ur = br[j] * wr - bi[j] * wi, ui = br[j] * wi + bi[j] * wr;
+                br[j] = br[i] - ur;
+                bi[j] = bi[i] - ui;
+                br[i] += ur;
+                bi[i] += ui;
+            }
+        }
+    }
+    std::vector<double> bperm;
+    switch (m) {
+        case 512: blue_perm<512>(br, bi, bperm); break;
+        case 1024: blue_perm<1024>(br, bi, bperm); break;
+        case 2048: blue_perm<2048>(br, bi, bperm); break;
+        case 4096: blue_perm<4096>(br, bi, bperm); break;
+        default: blue_perm<8192>(br, bi, bperm); break;
+    }
+    OSZ_HIP(hipMalloc(&h->dchirp, chirp.size() * sizeof(double)));
+    OSZ_HIP(hipMalloc(&h->dbperm, bperm.size() * sizeof(double)));
+    OSZ_HIP(hipMemcpy(h->dchirp, chirp.data(), chirp.size() * sizeof(double), hipMemcpyHostToDevice));
+    OSZ_HIP(hipMemcpy(h->dbperm, bperm.data(), bperm.size() * sizeof(double), hipMemcpyHostToDevice));
+    return OSZ_OK;
+}
+
+template <int N>
+static int blue_launch(osz_spec_s *h, const BlueArgs &a, hipStream_t st) {
+    using kern_t = void (*)(BlueArgs);
+    static const kern_t ks[3][2] = {{spec_blue_kernel<N, 0, false>, spec_blue_kernel<N, 0, true>},
+                                    {spec_blue_kernel<N, 1, false>, spec_blue_kernel<N, 1, true>},
+                                    {spec_blue_kernel<N, 2, false>, spec_blue_kernel<N, 2, true>}};
+    static const kern_t km[2] = {spec_blue_mean_kernel<N, false>, spec_blue_mean_kernel<N, true>};
+    const int lin = h->detrend == OSZ_DETREND_LINEAR ? 1 : 0;
+    const kern_t k = h->mode == OSZ_SPEC_PSD_MEAN ? km[lin] : ks[h->mode][lin];
+    const size_t lds = sizeof(fft8::C2) * N;
+    OSZ_DYN_LDS(k, lds);
+    KernelTimer kt("spec_fused", st);
+    hipLaunchKernelGGL(k, dim3((unsigned)a.nruns, h->nch), dim3(N / 8), lds, st, a);
+    return OSZ_OK;
+}
+
+// one launch of spec_blue_kernel over nseg segments of a contiguous source
+static int blue_run(osz_spec_s *h, const double *src, int64_t ld, void *out, int64_t nseg, hipStream_t st) {
+    // work items per run (segments; pairs of them in the mean mode): a few rounds of the chip,
+    // the set-up amortised
+    const int64_t nitem = h->mode == OSZ_SPEC_PSD_MEAN ? (nseg + 1) / 2 : nseg;
+    int64_t R = (nitem * h->nch) / 2048;
+    if (R > 64) R = 64;
+    if (R < 1) R = 1;
+    const int64_t nruns = (nitem + R - 1) / R;
+    BlueArgs a{};
+    a.x = src;
+    a.window = h->dwindow;
+    a.out = out;
+    a.tab = h->tab8;
+    a.chirp = h->dchirp;
+    a.bperm = h->dbperm;
+    a.ldx = ld;
+    a.nseg = nseg;
+    a.stride = h->stride;
+    a.nwin = h->nwin;
+    a.nch = h->nch;
+    a.nruns = (int)nruns;
+    a.n = h->nfft;
+    a.nfreq = h->nfreq;
+    a.scale = h->scale;
+    if (h->mode == OSZ_SPEC_PSD_MEAN) {
+        const int64_t need = (int64_t)h->nch * nruns * h->nfreq;
+        if (need > h->partial_cap) {
+            OSZ_HIP(hipStreamSynchronize(st));
+            (void)hipFree(h->dpartial);
+            h->dpartial = nullptr;
+            if (hipMalloc(&h->dpartial, sizeof(double) * need) != hipSuccess)
+                return fail(OSZ_ERR_NOMEM, "osz_spec_push: partial sums (%lld doubles)", (long long)need);
+            h->partial_cap = need;
+        }
+        a.partial = h->dpartial;
+    }
+    int rc;
+    switch (h->blue_m) {
+        case 512: rc = blue_launch<512>(h, a, st); break;
+        case 1024: rc = blue_launch<1024>(h, a, st); break;
+        case 2048: rc = blue_launch<2048>(h, a, st); break;
+        case 4096: rc = blue_launch<4096>(h, a, st); break;
+        default: rc = blue_launch<8192>(h, a, st); break;
+    }
+    if (rc) return rc;
+    OSZ_HIP(hipGetLastError());
+    if (h->mode == OSZ_SPEC_PSD_MEAN) {
+        hipLaunchKernelGGL(spec_partial_reduce_n_kernel, dim3((h->nfreq + 255) / 256, h->nch), dim3(256),
+                           0, st, h->dpartial, h->dsum, (int)nruns, h->nfreq);
+        OSZ_HIP(hipGetLastError());
+    }
+    return OSZ_OK;
+}
+
 // one launch of spec8_kernel over nseg segments of a contiguous source
 static int spec8_run(osz_spec_s *h, const double *src, int64_t ld, void *out, int64_t nseg,
                      hipStream_t st) {
     if (h->mixed) return specmix_run(h, src, ld, out, nseg, st);
+    if (h->blue) return blue_run(h, src, ld, out, nseg, st);
     const int64_t npairs = (nseg + 1) / 2;
     // runs: enough workgroups for a few rounds of the chip, long enough that the
     // per-run set-up (twiddles, window, partial sums) stays small
@@ -1097,6 +1551,18 @@ int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride, const double 
             int rc = specmix_tables(p);
             if (rc) { (void)hipFree(p->dtwn); (void)hipFree(p->dpos); delete p->plans; delete p; return rc; }
         }
+        // every other length up to 4096: the chirp transform (OSZ_SPEC_MIX=0 keeps it off too)
+        p->dchirp = p->dbperm = nullptr;
+        p->blue = !p->fused && !p->fused8 && !p->mixed && !(em && atoi(em) == 0) && nfft >= 2 && nfft <= 4096;
+        p->blue_m = 0;
+        if (p->blue) {
+            int m = 512;
+            while (m < 2 * nfft - 1) m <<= 1;
+            p->blue_m = m;
+            int rc = get_fft8_table(&p->tab8);
+            if (!rc) rc = blue_tables(p);
+            if (rc) { (void)hipFree(p->dchirp); (void)hipFree(p->dbperm); delete p->plans; delete p; return rc; }
+        }
     }
     const size_t cb = sizeof(double) * (size_t)nch * p->ncap;
     const size_t ab = sizeof(double) * (size_t)nch * p->nfreq;
@@ -1127,6 +1593,8 @@ int osz_spec_destroy(osz_spec_t h) {
     (void)hipFree(h->dhead);
     (void)hipFree(h->dtwn);
     (void)hipFree(h->dpos);
+    (void)hipFree(h->dchirp);
+    (void)hipFree(h->dbperm);
     delete h;
     return OSZ_OK;
 }
@@ -1155,7 +1623,7 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
     const int64_t total = h->ncarry + n;
     const int64_t nseg = osz_spec_seg_count(h, n);
     OSZ_REQUIRE(nseg == 0 || h->mode == OSZ_SPEC_PSD_MEAN || out, "osz_spec_push: null output");
-    if (nseg > 0 && (h->fused8 || h->mixed)) {
+    if (nseg > 0 && (h->fused8 || h->mixed || h->blue)) {
         int rc = spec8_push(h, x, ldx, n, out, nseg, st);
         if (rc) return rc;
         h->count += nseg;

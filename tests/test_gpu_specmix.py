@@ -4,8 +4,9 @@ nfft whose half is a product of 2, 3, 5 and 7 -- what nfft = int(fs / resolution
 10 000 Hz at the default 0.5 Hz resolution -- against the CPU oracle,
 whole-array SciPy and the rocFFT route of this library (OSZ_SPEC_MIX=0), for
 PSD mean / PSD segments / STFT segments, both detrends, short windows, any
-overlap, chunked pushes.  Lengths the plan cannot factor (odd, a factor 11,
-above 20 480) stay on rocFFT and are checked to do so by value.
+overlap, chunked pushes.  Lengths the plan cannot factor take the chirp transform up to 4096
+(BLUE_SIZES); above that (odd, a prime factor above 7) and above 20 480 they stay on rocFFT and
+are checked by value.
 """
 
 import os
@@ -17,6 +18,9 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-9
 SIZES = (96, 200, 500, 600, 1000, 1500, 2000, 5000, 10000, 20000, 98, 700, 1400, 4900)
+# lengths the mixed-radix plan cannot factor, up to 4096: Bluestein's chirp transform on the fft8
+# transforms (spec_blue_kernel) -- odd, prime, a factor 11, one below a power of two, tiny
+BLUE_SIZES = (347, 1001, 694, 2200, 3001, 4095, 2049, 129, 63, 22)
 
 
 def rel_err(a, b):
@@ -52,7 +56,7 @@ class rocfft_route:
             os.environ["OSZ_SPEC_MIX"] = self.old
 
 
-@pytest.mark.parametrize("nfft", SIZES)
+@pytest.mark.parametrize("nfft", SIZES + BLUE_SIZES)
 def test_psd_all_sizes_vs_oracle(nfft):
     """psd() with fs = nfft, resolution 1: host-fed in ragged chunks (the carry
     of every push feeds the head segments) and device-resident; the rocFFT
@@ -79,7 +83,7 @@ def test_psd_all_sizes_vs_oracle(nfft):
     from openseize_amd import _device as dev, _lib
     w = sps.get_window("hann", nfft)
     scale = float(np.sqrt(1 / (float(nfft) * np.sum(w ** 2))))
-    spec = dev.SpecStream(nfft, nfft, nfft // 2, w, scale, "constant", _lib.SPEC_PSD_MEAN, 5)
+    spec = dev.SpecStream(nfft, nfft, nfft - int(0.5 * nfft), w, scale, "constant", _lib.SPEC_PSD_MEAN, 5)   # stride = nfft - noverlap
     xd = torch.from_numpy(x).cuda()
     cuts = [0, nfft // 3, nfft - 1, nfft + 7, 3 * nfft + 11, 3 * nfft + 12, 7 * nfft, x.shape[1]]
     for a, b in zip(cuts[:-1], cuts[1:]):
@@ -90,7 +94,7 @@ def test_psd_all_sizes_vs_oracle(nfft):
     assert cnt == rc and rel_err(p, rp) < RTOL
 
 
-@pytest.mark.parametrize("nfft", SIZES)
+@pytest.mark.parametrize("nfft", SIZES + BLUE_SIZES)
 def test_stft_and_welch_segments_all_sizes(nfft):
     """STFT (complex segments) and the per-segment Welch producer."""
     import scipy.signal as sps
@@ -132,12 +136,12 @@ def test_short_window_padded_to_nfft():
 
 
 def test_lengths_the_plan_leaves_to_rocfft():
-    """Odd nfft, a factor 11, a large prime factor, nfft / 2 above the LDS: the staging
-    route answers, and it matches SciPy."""
+    """Above 4096 and not a product of 2, 3, 5, 7 (a prime, an odd length, twice a prime),
+    nfft / 2 above the LDS: the staging route answers, and it matches SciPy."""
     import scipy.signal as sps
     from openseize_amd.core import numerical as nm
     rng = np.random.default_rng(3)
-    for nfft in (1001, 2200, 694, 30000):
+    for nfft in (4099, 5001, 8198, 30000):
         x = rng.standard_normal((2, 4 * nfft + 50))
         freqs, pro = nm.welch(producer(x, 2 * nfft + 5, -1), float(nfft), nfft, "hann", 0.5, -1,
                               "constant", "density")
@@ -169,3 +173,40 @@ def test_fullsize_256ch_default_resolution_5khz():
     pick = [0, 131, 255]
     rc, _, rp = orc.psd(x[pick].cpu().numpy(), fs, resolution=0.5)
     assert rc == cnt and rel_err(p[pick], rp) < RTOL
+
+
+def test_which_route_a_length_takes():
+    """The on-chip kernels run where the plan says so (kernel timers of the library: every
+    on-chip spectra kernel reports as `spec_fused`, the staging route as `spec_rocfft`):
+    a product of 2, 3, 5, 7 and a Bluestein length stay on chip, a prime above 4096 and
+    any length under OSZ_SPEC_MIX=0 go through rocFFT."""
+    import ctypes
+    import torch
+    from openseize_amd import _lib
+    from openseize_amd.spectra.estimators import psd
+    lib = _lib.load()
+
+    def launches(nfft):
+        x = torch.from_numpy(np.random.default_rng(1).standard_normal((3, 6 * nfft + 5))).cuda()
+        _lib.check(lib.osz_profile_reset())
+        _lib.check(lib.osz_profile_enable(1))
+        try:
+            psd(x, fs=nfft, axis=-1, resolution=1.0)
+            torch.cuda.synchronize()
+        finally:
+            _lib.check(lib.osz_profile_enable(0))
+        out = {}
+        for name in ("spec_fused", "spec_rocfft"):
+            n, ms = ctypes.c_int64(), ctypes.c_double()
+            _lib.check(lib.osz_profile_query(name.encode(), ctypes.byref(n), ctypes.byref(ms)))
+            out[name] = n.value
+        return out
+
+    for nfft in (1400, 347, 3001, 4095):
+        got = launches(nfft)
+        assert got["spec_fused"] > 0 and got["spec_rocfft"] == 0, (nfft, got)
+    got = launches(4099)
+    assert got["spec_fused"] == 0 and got["spec_rocfft"] > 0, got
+    with rocfft_route():
+        got = launches(347)
+    assert got["spec_fused"] == 0 and got["spec_rocfft"] > 0, got
