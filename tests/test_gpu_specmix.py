@@ -121,7 +121,7 @@ def test_short_window_padded_to_nfft():
     import scipy.signal as sps
     from openseize_amd.core import numerical as nm
     rng = np.random.default_rng(11)
-    for n, nfft in ((700, 1000), (300, 500), (5000, 10000), (2049, 6000), (1, 96)):
+    for n, nfft in ((700, 1000), (300, 500), (5000, 10000), (2049, 6000), (1, 96), (300, 347), (2500, 3001), (7, 1001)):
         x = rng.standard_normal((4, n)) + 1.0
         for detrend in ("constant", "linear"):
             for scaling in ("density", "spectrum"):
