@@ -103,7 +103,7 @@ def main():
                 e, what = rel(y, sps.resample_poly(x, L, M, axis=axis, window=h)), f"resample {L}/{M} n={n} shape={x.shape} axis={axis} cs={cs}"
             elif kind == 5:    # stft against the oracle's restatement
                 from openseize_amd.spectra.estimators import stft
-                fs = float(rng.choice([250, 500, 1000]))
+                fs = float(rng.choice([250, 500, 1000, 173.61, 700, 1111]))
                 res = float(rng.choice([0.5, 1.0, 2.0]))
                 nfft = int(fs / res)
                 n = interesting_length(rng, 3 * nfft, 40000)
@@ -189,7 +189,7 @@ def main():
                     del os.environ["OSZ_CHAIN_API"]
                 e, what = rel(got_, ref_) * 100, f"api chain taps={taps} C={C} cs={cs} total={total}"
             elif kind == 4:    # psd
-                fs = float(rng.choice([250, 500, 1000, 4096]))
+                fs = float(rng.choice([250, 500, 1000, 4096, 173.61, 700, 1111, 3001]))
                 res = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
                 nfft = int(fs / res)
                 n = interesting_length(rng, 3 * nfft, 120000)
