@@ -643,9 +643,8 @@ __global__ __launch_bounds__(N / 8, 4) void spec8_kernel(Spec8Args a) {
 // i.e. one circular convolution of length m = 2^L >= 2 n - 1 with a fixed sequence: a forward
 // transform of x w (zero padded), a multiplication with the transformed chirp (host table, in
 // the order the forward transform leaves its bins in, divided by m), an inverse transform,
-// and w[k] on the way out.  One segment per pair of transforms (the chirped input is complex:
-// no two real segments per transform here); detrend, window, scaling, |.|^2, one-sided
-// doubling and the segment sums as in spec8_kernel.  HBM sees each sample once and each
+// and w[k] on the way out.  Detrend, window, scaling, |.|^2, one-sided doubling and the segment
+// sums as in spec8_kernel.  HBM sees each sample once and each
 // output once, where the rocFFT route stages rows at 5-10 times that.
 struct BlueArgs {
     const double *x;        // one contiguous source: segment s starts at column s * stride
@@ -675,137 +674,14 @@ struct Inv8 {
     }
 };
 
-template <int N, int MODE, bool LINEAR>
-__global__ __launch_bounds__(N / 8, 2) void spec_blue_kernel(BlueArgs a) {
-    using fft8::C2;
-    constexpr int NT = N / 8, NWV = (NT + 63) / 64;
-    extern __shared__ C2 lds8[];
-    __shared__ double red[NWV][2];
-    const int t = threadIdx.x;
-    const int run = blockIdx.x;
-    const int c = blockIdx.y;
-    const double *xr = a.x + (int64_t)c * a.ldx;
-    const int64_t s0 = ((int64_t)run * a.nseg) / a.nruns;
-    const int64_t s1 = ((int64_t)(run + 1) * a.nseg) / a.nruns;
-    const double mid = 0.5 * (a.nwin - 1);
-    const double s2 = a.scale * a.scale;
-    const int n = a.n, NF = a.nfreq;
-
-    fft8::Twid<N> tw;
-    fft8::twid_load<N>(t, a.tab, tw);
-    // the window, the chirp and the transformed chirp of a thread's eight points stay in
-    // registers -- except at m = 8192, where 1024 threads leave 128 registers each: there the
-    // two chirps come from L2 where they are used
-    constexpr bool RES = N <= 4096;
-    double win[8], cr[RES ? 8 : 1], ci[RES ? 8 : 1], br[RES ? 8 : 1], bi[RES ? 8 : 1];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int i = NT * r + t;
-        const double wv = a.window[i < a.nwin ? i : 0];   // clamped address, no branch
-        win[r] = i < a.nwin ? wv : 0.0;                   // zero padding up to nfft
-        if (RES) {
-            cr[RES ? r : 0] = a.chirp[2 * i];
-            ci[RES ? r : 0] = a.chirp[2 * i + 1];
-            br[RES ? r : 0] = a.bperm[2 * i];
-            bi[RES ? r : 0] = a.bperm[2 * i + 1];
-        }
-    }
-    double acc[3] = {0.0, 0.0, 0.0};                      // bins t, NT + t, 2 NT + t (nfreq <= m / 4 + 1)
-
-    for (int64_t s = s0; s < s1; ++s) {
-        const double *pa = xr + s * (int64_t)a.stride + t;
-        double re[8], im[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = NT * r + t;
-            const bool in = i < a.nwin;
-            const double xa = pa[in ? NT * r : -t];       // stays inside the segment
-            re[r] = in ? xa : 0.0;
-        }
-        // ---- trend: block sums over the nwin samples
-        double sum = 0.0, lin = 0.0;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            sum += re[r];
-            if (LINEAR) lin += (NT * r + t - mid) * re[r];
-        }
-        sum = wave_sum63(sum);
-        if (LINEAR) lin = wave_sum63(lin);
-        if ((t & 63) == 63) {
-            red[t >> 6][0] = sum;
-            red[t >> 6][1] = lin;
-        }
-        __syncthreads();   // also: every LDS read of the previous segment is done
-        double tot = 0.0, tlin = 0.0;
-#pragma unroll
-        for (int q = 0; q < NWV; ++q) {
-            tot += red[q][0];
-            if (LINEAR) tlin += red[q][1];
-        }
-        const double mean = tot / a.nwin;
-        double slope = 0.0;
-        if (LINEAR) {
-            const double nn = (double)a.nwin;
-            const double sxx = nn * (nn * nn - 1.0) / 12.0;
-            slope = sxx > 0.0 ? tlin / sxx : 0.0;
-        }
-        // detrended, windowed, chirped: a[j] = v[j] w[j]
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = NT * r + t;
-            const double v = (LINEAR ? re[r] - mean - slope * (i - mid) : re[r] - mean) * win[r];
-            re[r] = v * (RES ? cr[RES ? r : 0] : a.chirp[2 * i]);
-            im[r] = v * (RES ? ci[RES ? r : 0] : a.chirp[2 * i + 1]);
-        }
-        int tt = t;   // opaque copy: keeps the LDS slot numbers out of loop-invariant registers
-        asm volatile("" : "+v"(tt));
-        Fwd8<N, 0>::run(tt, re, im, tw, lds8);
-        // times the transformed chirp, bin by bin where the forward transform left them
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = NT * r + tt;
-            fft8::cmul(re[r], im[r], RES ? br[RES ? r : 0] : a.bperm[2 * i], RES ? bi[RES ? r : 0] : a.bperm[2 * i + 1]);
-        }
-        __syncthreads();   // the forward transform's last LDS reads are done
-        asm volatile("" : "+v"(tt));
-        Inv8<N, fft8::Plan<N>::NS - 1>::run(tt, re, im, tw, lds8);
-        // ---- X[k] = w[k] conv[k], k = NT r + t < nfreq (r < 3)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int k = NT * r + t;
-            if (k >= NF) continue;
-            double zr = re[r], zi = im[r];
-            fft8::cmul(zr, zi, RES ? cr[RES ? r : 0] : a.chirp[2 * k], RES ? ci[RES ? r : 0] : a.chirp[2 * k + 1]);
-            const bool dbl = k != 0 && !(2 * k == n);
-            if (MODE == OSZ_SPEC_DFT_SEGMENTS) {
-                double *o = (double *)a.out + (((s * a.nch + c) * (int64_t)NF + k) * 2);
-                o[0] = zr * a.scale;
-                o[1] = zi * a.scale;
-            } else {
-                const double pw = (zr * zr + zi * zi) * (dbl ? 2.0 * s2 : s2);
-                if (MODE == OSZ_SPEC_PSD_SEGMENTS) ((double *)a.out)[(s * a.nch + c) * (int64_t)NF + k] = pw;
-                else acc[r] += pw;
-            }
-        }
-    }
-    if (MODE == OSZ_SPEC_PSD_MEAN) {
-        double *o = a.partial + ((int64_t)c * a.nruns + run) * NF;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int k = NT * r + t;
-            if (k < NF) o[k] = acc[r];
-        }
-    }
-}
-
-
-// PSD_MEAN by the chirp transform, TWO real segments per pair of transforms: z = a + i b goes
-// through as one complex sequence, X = A + i B, and the sum over a pair needs no separation:
+// TWO real segments per pair of transforms: z = a + i b goes through as one complex sequence,
+// X = A + i B.  The mean mode needs no separation,
 //   |A[k]|^2 + |B[k]|^2 = (|X[k]|^2 + |X[n-k]|^2) / 2   (a, b real),
 // so a thread sums |X|^2 of the bins it holds (k = NT r + t < n: r < 4) over its run and the
-// bins meet their mirrors once, after the run (as in spec8_kernel).
-template <int N, bool LINEAR>
-__global__ __launch_bounds__(N / 8, 2) void spec_blue_mean_kernel(BlueArgs a) {
+// bins meet their mirrors once, after the run (as in spec8_kernel); the segment modes park
+// X[k], k < n, in LDS and read k and n - k: A = (X[k] + conj X[n-k]) / 2, B = (X[k] - conj X[n-k]) / 2i.
+template <int N, int MODE, bool LINEAR>
+__global__ __launch_bounds__(N / 8, 2) void spec_blue_kernel(BlueArgs a) {
     using fft8::C2;
     constexpr int NT = N / 8, NWV = (NT + 63) / 64;
     extern __shared__ C2 lds8[];
@@ -916,10 +792,51 @@ __global__ __launch_bounds__(N / 8, 2) void spec_blue_mean_kernel(BlueArgs a) {
         __syncthreads();   // the forward transform's last LDS reads are done
         asm volatile("" : "+v"(tt));
         Inv8<N, fft8::Plan<N>::NS - 1>::run(tt, re, im, tw, lds8);
-        // |X[k]|^2 = |conv[k]|^2 (the chirp on the way out has modulus one)
+        if (MODE == OSZ_SPEC_PSD_MEAN) {
+            // |X[k]|^2 = |conv[k]|^2 (the chirp on the way out has modulus one)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = fma(re[r], re[r], fma(im[r], im[r], acc[r]));
+            for (int r = 0; r < 4; ++r) acc[r] = fma(re[r], re[r], fma(im[r], im[r], acc[r]));
+            continue;
+        }
+        // ---- segment modes: X[k] = w[k] conv[k], k < n, side by side in LDS
+        __syncthreads();   // the inverse transform's last LDS reads are done
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = NT * r + tt;
+            if (k < n) {
+                double zr = re[r], zi = im[r];
+                fft8::cmul(zr, zi, RES ? cr[RES ? r : 0] : a.chirp[2 * k], RES ? ci[RES ? r : 0] : a.chirp[2 * k + 1]);
+                lds8[k] = C2{zr, zi};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int k = NT * r + tt;
+            if (k >= NF) continue;
+            const C2 z = lds8[k], q = lds8[k == 0 ? 0 : n - k];
+            const double ar = 0.5 * (z.re + q.re), ai = 0.5 * (z.im - q.im);
+            const double br_ = 0.5 * (z.im + q.im), bi_ = -0.5 * (z.re - q.re);
+            const bool dbl = k != 0 && !(2 * k == n);
+            if (MODE == OSZ_SPEC_DFT_SEGMENTS) {
+                double *o = (double *)a.out;
+                const int64_t ia = ((sa * a.nch + c) * (int64_t)NF + k) * 2;
+                o[ia] = ar * a.scale;
+                o[ia + 1] = ai * a.scale;
+                if (has_b) {
+                    const int64_t ib = ((sb * a.nch + c) * (int64_t)NF + k) * 2;
+                    o[ib] = br_ * a.scale;
+                    o[ib + 1] = bi_ * a.scale;
+                }
+            } else {
+                const double f = dbl ? 2.0 * s2 : s2;
+                double *o = (double *)a.out;
+                o[(sa * a.nch + c) * (int64_t)NF + k] = (ar * ar + ai * ai) * f;
+                if (has_b) o[(sb * a.nch + c) * (int64_t)NF + k] = (br_ * br_ + bi_ * bi_) * f;
+            }
+        }
     }
+    if (MODE != OSZ_SPEC_PSD_MEAN) return;
     // fold bin k with its mirror n - k; one-sided doubling and the scale here
     double *D = reinterpret_cast<double *>(lds8);
     __syncthreads();       // the last pair's LDS reads are done
@@ -1332,9 +1249,7 @@ static int blue_launch(osz_spec_s *h, const BlueArgs &a, hipStream_t st) {
     static const kern_t ks[3][2] = {{spec_blue_kernel<N, 0, false>, spec_blue_kernel<N, 0, true>},
                                     {spec_blue_kernel<N, 1, false>, spec_blue_kernel<N, 1, true>},
                                     {spec_blue_kernel<N, 2, false>, spec_blue_kernel<N, 2, true>}};
-    static const kern_t km[2] = {spec_blue_mean_kernel<N, false>, spec_blue_mean_kernel<N, true>};
-    const int lin = h->detrend == OSZ_DETREND_LINEAR ? 1 : 0;
-    const kern_t k = h->mode == OSZ_SPEC_PSD_MEAN ? km[lin] : ks[h->mode][lin];
+    const kern_t k = ks[h->mode][h->detrend == OSZ_DETREND_LINEAR ? 1 : 0];
     const size_t lds = sizeof(fft8::C2) * N;
     OSZ_DYN_LDS(k, lds);
     KernelTimer kt("spec_fused", st);
@@ -1344,9 +1259,8 @@ static int blue_launch(osz_spec_s *h, const BlueArgs &a, hipStream_t st) {
 
 // one launch of spec_blue_kernel over nseg segments of a contiguous source
 static int blue_run(osz_spec_s *h, const double *src, int64_t ld, void *out, int64_t nseg, hipStream_t st) {
-    // work items per run (segments; pairs of them in the mean mode): a few rounds of the chip,
-    // the set-up amortised
-    const int64_t nitem = h->mode == OSZ_SPEC_PSD_MEAN ? (nseg + 1) / 2 : nseg;
+    // pairs of segments per run: a few rounds of the chip, the set-up amortised
+    const int64_t nitem = (nseg + 1) / 2;
     int64_t R = (nitem * h->nch) / 2048;
     if (R > 64) R = 64;
     if (R < 1) R = 1;
