@@ -284,7 +284,36 @@ __device__ unsigned long long *g_zp_marks = nullptr;   // [nch][nruns][8]
 #define OSZ_ZMARK(k) do { } while (0)
 #endif
 
-template <int NR, int NM>
+// One pair's 2 NR rows of 256 samples, requested by LDS-DMA into the cube (DMA kernels).  A wave
+// owns, in every 4 KB plane of the cube, the 1 KB piece [1024 w, 1024 w + 1024) -- the slots it
+// reads last in a transform (inverse pass 1, view A) and writes first in the next one (pass 1) --
+// so between the two nobody else touches it: piece m takes the wave's 64 samples of rows 2 m and
+// 2 m + 1 (one 16-byte request per lane: lanes 0-31 row 2 m, lanes 32-63 row 2 m + 1), and the
+// wave reads its own requests back behind its own vmcnt wait -- no barrier, no registers held
+// while the samples are on their way.
+template <int NR>
+__device__ __forceinline__ void zp_request_pair(const double *src, int t, const void *cube) {
+    int tq = t;
+    asm volatile("" : "+v"(tq));     // per pair, not hoisted
+    const __amdgpu_buffer_rsrc_t rx = buf_rsrc(src);
+    const unsigned voff = 2048u * (((unsigned)tq >> 5) & 1u) + 512u * ((unsigned)tq >> 6) + 16u * ((unsigned)tq & 31u);
+    const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(cube) +
+                                                         1024u * ((unsigned)tq >> 6));
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(ldsb + 4096u * m), "v"(voff), "s"(rx), "s"(4096u * m)
+                     : "memory");
+    }
+}
+
+template <int NR, int NM, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     OSZ_ZMARK(0);
 #ifdef OSZ_ZP_MARKS
@@ -313,15 +342,18 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     double *y0r = g.y0 ? g.y0 + (int64_t)c * g.ldy0 : nullptr;
     double *yr = a.y + (int64_t)c * a.ldy - n0;
     double *ho = g.held_out + (int64_t)c * L;
-    const int64_t p0 = zp_run_start(run, g.W, g.nruns, g.wclose);
-    const int64_t p1 = zp_run_start(run + 1, g.W, g.nruns, g.wclose);
-    const int64_t first = run == 0 ? 0 : p0 - 1;
-    const int64_t lastf = p1 - 1;
+    // (the partition's 64-bit divisions run on the vector unit: their results, uniform, go back to
+    // scalar registers -- a chunk has far fewer than 2^31 pairs)
+    const int p0 = __builtin_amdgcn_readfirstlane((int)zp_run_start(run, g.W, g.nruns, g.wclose));
+    const int p1 = __builtin_amdgcn_readfirstlane((int)zp_run_start(run + 1, g.W, g.nruns, g.wclose));
+    const int first = run == 0 ? 0 : p0 - 1;
+    const int lastf = p1 - 1;
 
     FirPair<NR, 16, 0, true> P{a, t, a.wlen - 1, xr, yr, 0, cube_lds};
     fft::cube2::tw_load(t, a.tb, P.tw1, P.tw2);
 #pragma unroll
     for (int j = 0; j < D; ++j) P.cr[j] = 0.0;
+    if (DMA && first <= lastf) zp_request_pair<NR>(xr + (int64_t)first * (2 * S), t, cube_lds);
     {
         // lrow | ptab | mtab are one table on the device too (g.Lrow): every request of the
         // sweep is out before the first answer is needed
@@ -339,7 +371,8 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     bool bad = g.nanpos[c] != 0x7fffffffffffffffLL;
     int64_t bad_at = 0;              // chunk position of the pair that went bad
     int par = 0;
-    const unsigned lane8 = 8u * (unsigned)t;   // a lane's byte offset inside a row of 256 samples
+    int younger = -1;                // DMA kernels: vector-memory operations behind the pending requests
+    const unsigned lane8_entry = 8u * (unsigned)t;   // a lane's byte offset inside a row of 256 samples
     __syncthreads();
     OSZ_ZMARK(1);
 
@@ -359,25 +392,47 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     for (int q = 0; q < 12; ++q) P.stamp_acc[q] = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.stamp_last)::"memory");
 #endif
-    for (int64_t p = first; p <= lastf; ++p) {
-        const int64_t o = p * (2 * S);
+    for (int p = first; p <= lastf; ++p) {
+        const int64_t o = (int64_t)p * (2 * S);
         double re[16], im[16];
         take_turns();
-        {
+        if (DMA) {
+            // the pair's samples were requested behind the previous pair's transform: younger
+            // than they are only that pair's stores (requests and stores retire in order on
+            // one counter), `younger` of them when every one went through the row stores
+            if (younger == 2 * NR) asm volatile("s_waitcnt vmcnt(%0) ; osz:dma" ::"n"(2 * NR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) ; osz:dma" ::: "memory");
+            int tq = t;
+            asm volatile("" : "+v"(tq));
+            const double *xs = reinterpret_cast<const double *>(cube_lds) + 128 * (tq >> 6) + (tq & 63);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = j < NR ? xs[512 * (j >> 1) + 64 * (j & 1)] : 0.0;
+                im[j] = j < NR ? xs[512 * ((j + NR) >> 1) + 64 * ((j + NR) & 1)] : 0.0;
+            }
+        } else {
             // rows of the pair: base and row offsets in scalar registers (buf_rsrc, common.h)
             const __amdgpu_buffer_rsrc_t rx = buf_rsrc(xr + o);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                re[j] = j < NR ? buf_load(rx, lane8, 2048u * j) : 0.0;
-                im[j] = j < NR ? buf_load(rx, lane8, 2048u * (j + NR)) : 0.0;
+                re[j] = j < NR ? buf_load(rx, lane8_entry, 2048u * j) : 0.0;
+                im[j] = j < NR ? buf_load(rx, lane8_entry, 2048u * (j + NR)) : 0.0;
             }
         }
         OSZ_ZSTAMP(0);    // previous pair's stores + this pair's loads issued
         P.transform(re, im);
+        if (DMA && p < lastf) {
+            // inverse pass 1 has read this wave's pieces of the cube (its values are in use
+            // below): the next pair's samples can land there while fit, bursts and stores run
+            asm volatile("s_waitcnt lgkmcnt(0) ; osz:dma" ::: "memory");
+            zp_request_pair<NR>(xr + o + 2 * S, t, cube_lds);
+        }
+        int nst = 0;             // row stores of this pair, -1: some went another way
         OSZ_ZSTAMP(11);   // inverse pass 1
         // thread -> role indices, recomputed per pair from an opaque copy of t
         int tt = t;
         asm volatile("" : "+v"(tt));
+        const unsigned lane8 = DMA ? 8u * (unsigned)tt : lane8_entry;   // (DMA: not kept over the transform)
         if (tt < nh) {
             fitbuf[tt] = re[15];
             fitbuf[ns + tt] = im[15];
@@ -443,6 +498,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         if (run == 0 && p == 0) {
             // the chunk opens: what the stream so far still owes these samples, and the
             // previous chunk's last L samples, complete with this block's +nu
+            nst = -1;
             const double *ci = g.carry_in + (int64_t)c * kSpecLdc + tt;
             if (!bad &&
                 __builtin_amdgcn_readfirstlane((int)sos_not_finite(g.carry_in[(int64_t)c * kSpecLdc + 4095 + 256 * R]))) {
@@ -470,7 +526,9 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
 #pragma unroll
                 for (int r = 0; r < kSpecRMax; ++r)
                     if (r < R) buf_store(held[r] + c7[r], ry, lane8, 2048u * (NR - 1 - r));
+                if (nst >= 0) nst += R;
             } else {
+                nst = -1;
                 const int64_t ob = o - S + tt;
 #pragma unroll
                 for (int r = 0; r < kSpecRMax; ++r)
@@ -486,7 +544,9 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
                     buf_store(re[j], ry, lane8, 2048u * j);
                     if (j < NR - R) buf_store(im[j], ry, lane8, 2048u * (j + NR));
                 }
+                if (nst >= 0) nst += 2 * NR - R;
             } else {
+                nst = -1;
                 int64_t off = o + tt;
                 asm volatile("" : "+v"(off));
 #pragma unroll
@@ -500,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
         for (int r = 0; r < kSpecRMax; ++r)
             if (r < R) held[r] = im[(NR - 1 - r) & 15];
         par ^= 1;
+        younger = nst;
     }
 
 #ifdef OSZ_FIR_STAMPS
@@ -763,12 +824,21 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
 }
 
 using zp_kern_t = void (*)(ZpArgs);
-template <int NM>
+template <int NM, bool DMA>
 static zp_kern_t zp_kernel_for(int nr) {
-    static const zp_kern_t k[8] = {chain_zp_kernel<8, NM>,  chain_zp_kernel<9, NM>,  chain_zp_kernel<10, NM>,
-                                   chain_zp_kernel<11, NM>, chain_zp_kernel<12, NM>, chain_zp_kernel<13, NM>,
-                                   chain_zp_kernel<14, NM>, chain_zp_kernel<15, NM>};
+    static const zp_kern_t k[8] = {chain_zp_kernel<8, NM, DMA>,  chain_zp_kernel<9, NM, DMA>,
+                                   chain_zp_kernel<10, NM, DMA>, chain_zp_kernel<11, NM, DMA>,
+                                   chain_zp_kernel<12, NM, DMA>, chain_zp_kernel<13, NM, DMA>,
+                                   chain_zp_kernel<14, NM, DMA>, chain_zp_kernel<15, NM, DMA>};
     return k[nr - 8];
+}
+// OSZ_ZP_DMA=0: the pair's samples by plain row loads (the kernel of round 3), for comparison
+static bool zp_dma() {
+    static const bool on = [] {
+        const char *e = getenv("OSZ_ZP_DMA");
+        return !(e && e[0] == '0');
+    }();
+    return on;
 }
 
 // one chunk through the kernel; hist: keep the input a later osz_chain_zp_finish replays
@@ -834,7 +904,10 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
         g.hist = nullptr;
         g.hist_len = 0;
     }
-    zp_kern_t kern = s->NM == 2 ? zp_kernel_for<2>(NR) : s->NM == 4 ? zp_kernel_for<4>(NR) : zp_kernel_for<6>(NR);
+    zp_kern_t kern = zp_dma() ? (s->NM == 2 ? zp_kernel_for<2, true>(NR) : s->NM == 4 ? zp_kernel_for<4, true>(NR)
+                                                                                      : zp_kernel_for<6, true>(NR))
+                              : (s->NM == 2 ? zp_kernel_for<2, false>(NR) : s->NM == 4 ? zp_kernel_for<4, false>(NR)
+                                                                                       : zp_kernel_for<6, false>(NR));
     const size_t lds = zp_lds_bytes(s);
     OSZ_DYN_LDS(kern, lds);
     {
