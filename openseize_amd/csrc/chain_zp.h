@@ -1,0 +1,111 @@
+// chain_zp.h -- what the two zero-phase chain kernels share: chain_zp.hip (two real blocks per
+// 4096-point transform, the pair trick) and chain_zpn.hip (ONE real block of up to 30 rows per
+// transform at the odd frequencies, fft::nega) -- launch arguments, the run partition, mode
+// powers and burst sums, the request of a block's rows by LDS-DMA.
+#pragma once
+
+#include "chain_spec.h"
+#include "fft4096.h"
+#include "fir_pair.h"
+#include "handles.h"
+
+namespace osz {
+
+struct ZpArgs {
+    FirArgs f;                 // x, ldx, wlen, step, H (zero-phase composite), tb; y / ldy: outputs n0 .. n
+    double *y0;                // outputs 0 .. n0 (the tail of the caller's previous output chunk), or null
+    int64_t ldy0, n0;
+    int64_t n;                 // samples of this chunk
+    int64_t W;                 // whole pairs on the fast path
+    int nruns;
+    int la, lb;                // lengths of the closing pair's two blocks
+    int R, Rf, nh;             // burst rows backwards (and table stride) / forwards; fit samples at either end of row 15
+    const double *M;           // [4 NM][2 nh]
+    const double *P;           // [20][NM][2]
+    const double *Lrow;        // [R][NM][2]
+    const double *carry_in;    // (nch, kSpecLdc)
+    double *carry_out;
+    const double *held_in;     // (nch, 256 R): the previous chunk's last samples, one burst short
+    double *held_out;
+    double *hist;              // (nch, hist_len): the chunk's last input samples, or null
+    int hist_len;
+    long long *nanpos;         // (nch): stream position at which the forward stream went bad
+    long long pos;             // stream position of this chunk's first sample
+    int wclose;                // what closing the chunk costs its last run, in pairs
+};
+
+// First pair of run r (r = nruns: one past the last).  The runs of a channel do not cost the
+// same: every run but the first starts one pair early, and the last one closes the chunk (a
+// generic path, `wclose` pairs' worth); with balanced costs the last run gets fewer pairs of its
+// own and the launch does not wait for it (256 channels, two runs each: 94.5 : 94.5 instead
+// of 93 : 96).  Short runs keep the even split.
+__host__ __device__ __forceinline__ int64_t zp_run_start(int64_t r, int64_t W, int nruns, int wclose) {
+    if (r <= 0) return 0;
+    if (r >= nruns) return W;
+    if (W < 8 * (int64_t)nruns) return (r * W) / nruns;
+    const int64_t V = W + (nruns - 1) + wclose;        // pairs, pre-roll pairs, the closing pair
+    const int64_t s = (r * V) / nruns - (r - 1);
+    return s < W - (nruns - r) ? s : W - (nruns - r);  // every later run keeps a pair of its own
+}
+
+// lambda^e for e = 0..255 from the three-level table [20][NM][2]
+template <int NM>
+__device__ __forceinline__ void zp_powers(const double *ptab, int e, double *pr, double *pi) {
+    const double *p1 = ptab + ((e >> 5) * NM) * 2, *p2 = ptab + ((8 + ((e >> 2) & 7)) * NM) * 2,
+                 *p3 = ptab + ((16 + (e & 3)) * NM) * 2;
+#pragma unroll
+    for (int q = 0; q < NM; ++q) {
+        const double ar = p1[2 * q] * p2[2 * q] - p1[2 * q + 1] * p2[2 * q + 1];
+        const double ai = p1[2 * q] * p2[2 * q + 1] + p1[2 * q + 1] * p2[2 * q];
+        pr[q] = ar * p3[2 * q] - ai * p3[2 * q + 1];
+        pi[q] = ar * p3[2 * q + 1] + ai * p3[2 * q];
+    }
+}
+
+// Re sum_q kappa_q P_q
+template <int NM>
+__device__ __forceinline__ double zp_dot(const double *kk, const double *pr, const double *pi) {
+    double c = 0.0;
+#pragma unroll
+    for (int q = 0; q < NM; ++q) c = fma(kk[2 * q], pr[q], fma(-kk[2 * q + 1], pi[q], c));
+    return c;
+}
+
+// A block's (a pair's) rows of 256 samples, requested by LDS-DMA into the cube.  A wave
+// owns, in every 4 KB plane of the cube, the 1 KB piece [1024 w, 1024 w + 1024) -- the slots it
+// reads last in a transform (inverse pass 1, view A) and writes first in the next one (pass 1) --
+// so between the two nobody else touches it: piece m takes the wave's 64 samples of rows 2 m and
+// 2 m + 1 (one 16-byte request per lane: lanes 0-31 row 2 m, lanes 32-63 row 2 m + 1), and the
+// wave reads its own requests back behind its own vmcnt wait -- no barrier, no registers held
+// while the samples are on their way.
+// NP pieces = 2 NP rows from src on; rows >= nrows (an odd count's last half piece) lie behind the
+// descriptor's range: their lanes request nothing.
+template <int NP>
+__device__ __forceinline__ void zp_request_rows(const double *src, int nrows, int t, const void *cube) {
+    int tq = t;
+    asm volatile("" : "+v"(tq));     // per block, not hoisted
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(src), 0, 2048 * nrows, 0x00020000);
+    const unsigned voff = 2048u * (((unsigned)tq >> 5) & 1u) + 512u * ((unsigned)tq >> 6) + 16u * ((unsigned)tq & 31u);
+    const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(cube) +
+                                                         1024u * ((unsigned)tq >> 6));
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(ldsb + 4096u * m), "v"(voff + 4096u * m), "s"(rx)   // (the range check sees the lane offset)
+                     : "memory");
+    }
+}
+
+
+// chain_zpn.hip: the kernel for NB rows per block (24 .. 30) and NM modes (2, 4, 6)
+using zp_kern_t = void (*)(ZpArgs);
+zp_kern_t zpn_kernel_for(int nb, int nm);
+
+}  // namespace osz

@@ -36,72 +36,9 @@
 #include <functional>
 #include <vector>
 
-#include "chain_spec.h"
-#include "fft4096.h"
-#include "fir_pair.h"
-#include "handles.h"
+#include "chain_zp.h"
 
 namespace osz {
-
-struct ZpArgs {
-    FirArgs f;                 // x, ldx, wlen, step, H (zero-phase composite), tb; y / ldy: outputs n0 .. n
-    double *y0;                // outputs 0 .. n0 (the tail of the caller's previous output chunk), or null
-    int64_t ldy0, n0;
-    int64_t n;                 // samples of this chunk
-    int64_t W;                 // whole pairs on the fast path
-    int nruns;
-    int la, lb;                // lengths of the closing pair's two blocks
-    int R, Rf, nh;             // burst rows backwards (and table stride) / forwards; fit samples at either end of row 15
-    const double *M;           // [4 NM][2 nh]
-    const double *P;           // [20][NM][2]
-    const double *Lrow;        // [R][NM][2]
-    const double *carry_in;    // (nch, kSpecLdc)
-    double *carry_out;
-    const double *held_in;     // (nch, 256 R): the previous chunk's last samples, one burst short
-    double *held_out;
-    double *hist;              // (nch, hist_len): the chunk's last input samples, or null
-    int hist_len;
-    long long *nanpos;         // (nch): stream position at which the forward stream went bad
-    long long pos;             // stream position of this chunk's first sample
-    int wclose;                // what closing the chunk costs its last run, in pairs
-};
-
-// First pair of run r (r = nruns: one past the last).  The runs of a channel do not cost the
-// same: every run but the first starts one pair early, and the last one closes the chunk (a
-// generic path, `wclose` pairs' worth); with balanced costs the last run gets fewer pairs of its
-// own and the launch does not wait for it (256 channels, two runs each: 94.5 : 94.5 instead
-// of 93 : 96).  Short runs keep the even split.
-__host__ __device__ __forceinline__ int64_t zp_run_start(int64_t r, int64_t W, int nruns, int wclose) {
-    if (r <= 0) return 0;
-    if (r >= nruns) return W;
-    if (W < 8 * (int64_t)nruns) return (r * W) / nruns;
-    const int64_t V = W + (nruns - 1) + wclose;        // pairs, pre-roll pairs, the closing pair
-    const int64_t s = (r * V) / nruns - (r - 1);
-    return s < W - (nruns - r) ? s : W - (nruns - r);  // every later run keeps a pair of its own
-}
-
-// lambda^e for e = 0..255 from the three-level table [20][NM][2]
-template <int NM>
-__device__ __forceinline__ void zp_powers(const double *ptab, int e, double *pr, double *pi) {
-    const double *p1 = ptab + ((e >> 5) * NM) * 2, *p2 = ptab + ((8 + ((e >> 2) & 7)) * NM) * 2,
-                 *p3 = ptab + ((16 + (e & 3)) * NM) * 2;
-#pragma unroll
-    for (int q = 0; q < NM; ++q) {
-        const double ar = p1[2 * q] * p2[2 * q] - p1[2 * q + 1] * p2[2 * q + 1];
-        const double ai = p1[2 * q] * p2[2 * q + 1] + p1[2 * q + 1] * p2[2 * q];
-        pr[q] = ar * p3[2 * q] - ai * p3[2 * q + 1];
-        pi[q] = ar * p3[2 * q + 1] + ai * p3[2 * q];
-    }
-}
-
-// Re sum_q kappa_q P_q
-template <int NM>
-__device__ __forceinline__ double zp_dot(const double *kk, const double *pr, const double *pi) {
-    double c = 0.0;
-#pragma unroll
-    for (int q = 0; q < NM; ++q) c = fma(kk[2 * q], pr[q], fma(-kk[2 * q + 1], pi[q], c));
-    return c;
-}
 
 // The fit and the burst amplitudes of a pair in one stage.  Eight consecutive lanes share one
 // amplitude (block, causal / anticausal, mode): each takes an eighth of the 2 nh fit samples
@@ -284,35 +221,6 @@ __device__ unsigned long long *g_zp_marks = nullptr;   // [nch][nruns][8]
 #define OSZ_ZMARK(k) do { } while (0)
 #endif
 
-// One pair's 2 NR rows of 256 samples, requested by LDS-DMA into the cube (DMA kernels).  A wave
-// owns, in every 4 KB plane of the cube, the 1 KB piece [1024 w, 1024 w + 1024) -- the slots it
-// reads last in a transform (inverse pass 1, view A) and writes first in the next one (pass 1) --
-// so between the two nobody else touches it: piece m takes the wave's 64 samples of rows 2 m and
-// 2 m + 1 (one 16-byte request per lane: lanes 0-31 row 2 m, lanes 32-63 row 2 m + 1), and the
-// wave reads its own requests back behind its own vmcnt wait -- no barrier, no registers held
-// while the samples are on their way.
-template <int NR>
-__device__ __forceinline__ void zp_request_pair(const double *src, int t, const void *cube) {
-    int tq = t;
-    asm volatile("" : "+v"(tq));     // per pair, not hoisted
-    const __amdgpu_buffer_rsrc_t rx = buf_rsrc(src);
-    const unsigned voff = 2048u * (((unsigned)tq >> 5) & 1u) + 512u * ((unsigned)tq >> 6) + 16u * ((unsigned)tq & 31u);
-    const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(cube) +
-                                                         1024u * ((unsigned)tq >> 6));
-#pragma unroll
-    for (int m = 0; m < NR; ++m) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %1\n\t"
-                     "s_nop 0\n\t"
-                     "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "s"(ldsb + 4096u * m), "v"(voff), "s"(rx), "s"(4096u * m)
-                     : "memory");
-    }
-}
-
 template <int NR, int NM, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     OSZ_ZMARK(0);
@@ -353,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     fft::cube2::tw_load(t, a.tb, P.tw1, P.tw2);
 #pragma unroll
     for (int j = 0; j < D; ++j) P.cr[j] = 0.0;
-    if (DMA && first <= lastf) zp_request_pair<NR>(xr + (int64_t)first * (2 * S), t, cube_lds);
+    if (DMA && first <= lastf) zp_request_rows<NR>(xr + (int64_t)first * (2 * S), 2 * NR, t, cube_lds);
     {
         // lrow | ptab | mtab are one table on the device too (g.Lrow): every request of the
         // sweep is out before the first answer is needed
@@ -425,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             // inverse pass 1 has read this wave's pieces of the cube (its values are in use
             // below): the next pair's samples can land there while fit, bursts and stores run
             asm volatile("s_waitcnt lgkmcnt(0) ; osz:dma" ::: "memory");
-            zp_request_pair<NR>(xr + o + 2 * S, t, cube_lds);
+            zp_request_rows<NR>(xr + o + 2 * S, 2 * NR, t, cube_lds);
         }
         int nst = 0;             // row stores of this pair, -1: some went another way
         OSZ_ZSTAMP(11);   // inverse pass 1
@@ -723,6 +631,7 @@ struct ChainZp {
     osz_fir_s *fir = nullptr;
     osz_sos_s *sos = nullptr;
     bool eligible = false, open = false;
+    bool nega = false;             // one real block per transform (chain_zpn.hip); NR is then its rows per block
     int NR = 0, NM = 0, R = 0, Rf = 0, nh = 0;
     double *dH = nullptr, *dT = nullptr;   // dT: burst rows | mode powers | fit matrix, as the kernel's LDS holds them
     double *dM = nullptr, *dP = nullptr, *dL = nullptr;   // (views into dT)
@@ -737,6 +646,27 @@ struct ChainZp {
     double *dscratch = nullptr;
     double *dzero = nullptr;       // (nsec, nch, 2) zeros: start state of the opening's backward pass
 };
+
+// OSZ_ZP_NEGA=0: the pair kernel of this file instead of chain_zpn.hip's (one real block per
+// transform), for comparison
+static bool zp_nega() {
+    static const bool on = [] {
+        const char *e = getenv("OSZ_ZP_NEGA");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+// OSZ_ZP_DMA=0: the pair's samples by plain row loads (the kernel of round 3), for comparison
+static bool zp_dma() {
+    static const bool on = [] {
+        const char *e = getenv("OSZ_ZP_DMA");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// the shortest chunk a step takes: two pairs of blocks / two blocks
+static int64_t zp_min_chunk(const ChainZp *s) { return (s->nega ? 2 : 4) * 256 * (int64_t)s->NR; }
 
 static void zp_free(ChainZp *s) {
     (void)hipFree(s->dH);
@@ -761,6 +691,9 @@ void zp_unlink(ChainZp *s) {
 
 static size_t zp_lds_bytes(const ChainZp *s) {
     const int NM = s->NM, R = s->R, ns = 2 * s->nh;
+    if (s->nega)
+        return sizeof(fft::cube::C2) * fft::cube::SLOTS +
+               sizeof(double) * (ns + 4 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * ns) + 1024;   // + W256 rows
     return sizeof(fft::cube::C2) * fft::cube::SLOTS +
            sizeof(double) * (2 * ns + 8 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * ns);
 }
@@ -778,8 +711,14 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
         s->sos = sos;
         fir->zp = sos->zp = s;
         if (fir->parts.size() == 1 && fir->nch == sos->nch) {
-            const spec::TablesZp T = spec::build_zp(fir->htaps.data(), fir->ntaps, sos->coef, sos->nsec,
-                                                    sos->warm_len <= (1 << 20));
+            spec::TablesZp T;
+            if (zp_nega()) {
+                T = spec::build_zpn(fir->htaps.data(), fir->ntaps, sos->coef, sos->nsec, sos->warm_len <= (1 << 20),
+                                    15360 - 1024);
+                s->nega = T.eligible;
+            }
+            if (!T.eligible)
+                T = spec::build_zp(fir->htaps.data(), fir->ntaps, sos->coef, sos->nsec, sos->warm_len <= (1 << 20));
             if (T.eligible) {
                 auto up = [](double **d, const std::vector<double> &v) -> int {
                     OSZ_HIP(hipMalloc(d, v.size() * sizeof(double)));
@@ -823,7 +762,6 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
     return OSZ_OK;
 }
 
-using zp_kern_t = void (*)(ZpArgs);
 template <int NM, bool DMA>
 static zp_kern_t zp_kernel_for(int nr) {
     static const zp_kern_t k[8] = {chain_zp_kernel<8, NM, DMA>,  chain_zp_kernel<9, NM, DMA>,
@@ -832,15 +770,6 @@ static zp_kern_t zp_kernel_for(int nr) {
                                    chain_zp_kernel<14, NM, DMA>, chain_zp_kernel<15, NM, DMA>};
     return k[nr - 8];
 }
-// OSZ_ZP_DMA=0: the pair's samples by plain row loads (the kernel of round 3), for comparison
-static bool zp_dma() {
-    static const bool on = [] {
-        const char *e = getenv("OSZ_ZP_DMA");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
-
 // one chunk through the kernel; hist: keep the input a later osz_chain_zp_finish replays
 static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double *y0, int64_t ldy0,
                      int64_t n0, double *y, int64_t ldy, hipStream_t st) {
@@ -848,8 +777,10 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
     const int NR = s->NR, S = 256 * NR;
     const int64_t pair = 2 * (int64_t)S;
     const int64_t npw = n / pair, rem = n - npw * pair;
-    const int64_t W = rem == 0 ? npw - 1 : npw;
-    const int64_t nlast = n - W * pair;
+    // whole pairs (blocks) on the fast path; the closing pair has 1 .. 2 S samples, the new
+    // kernel's closing block 1 .. S
+    const int64_t W = s->nega ? (n - 1) / S : rem == 0 ? npw - 1 : npw;
+    const int64_t nlast = s->nega ? n - W * S : n - W * pair;
     // one round of resident workgroups (two per CU); a run has a pair of its own
     int64_t nruns = 512 / fir->nch;
     if (nruns > W) nruns = W;
@@ -885,7 +816,7 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
     g.held_out = s->dheld[s->cur ^ 1];
     g.nanpos = s->dnanpos;
     g.pos = s->pos;
-    g.wclose = 4;   // measured: 2 ... 12 pairs, 32 and 256 channels (profiles/README.md)
+    g.wclose = s->nega ? 1 : 4;   // pairs: measured, 2 ... 12 at 32 and 256 channels (profiles/README.md); a closing block is one more block
     if (n >= s->hist_cap) {
         g.hist = s->dhist[s->hcur];
         g.hist_len = s->hist_cap;
@@ -904,10 +835,12 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
         g.hist = nullptr;
         g.hist_len = 0;
     }
-    zp_kern_t kern = zp_dma() ? (s->NM == 2 ? zp_kernel_for<2, true>(NR) : s->NM == 4 ? zp_kernel_for<4, true>(NR)
-                                                                                      : zp_kernel_for<6, true>(NR))
-                              : (s->NM == 2 ? zp_kernel_for<2, false>(NR) : s->NM == 4 ? zp_kernel_for<4, false>(NR)
-                                                                                       : zp_kernel_for<6, false>(NR));
+    zp_kern_t kern = s->nega    ? zpn_kernel_for(NR, s->NM)
+                     : zp_dma() ? (s->NM == 2 ? zp_kernel_for<2, true>(NR) : s->NM == 4 ? zp_kernel_for<4, true>(NR)
+                                                                                       : zp_kernel_for<6, true>(NR))
+                                : (s->NM == 2 ? zp_kernel_for<2, false>(NR) : s->NM == 4 ? zp_kernel_for<4, false>(NR)
+                                                                                        : zp_kernel_for<6, false>(NR));
+    if (!kern) return fail(OSZ_ERR_STATE, "zero-phase kernel: no instance for %d rows, %d modes", NR, s->NM);
     const size_t lds = zp_lds_bytes(s);
     OSZ_DYN_LDS(kern, lds);
     {
@@ -937,7 +870,7 @@ int64_t osz_chain_zp_min_chunk(osz_fir_t fir, osz_sos_t sos) {
     if (!fir || !sos) return -1;
     ChainZp *s = nullptr;
     if (zp_get(fir, sos, &s) != OSZ_OK || !s->eligible) return -1;
-    return 4 * 256 * (int64_t)s->NR;
+    return zp_min_chunk(s);
 }
 
 int osz_chain_zp_open(osz_fir_t fir, osz_sos_t sos, int64_t skip, void *stream) {
@@ -983,8 +916,8 @@ int osz_chain_zp_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
     OSZ_SAME_DEVICE(sos, "osz_chain_zp_step");
     ChainZp *s = sos->zp;
     OSZ_REQUIRE(s && s->fir == fir && s->open, "osz_chain_zp_step: osz_chain_zp_open first");
-    OSZ_REQUIRE(n >= 4 * 256 * (int64_t)s->NR, "osz_chain_zp_step: a chunk of %lld samples is shorter than two pairs of blocks (%d)",
-                (long long)n, 4 * 256 * s->NR);
+    OSZ_REQUIRE(n >= zp_min_chunk(s), "osz_chain_zp_step: a chunk of %lld samples is shorter than two (pairs of) blocks (%lld)",
+                (long long)n, (long long)zp_min_chunk(s));
     return zp_launch(s, x, ldx, n, y0, ldy0, n0, y, ldy, as_stream(stream));
 }
 
@@ -1022,7 +955,7 @@ int osz_chain_zp_finish(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t l
     OSZ_HIP(hipGetLastError());
     // 2. the output samples the stream is still short of need the head of what follows
     if (ny > 0) {
-        OSZ_REQUIRE(x && y && m >= 4 * 256 * (int64_t)s->NR && ldx >= m && ny <= m - 2 * 256 * (int64_t)s->NR &&
+        OSZ_REQUIRE(x && y && m >= zp_min_chunk(s) && ldx >= m && ny <= m - zp_min_chunk(s) / 2 &&
                         ldy >= ny,
                     "osz_chain_zp_finish: %lld output samples from %lld input samples", (long long)ny, (long long)m);
         // through a scratch output: the kernel writes all m of them

@@ -1,0 +1,477 @@
+// chain_zpn.hip -- FIR -> sosfiltfilt of a long stream, ONE real block per transform.
+//
+// Same scheme as chain_zp.hip (oaconvolve, core/numerical.py:158-298, into sosfiltfilt,
+// :338-411, as one multiplication per bin by H_fir |H_iir|^2 plus mode bursts for what the
+// cascade's two-sided ringing does in a finite window), on a different transform: fft::nega
+// (fft4096.h) takes a window of 8192 samples of ONE real block through the 4096-point complex
+// transform at the odd frequencies.  The FIR's tail (wlen - 1 samples) and the guard row the
+// fit reads are paid once per 8192-sample window instead of once per 4096: at 1024 taps a
+// transform carries 27 rows of 256 samples where the pair trick carries 2 x 11, and the fit
+// and the bursts are one block's, not two.
+//
+// The window (rows of 256 samples; a thread holds sample t of every row: rows 0-15 in re[],
+// rows 16-31 in im[]):
+//     rows 0 .. NB-1        the block's outputs (rows 0 .. D-1 also take the previous block's
+//                           tail rows, D = 32 - NB, carried in registers)
+//     rows NB .. 30         FIR tail + ringing: the next block's rows 0 .. D-2
+//     row 31                ringing only: the fit's samples (first and last nh), then the next
+//                           block's row D-1
+// The wrap is NEGACYCLIC: what leaves the window on one side returns on the other with its
+// sign changed.  With mu (causal, at window sample 8192) and nu (anticausal, at sample -1)
+// from the joint fit (spec::build_zpn gives nu its true sign) a block adds
+//     +mu forwards from its row 0          (the wrapped right tail leaves the window)
+//     +nu backwards from its row 31        (the wrapped left tail leaves the window)
+// and receives the true tails of its neighbours:
+//     +mu of the PREVIOUS block forwards from row D   (kapP, one block old)
+//     +nu of the NEXT block backwards from row NB-1   (the last R rows of a block wait in
+//                                                      registers for the next block's fit: the
+//                                                      output stream runs L = 256 R samples late)
+// Three burst evaluations per row index serve the four places (the left tail leaves row 31-r
+// and arrives in the held rows with the same values).  Runs, the opening block (carry, held),
+// NaN reach, hist: as in chain_zp.hip.  The closing block (1 .. S samples) is the same body
+// with predicated loads and stores: every sum stays inside a thread's own column (block and
+// bursts start at whole rows), so there is no accumulation through LDS; what lies behind the
+// chunk's end goes to `carry`.
+//
+// A block's rows come in by LDS-DMA (zp_request_rows, chain_zp.h) behind the previous block's
+// transform.
+#include <type_traits>
+
+#include "chain_zp.h"
+
+namespace osz {
+
+// The fit and the burst amplitudes of a block in one stage.  Sixteen consecutive lanes (one DPP
+// row) share one amplitude (causal / anticausal, mode): each takes a sixteenth of the 2 nh fit
+// samples for the real AND the imaginary row of M, four DPP steps add the parts up in the row's
+// last lane, and that lane writes kappa[r] = amplitude * lambda^(256 r), r < R:
+//   kapA[kind][r][q]   kind = 0 mu, 1 nu            (this block)
+//   kapN[r][q]         mu: what the NEXT block meets as mu of the previous block
+template <int NM, int PER>
+__device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fitbuf, const double *mtab,
+                                                const double *lrow, double *kapA, double *kapN) {
+    constexpr int ns = 16 * PER;
+    if ((tt & ~63) >= 32 * NM) return;          // whole waves without an amplitude skip the stage
+    const int qd = tt >> 4, p16 = tt & 15;
+    const bool valid = qd < 2 * NM;
+    const int kind = valid ? qd / NM : 0, q = valid ? qd % NM : 0;
+    const double *yb = fitbuf + PER * p16;
+    const double *mr = mtab + ns * ((2 * kind) * NM + q) + PER * p16;
+    const double *mi = mtab + ns * ((2 * kind + 1) * NM + q) + PER * p16;
+    double y[PER], a[PER], b[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        y[k] = yb[k];
+        a[k] = mr[k];
+        b[k] = mi[k];
+    }
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        sr = fma(a[k], y[k], sr);
+        si = fma(b[k], y[k], si);
+    }
+    if (!valid) sr = si = 0.0;
+    sr += dpp_row_shr0<1>(sr);
+    si += dpp_row_shr0<1>(si);
+    sr += dpp_row_shr0<2>(sr);
+    si += dpp_row_shr0<2>(si);
+    sr += dpp_row_shr0<4>(sr);
+    si += dpp_row_shr0<4>(si);
+    sr += dpp_row_shr0<8>(sr);
+    si += dpp_row_shr0<8>(si);
+    if (p16 == 15 && valid) {
+#pragma unroll
+        for (int r = 0; r < kSpecRMax; ++r) {
+            if (r < R) {
+                const double lr = lrow[(r * NM + q) * 2 + 0], li = lrow[(r * NM + q) * 2 + 1];
+                const double kr = sr * lr - si * li, ki = sr * li + si * lr;
+                kapA[((kind * R + r) * NM + q) * 2 + 0] = kr;
+                kapA[((kind * R + r) * NM + q) * 2 + 1] = ki;
+                if (kind == 0) {
+                    kapN[(r * NM + q) * 2 + 0] = kr;
+                    kapN[(r * NM + q) * 2 + 1] = ki;
+                }
+            }
+        }
+    }
+}
+
+// nh is 16, 24 or 32 (spec::build_zpn)
+template <int NM>
+__device__ __forceinline__ void zpn_fit_kappa(int tt, int nh, int R, const double *fitbuf, const double *mtab,
+                                              const double *lrow, double *kapA, double *kapN) {
+    if (nh == 24) zpn_fit_kappa_n<NM, 3>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+    else if (nh == 32) zpn_fit_kappa_n<NM, 4>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+    else zpn_fit_kappa_n<NM, 2>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+}
+
+// two bursts of one row at once: Re sum_q k0_q P_q and Re sum_q k1_q P_q
+template <int NM>
+__device__ __forceinline__ void zpn_dot2(const double *k0, const double *k1, const double *pr, const double *pi,
+                                         double &d0, double &d1) {
+    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+#pragma unroll
+    for (int q = 0; q < NM; ++q) {
+        ar = fma(k0[2 * q], pr[q], ar);
+        ai = fma(k0[2 * q + 1], pi[q], ai);
+        br = fma(k1[2 * q], pr[q], br);
+        bi = fma(k1[2 * q + 1], pi[q], bi);
+    }
+    d0 = ar - ai;
+    d1 = br - bi;
+}
+
+// The forward bursts (RF rows): this block's mu leaves row r, the previous block's arrives in
+// row D + r (both rows live in re[]: D + r <= 8 + 4).
+template <int D, int NM, int RF>
+__device__ __forceinline__ void zpn_fwd_bursts(double *re, const double *kmu, const double *kpm, const double *Pr,
+                                               const double *Pi, double &first) {
+#pragma unroll
+    for (int r = 0; r < RF; ++r) {
+        double ca, cp;
+        zpn_dot2<NM>(kmu + (r * NM) * 2, kpm + (r * NM) * 2, Pr, Pi, ca, cp);
+        re[r] += ca;
+        re[D + r] += cp;
+        if (r == 0) first = ca;
+    }
+}
+
+// The backward bursts (RB rows): this block's nu leaves window row 31 - r (im[15 - r]) and
+// arrives, with the same values, in the rows the previous block holds back (c7).
+template <int NM, int RB>
+__device__ __forceinline__ void zpn_bwd_bursts(double *im, double *c7, const double *knu, const double *Pr,
+                                               const double *Pi) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const double nb = zp_dot<NM>(knu + (r * NM) * 2, Pr, Pi);
+        im[15 - r] += nb;
+        c7[r] = nb;
+    }
+}
+
+// the transform of a block's window in place: pack, forward, x spectrum, inverse, unpack
+template <int NHI>
+struct NegaWindow {
+    using C2 = fft::cube::C2;
+    const FirArgs &a;
+    C2 *L;
+    const C2 *tw2l;               // [16 n0][4]: W256^(n0 2^q) in LDS (sixteen distinct rows: not worth registers)
+    fft::nega::TwPowN tw1;
+
+    __device__ __forceinline__ void load_tw2(int t, fft::cube::TwPow &w) const {
+        const C2 *p = tw2l + 4 * (t & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const C2 v = p[q];
+            w.r[q] = v.re;
+            w.i[q] = v.im;
+        }
+    }
+
+    __device__ __forceinline__ void transform(int t_in, double *re, double *im) {
+        // LDS slot numbers are recomputed per block from an opaque copy of the thread index:
+        // hoisted out of the loop they would pin registers
+        int t = t_in;
+        asm volatile("" : "+v"(t));
+        fft::nega::f1<NHI>(t, re, im, tw1, L);
+        __syncthreads();
+        fft::cube::TwPow tw2;
+        load_tw2(t, tw2);
+        fft::cube2::f2(t, re, im, tw2, L);
+        // the spectrum of the pair's sixteen bins is requested before the fence (from L2: resident
+        // it spills); base and bin row in scalar registers, one 32-bit lane offset (buf_rsrc)
+        double hr[16], hi[16];
+        const unsigned lane16 = 16u * ((unsigned)t & 255u);
+        const __amdgpu_buffer_rsrc_t rh = buf_rsrc(a.H);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const buf_d2 h = buf_load2(rh, lane16, 4096u * r);
+            hr[r] = h.x;
+            hi[r] = h.y;
+        }
+        wave_lds_fence();
+        fft::cube2::f3(t, re, im, L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fft::cube::cmul(re[r], im[r], hr[r], hi[r]);
+        fft::cube2::i3(t, re, im, L);
+        wave_lds_fence();
+        load_tw2(t, tw2);
+        fft::cube2::i2(t, re, im, tw2, L);
+        __syncthreads();
+        fft::nega::i1(t, re, im, tw1, L);
+    }
+};
+
+template <int NB, int NM>
+__global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
+    constexpr int D = 32 - NB, S = 256 * NB, NHI = NB - 16, NP = (NB + 1) / 2;
+    static_assert(NB >= 24 && NB <= 30, "rows per block");
+    extern __shared__ fft::cube::C2 cube_lds[];
+    const int R = g.R, Rf = g.Rf, nh = g.nh, ns = 2 * nh;
+    double *xl = reinterpret_cast<double *>(cube_lds) + 2 * fft::cube::SLOTS;   // behind the cube
+    double *fitbuf = xl;                               // [2 nh]
+    double *kapA = fitbuf + ns;                        // [2 kind][R][NM][2]: this block's mu, nu
+    double *kapP = kapA + 2 * R * NM * 2;              // [2 parity][R][NM][2]: the previous block's mu
+    double *lrow = kapP + 2 * R * NM * 2;              // [R][NM][2]
+    double *ptab = lrow + R * NM * 2;                  // [20][NM][2]
+    double *mtab = ptab + 20 * NM * 2;                 // [4 NM][2 nh]
+    fft::cube::C2 *tw2l = reinterpret_cast<fft::cube::C2 *>(mtab + 4 * NM * ns);   // [16][4]
+    const FirArgs &a = g.f;
+    const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
+    const int L = 256 * R;
+    const double *xr = a.x + (int64_t)c * a.ldx;
+    // output q of this chunk: q < n0 -> y0r[q], else yr[q] (yr: the second buffer, shifted by n0)
+    const int64_t n = g.n, n0 = g.n0;
+    double *y0r = g.y0 ? g.y0 + (int64_t)c * g.ldy0 : nullptr;
+    double *yr = a.y + (int64_t)c * a.ldy - n0;
+    double *ho = g.held_out + (int64_t)c * L;
+    // (the partition's 64-bit divisions run on the vector unit: their results, uniform, go back to
+    // scalar registers -- a chunk has far fewer than 2^31 blocks)
+    const int p0 = __builtin_amdgcn_readfirstlane((int)zp_run_start(run, g.W, g.nruns, g.wclose));
+    const int p1 = __builtin_amdgcn_readfirstlane((int)zp_run_start(run + 1, g.W, g.nruns, g.wclose));
+    const int first = run == 0 ? 0 : p0 - 1;
+    const int lastf = p1 - 1;
+    const bool closes = run == g.nruns - 1;
+
+    NegaWindow<NHI> P{a, cube_lds, tw2l};
+    {
+        fft::cube::TwPow w2;                               // (its sixteen rows go to LDS below)
+        fft::nega::tw_load(t, a.tb, P.tw1, w2);
+        if (t < 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tw2l[4 * t + q] = fft::cube::C2{w2.r[q], w2.i[q]};
+        }
+    }
+    double cr[D];                    // the previous block's rows NB .. 31: this block's rows 0 .. D-1
+#pragma unroll
+    for (int j = 0; j < D; ++j) cr[j] = 0.0;
+    if (first <= lastf) zp_request_rows<NP>(xr + (int64_t)first * S, NB, t, cube_lds);
+    {
+        // lrow | ptab | mtab are one table on the device too (g.Lrow)
+        const int ntab = R * NM * 2 + 20 * NM * 2 + 4 * NM * ns;
+#pragma unroll 8
+        for (int i = t; i < ntab; i += 256) lrow[i] = g.Lrow[i];
+    }
+    for (int i = t; i < 2 * R * NM * 2; i += 256) kapP[i] = 0.0;
+    double held[kSpecRMax];          // rows NB-1-r of the previous block, one burst short
+#pragma unroll
+    for (int r = 0; r < kSpecRMax; ++r) held[r] = 0.0;
+    // `bad` is uniform (a scalar), and sticky: the stream went bad in an earlier chunk, or a block
+    // of this run held non-finite samples -- behind the transform they are everywhere
+    bool bad = g.nanpos[c] != 0x7fffffffffffffffLL;
+    int64_t bad_at = 0;
+    int par = 0;
+    int younger = -1;                // vector-memory operations behind the pending requests
+    __syncthreads();
+
+    // a sample of the chunk (position i, value v) goes to the output, L samples late, or,
+    // the chunk's last L samples, to `held`
+#define OSZ_ZP_PUT(i_, v_)                      \
+    do {                                        \
+        const int64_t q_ = (i_) + L;            \
+        if (q_ < n0) y0r[q_] = (v_);            \
+        else if (q_ < n) yr[q_] = (v_);         \
+        else ho[q_ - n] = (v_);                 \
+    } while (0)
+
+    // One block.  `closing` (a compile-time tag: the two bodies are allocated apart, the ragged
+    // one does not weigh on the hot loop) is the chunk's last block of g.la samples.
+    auto block = [&](const int p, auto closing_tag) __attribute__((always_inline)) {
+        constexpr bool closing = decltype(closing_tag)::value;
+        const int64_t o = (int64_t)p * S;
+        double re[16], im[16];
+        take_turns();
+        if (!closing) {
+            // the block's samples were requested behind the previous block's transform: younger
+            // than they are only that block's stores (requests and stores retire in order on one
+            // counter), `younger` of them when every one went through the row stores
+            if (younger == NB) asm volatile("s_waitcnt vmcnt(%0) ; osz:dma" ::"n"(NB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) ; osz:dma" ::: "memory");
+            int tq = t;
+            asm volatile("" : "+v"(tq));
+            const double *xs = reinterpret_cast<const double *>(cube_lds) + 128 * (tq >> 6) + (tq & 63);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = xs[512 * (j >> 1) + 64 * (j & 1)];
+                im[j] = j < NHI ? xs[512 * ((j + 16) >> 1) + 64 * ((j + 16) & 1)] : 0.0;
+            }
+        } else {
+            const int la = g.la;
+            const double *xc = xr + o + t;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = 256 * j + t < la ? xc[256 * j] : 0.0;
+                im[j] = (j < NHI && 4096 + 256 * j + t < la) ? xc[4096 + 256 * j] : 0.0;
+            }
+        }
+        P.transform(t, re, im);
+        if (!closing && p < lastf) {
+            // inverse pass 1 has read this wave's pieces of the cube: the next block's samples can
+            // land there while fit, bursts and stores run
+            asm volatile("s_waitcnt lgkmcnt(0) ; osz:dma" ::: "memory");
+            zp_request_rows<NP>(xr + o + S, NB, t, cube_lds);
+        }
+        int nst = 0;             // row stores of this block, -1: some went another way
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const unsigned lane8 = 8u * (unsigned)tt;
+        if (tt < nh) fitbuf[tt] = im[15];
+        else if (tt >= 256 - nh) fitbuf[tt - 256 + ns] = im[15];
+#pragma unroll
+        for (int j = 0; j < D; ++j) re[j] += cr[j];
+        __syncthreads();
+        zpn_fit_kappa<NM>(tt, nh, R, fitbuf, mtab, lrow, kapA, kapP + (par ^ 1) * (R * NM * 2));
+        __syncthreads();
+        double c7[kSpecRMax];
+#pragma unroll
+        for (int r = 0; r < kSpecRMax; ++r) c7[r] = 0.0;
+        {
+            double Pr[NM], Pi[NM];
+            zp_powers<NM>(ptab, tt, Pr, Pi);
+            const double *kpm = kapP + par * (R * NM * 2);
+            double ca = 0.0;
+            switch (Rf) {
+                case 1: zpn_fwd_bursts<D, NM, 1>(re, kapA, kpm, Pr, Pi, ca); break;
+                case 2: zpn_fwd_bursts<D, NM, 2>(re, kapA, kpm, Pr, Pi, ca); break;
+                case 3: zpn_fwd_bursts<D, NM, 3>(re, kapA, kpm, Pr, Pi, ca); break;
+                case 4: zpn_fwd_bursts<D, NM, 4>(re, kapA, kpm, Pr, Pi, ca); break;
+                default: zpn_fwd_bursts<D, NM, 5>(re, kapA, kpm, Pr, Pi, ca); break;
+            }
+            if (!bad && __builtin_amdgcn_readfirstlane((int)sos_not_finite(ca))) {
+                bad = true;
+                bad_at = o;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            zp_powers<NM>(ptab, 255 - tt, Pr, Pi);
+            const double *knu = kapA + (R * NM) * 2;
+            switch (R) {
+                case 1: zpn_bwd_bursts<NM, 1>(im, c7, knu, Pr, Pi); break;
+                case 2: zpn_bwd_bursts<NM, 2>(im, c7, knu, Pr, Pi); break;
+                case 3: zpn_bwd_bursts<NM, 3>(im, c7, knu, Pr, Pi); break;
+                case 4: zpn_bwd_bursts<NM, 4>(im, c7, knu, Pr, Pi); break;
+                default: zpn_bwd_bursts<NM, 5>(im, c7, knu, Pr, Pi); break;
+            }
+        }
+        const double qn = spec_qnan();
+        const bool own = p >= p0;                      // (a run's first block may be its neighbour's)
+        const bool edge = p >= g.W - 1;                // its samples may be among the chunk's last L
+        if (run == 0 && p == 0) {
+            // the chunk opens: what the stream so far still owes these samples, and the
+            // previous chunk's last L samples, complete with this block's +nu
+            nst = -1;
+            const double *ci = g.carry_in + (int64_t)c * kSpecLdc + tt;
+            if (!bad &&
+                __builtin_amdgcn_readfirstlane((int)sos_not_finite(g.carry_in[(int64_t)c * kSpecLdc + 4095 + 256 * R]))) {
+                bad = true;
+                bad_at = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] += ci[256 * j];
+                if (j < NHI) im[j] += ci[4096 + 256 * j];
+            }
+            const double *hi = g.held_in + (int64_t)c * L + tt;
+#pragma unroll
+            for (int r = 0; r < kSpecRMax; ++r)
+                if (r < R) {
+                    const int64_t q = 256 * (R - 1 - r) + tt;
+                    (q < n0 ? y0r : yr)[q] = bad ? qn : hi[256 * (R - 1 - r)] + c7[r];
+                }
+        } else if (p > first) {
+            // the previous block's last R rows, complete now (also those of the block a run
+            // starts early with: the run before this one leaves them to us)
+            if (!bad && !closing && o - S + L >= n0) {
+                const __amdgpu_buffer_rsrc_t ry = buf_rsrc(yr + (o - S + L));
+#pragma unroll
+                for (int r = 0; r < kSpecRMax; ++r)
+                    if (r < R) buf_store(held[r] + c7[r], ry, lane8, 2048u * (NB - 1 - r));
+                if (nst >= 0) nst += R;
+            } else {
+                nst = -1;
+                const int64_t ob = o - S + tt;
+#pragma unroll
+                for (int r = 0; r < kSpecRMax; ++r)
+                    if (r < R) OSZ_ZP_PUT(ob + 256 * (NB - 1 - r), bad ? qn : held[r] + c7[r]);
+            }
+        }
+        if (closing) {
+            // the chunk's last block: la samples of output, everything behind them to the carry
+            // (window rows up to 31, then this block's own +mu behind the window)
+            const int la = g.la;
+            double *co = g.carry_out + (int64_t)c * kSpecLdc;
+            for (int i = tt; i < kSpecLdc; i += 256) co[i] = bad ? qn : 0.0;
+            __syncthreads();           // (the zeros and the values below come from different threads)
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int pp = 256 * j + tt;
+                const double v = j < 16 ? re[j & 15] : im[j & 15];
+                if (pp < la) OSZ_ZP_PUT(o + pp, bad ? qn : v);
+                else if (!bad && pp - la < kSpecLdc) co[pp - la] = v;
+            }
+            if (!bad) {
+                double Pr[NM], Pi[NM];
+                zp_powers<NM>(ptab, tt, Pr, Pi);
+                for (int r = 0; r < Rf; ++r) {
+                    const int k = 8192 + 256 * r + tt - la;
+                    if (k < kSpecLdc) co[k] = zp_dot<NM>(kapA + (r * NM) * 2, Pr, Pi);
+                }
+            }
+            if (g.hist) {
+                double *hr = g.hist + (int64_t)c * g.hist_len;
+                const double *src = xr + n - g.hist_len;
+                for (int i = tt; i < g.hist_len; i += 256) hr[i] = src[i];
+            }
+        } else {
+            if (own) {
+                if (!bad && !edge && o + L >= n0) {
+                    // the common case: whole rows into the current output
+                    const __amdgpu_buffer_rsrc_t ry = buf_rsrc(yr + (o + L));
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        buf_store(re[j], ry, lane8, 2048u * j);
+                        if (j < NHI - R) buf_store(im[j], ry, lane8, 2048u * (j + 16));
+                    }
+                    if (nst >= 0) nst += NB - R;
+                } else {
+                    nst = -1;
+                    int64_t off = o + tt;
+                    asm volatile("" : "+v"(off));
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        OSZ_ZP_PUT(off + 256 * j, bad ? qn : re[j]);
+                        if (j < NHI - R) OSZ_ZP_PUT(off + 256 * (j + 16), bad ? qn : im[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kSpecRMax; ++r)
+                if (r < R) held[r] = im[(NHI - 1 - r) & 15];
+#pragma unroll
+            for (int j = 0; j < D; ++j) cr[j] = im[NHI + j];
+        }
+        par ^= 1;
+        younger = nst;
+    };
+    for (int p = first; p <= lastf; ++p) block(p, std::false_type{});
+    if (closes) block(lastf + 1, std::true_type{});
+#undef OSZ_ZP_PUT
+    // where the forward stream of this channel first went bad (chain_zp.hip: later launches start
+    // bad, osz_chain_zp_seal settles the chunks the reference loses)
+    if (bad && t == 0) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
+}
+
+template <int NM>
+static zp_kern_t zpn_kernel_nb(int nb) {
+    static const zp_kern_t k[7] = {chain_zpn_kernel<24, NM>, chain_zpn_kernel<25, NM>, chain_zpn_kernel<26, NM>,
+                                   chain_zpn_kernel<27, NM>, chain_zpn_kernel<28, NM>, chain_zpn_kernel<29, NM>,
+                                   chain_zpn_kernel<30, NM>};
+    return k[nb - 24];
+}
+
+zp_kern_t zpn_kernel_for(int nb, int nm) {
+    if (nb < 24 || nb > 30) return nullptr;
+    return nm == 2 ? zpn_kernel_nb<2>(nb) : nm == 4 ? zpn_kernel_nb<4>(nb) : nm == 6 ? zpn_kernel_nb<6>(nb) : nullptr;
+}
+
+}  // namespace osz

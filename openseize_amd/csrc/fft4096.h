@@ -120,6 +120,7 @@ OSZ_HD void inv16(double *re, double *im) {
 struct Tables {
     const double *t1;  // [16][256][2]  W4096^(t k0)  (re, im)
     const double *t2;  // [16][16][2]   W256^(n0 k1)
+    const double *t0 = nullptr;  // [256][2]  W16384^t (the negacyclic transform's per-thread twist, nega below)
 };
 
 // ---- cube layout: interleaved complex, in-place exchanges ------------------
@@ -393,6 +394,161 @@ OSZ_HD void i1(int t, double *re, double *im, const TwPow &w1, const C2 *L) {
 }
 
 }  // namespace cube2
+
+
+// ---- nega: ONE real block of 8192 samples on the 4096-point transform -------------------
+// The pair trick (two real blocks as the real and imaginary part of one complex transform)
+// pays the filter's tail and a guard row once per 4096-sample window.  Here the window is 8192
+// samples of ONE real block and the transform is the DFT at the ODD frequencies
+//   w_k = 2 pi (k + 1/2) / 8192,  k = 0 .. 8191,
+// whose even-numbered half X_{2j} (the odd-numbered half is its conjugate mirror, x being real)
+// is a 4096-point complex transform of
+//   z[n] = (x[n] - i x[n + 4096]) e^{-i pi n / 8192},   n = 0 .. 4095:   X_{2j} = FFT4096(z)[j].
+// No untangling pass: the filter multiplies bin j by its response at 2 pi (j + 1/4) / 4096, and
+//   y[n] - i y[n + 4096] = IFFT4096(Y)[n] e^{+i pi n / 8192}.
+// Multiplication at the odd frequencies is the NEGACYCLIC convolution: what leaves the window on
+// one side comes back on the other with its sign changed -- as good as the cyclic one for
+// overlap-add, where nothing but a cascade's ringing (fitted and removed, chain_zp.hip) wraps.
+// Registers: re[j] = x[256 j + t], im[j] = x[4096 + 256 j + t] (rows 0-15 and 16-31 of the window),
+// the same on the way out.  The twist e^{-i pi n / 8192}, n = 256 j + t, splits into a register
+// part e^{-i pi j / 32} (constants, applied with the packing / unpacking) and a thread part
+// beta = e^{-i pi t / 8192} = W16384^t that rides the pass-1 twiddle: W4096^(t k0) beta =
+// beta^(4 k0 + 1).
+namespace nega {
+
+using cube::C2;
+using cube::cmul;
+using cube::cmulc;
+
+constexpr double kCos[16] = {1.0,
+                             0.995184726672196886244837,
+                             0.9807852804032304491261822,
+                             0.9569403357322088649357979,
+                             0.9238795325112867561281832,
+                             0.8819212643483550297127569,
+                             0.8314696123025452370787884,
+                             0.7730104533627369608109066,
+                             0.7071067811865475244008444,
+                             0.6343932841636454982151716,
+                             0.5555702330196022247428308,
+                             0.4713967368259976485563876,
+                             0.38268343236508977172846,
+                             0.2902846772544623676361924,
+                             0.1950903220161282678482849,
+                             0.09801714032956060199419556};
+constexpr double kSin[16] = {0.0,
+                             0.09801714032956060199419556,
+                             0.1950903220161282678482849,
+                             0.2902846772544623676361924,
+                             0.38268343236508977172846,
+                             0.4713967368259976485563876,
+                             0.5555702330196022247428308,
+                             0.6343932841636454982151716,
+                             0.7071067811865475244008444,
+                             0.7730104533627369608109066,
+                             0.8314696123025452370787884,
+                             0.8819212643483550297127569,
+                             0.9238795325112867561281832,
+                             0.9569403357322088649357979,
+                             0.9807852804032304491261822,
+                             0.995184726672196886244837};
+
+struct TwPowN {
+    double r[5], i[5];   // beta, W, W^2, W^4, W^8 with W = beta^4 = W4096^t
+};
+
+OSZ_HD void tw_load(int t, const Tables &tb, TwPowN &w1, cube::TwPow &w2) {
+    const int n0 = t & 15;
+    w1.r[0] = tb.t0[2 * t];
+    w1.i[0] = tb.t0[2 * t + 1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = 1 << q;
+        w1.r[q + 1] = tb.t1[(k * 256 + t) * 2];
+        w1.i[q + 1] = tb.t1[(k * 256 + t) * 2 + 1];
+        w2.r[q] = tb.t2[(n0 * 16 + k) * 2];
+        w2.i[q] = tb.t2[(n0 * 16 + k) * 2 + 1];
+    }
+}
+
+// register r (bin digit k0 = dr(r) = b + 4 a, b = r >> 2, a = r & 3) times beta^(4 k0 + 1) =
+// (beta W^b) (W^4)^a, or its conjugate
+template <bool CONJ>
+OSZ_HD void tw_mul(double *re, double *im, const TwPowN &w) {
+    double br[4], bi[4], ar[4], ai[4];
+    br[0] = w.r[0]; bi[0] = w.i[0];
+    br[1] = w.r[0] * w.r[1] - w.i[0] * w.i[1]; bi[1] = w.r[0] * w.i[1] + w.i[0] * w.r[1];   // beta W
+    br[2] = w.r[0] * w.r[2] - w.i[0] * w.i[2]; bi[2] = w.r[0] * w.i[2] + w.i[0] * w.r[2];   // beta W^2
+    br[3] = br[1] * w.r[2] - bi[1] * w.i[2];   bi[3] = br[1] * w.i[2] + bi[1] * w.r[2];     // beta W^3
+    ar[1] = w.r[3]; ai[1] = w.i[3];
+    ar[2] = w.r[4]; ai[2] = w.i[4];
+    ar[3] = ar[1] * ar[2] - ai[1] * ai[2]; ai[3] = ar[1] * ai[2] + ai[1] * ar[2];           // W^12
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int b = r >> 2, a = r & 3;
+        if (CONJ) {
+            cmulc(re[r], im[r], br[b], bi[b]);
+            if (a != 0) cmulc(re[r], im[r], ar[a], ai[a]);
+        } else {
+            cmul(re[r], im[r], br[b], bi[b]);
+            if (a != 0) cmul(re[r], im[r], ar[a], ai[a]);
+        }
+    }
+}
+
+// Pack: lo[j] = x[256 j + t], hi[j] = x[4096 + 256 j + t] (in re / im) -> z[256 j + t] without its
+// thread factor.  NHI: rows of the upper half that hold samples (the rest of hi is zero by
+// construction -- the block is shorter than the window).
+template <int NHI>
+OSZ_HD void pack(double *re, double *im) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double a = re[j], b = j < NHI ? im[j] : 0.0;
+        if (j == 0) {
+            im[j] = -b;
+        } else if (j < NHI) {
+            re[j] = a * kCos[j] - b * kSin[j];
+            im[j] = -(a * kSin[j]) - b * kCos[j];
+        } else {
+            re[j] = a * kCos[j];
+            im[j] = -(a * kSin[j]);
+        }
+    }
+}
+
+// Unpack: v = w e^{+i pi j / 32}; y[256 j + t] = Re v (re), y[4096 + 256 j + t] = -Im v (im)
+OSZ_HD void unpack(double *re, double *im) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+        const double a = re[j], b = im[j];
+        re[j] = a * kCos[j] - b * kSin[j];
+        im[j] = -(a * kSin[j]) - b * kCos[j];
+    }
+    im[0] = -im[0];
+}
+
+template <int NHI>
+OSZ_HD void f1(int t, double *re, double *im, const TwPowN &w1, C2 *L) {
+    pack<NHI>(re, im);
+    fwd16(re, im);
+    tw_mul<false>(re, im, w1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L[cube2::slot_a(t, dr(r))] = C2{re[r], im[r]};
+}
+
+OSZ_HD void i1(int t, double *re, double *im, const TwPowN &w1, const C2 *L) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const C2 v = L[cube2::slot_a(t, dr(r))];
+        re[r] = v.re;
+        im[r] = v.im;
+    }
+    tw_mul<true>(re, im, w1);
+    inv16(re, im);
+    unpack(re, im);
+}
+
+}  // namespace nega
 
 }  // namespace fft
 }  // namespace osz

@@ -200,7 +200,7 @@ __global__ void fir_flush_kernel(FlushArgs a) {
 // Twiddle tables on the device: one set per device, built on first use and
 // kept for the life of the process.
 struct FftTablesDev {
-    double *t1 = nullptr, *t2 = nullptr;
+    double *t1 = nullptr, *t2 = nullptr, *t0 = nullptr;
 };
 
 int get_fft_tables(fft::Tables &out) {
@@ -212,7 +212,12 @@ int get_fft_tables(fft::Tables &out) {
     FftTablesDev &tabs = per_device[dev];
     if (tabs.t1 == nullptr) {
         const long double PI = acosl(-1.0L);
-        std::vector<double> t1(16 * 256 * 2), t2(16 * 16 * 2);
+        std::vector<double> t1(16 * 256 * 2), t2(16 * 16 * 2), t0(256 * 2);
+        for (int t = 0; t < 256; ++t) {          // W16384^t: the thread part of fft::nega's twist
+            const long double ang = -PI * (long double)t / 8192.0L;
+            t0[2 * t] = (double)cosl(ang);
+            t0[2 * t + 1] = (double)sinl(ang);
+        }
         for (int k0 = 0; k0 < 16; ++k0)
             for (int t = 0; t < 256; ++t) {
                 const long double ang = -2.0L * PI * (long double)(t * k0) / 4096.0L;
@@ -229,9 +234,12 @@ int get_fft_tables(fft::Tables &out) {
         OSZ_HIP(hipMalloc(&tabs.t2, t2.size() * sizeof(double)));
         OSZ_HIP(hipMemcpy(tabs.t1, t1.data(), t1.size() * sizeof(double), hipMemcpyHostToDevice));
         OSZ_HIP(hipMemcpy(tabs.t2, t2.data(), t2.size() * sizeof(double), hipMemcpyHostToDevice));
+        OSZ_HIP(hipMalloc(&tabs.t0, t0.size() * sizeof(double)));
+        OSZ_HIP(hipMemcpy(tabs.t0, t0.data(), t0.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     out.t1 = tabs.t1;
     out.t2 = tabs.t2;
+    out.t0 = tabs.t0;
     return OSZ_OK;
 }
 

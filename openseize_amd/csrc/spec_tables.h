@@ -483,5 +483,183 @@ inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int ns
     return T;
 }
 
+
+// ---- the two-sided scheme on ONE real block per transform (chain_zpn.hip) ---------------
+// fft::nega (fft4096.h) takes a window of 8192 samples through the 4096-point transform at the
+// odd frequencies: the filter's tail (wlen - 1 samples) and the guard row are paid once per
+// 8192 instead of once per 4096 samples -- a block is NB <= 27 rows of 256 at 1024 taps where
+// the pair trick has 2 x 11 -- and the fit and the bursts are one block's, not two.  What
+// changes in the tables:
+//   NB    rows per block: the largest with 256 NB + wlen - 1 <= 7936 (row 31 holds nothing but
+//         ringing) whose guard rows hold the bursts (R <= D = 32 - NB, D + Rf <= NB); 24 .. 30
+//   H     [4096][2]  the zero-phase composite response at 2 pi (j + 1/4) / 4096, / 4096
+//   M     as above, fitted on row 31; the wrap is NEGACYCLIC, so what sits at the window's end
+//         is MINUS the left tail: the nu rows carry the sign, the kernel sees true amplitudes
+//         and ADDS its in-window corrections
+inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int nsec, bool forgets,
+                          int lds_budget = 15360) {
+    TablesZp T;
+    constexpr int kM = 8192;
+    if (wlen < 2 || !forgets) return T;
+    std::vector<Mode> modes;
+    for (int q = 0; q < nsec; ++q) {
+        const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+        if (a1 == 0.0L && a2 == 0.0L) continue;
+        if (a2 == 0.0L) {
+            modes.push_back({-a1, 0.0L, true});
+            continue;
+        }
+        const ld_t disc = a1 * a1 - 4.0L * a2;
+        if (disc < 0.0L) {
+            modes.push_back({-a1 / 2, sqrtl(-disc) / 2, false});
+        } else if (disc > 0.0L) {
+            modes.push_back({(-a1 + sqrtl(disc)) / 2, 0.0L, true});
+            modes.push_back({(-a1 - sqrtl(disc)) / 2, 0.0L, true});
+        } else {
+            return T;
+        }
+    }
+    const int nm = (int)modes.size();
+    if (nm < 1 || nm > 6) return T;
+    for (auto &m : modes)
+        if (!(m.re * m.re + m.im * m.im < 1.0L)) return T;
+    const int NM = (nm + 1) & ~1;
+    const int Lg = kM + 256 * 17;
+    std::vector<ld_t> g2(2 * Lg, 0.0L);
+    for (int i = 0; i < wlen && i < Lg; ++i) g2[Lg + i] = taps[i];
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int q = 0; q < nsec; ++q) {
+            const ld_t b0 = sos[6 * q], b1 = sos[6 * q + 1], b2 = sos[6 * q + 2];
+            const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+            ld_t z0 = 0.0L, z1 = 0.0L;
+            for (int i = 0; i < 2 * Lg; ++i) {
+                const int idx = pass == 0 ? i : 2 * Lg - 1 - i;
+                const ld_t xin = g2[idx], y = b0 * xin + z0;
+                z0 = b1 * xin - a1 * y + z1;
+                z1 = b2 * xin - a2 * y;
+                g2[idx] = y;
+            }
+        }
+    }
+    std::vector<ld_t> right2(2 * Lg + 1, 0.0L), left2(2 * Lg + 1, 0.0L);
+    for (int i = 2 * Lg - 1; i >= 0; --i) right2[i] = right2[i + 1] + g2[i] * g2[i];
+    for (int i = 0; i < 2 * Lg; ++i) left2[i + 1] = left2[i] + g2[i] * g2[i];
+    const ld_t tot = sqrtl(right2[0]);
+    int NBmax = (7937 - wlen) / 256;
+    if (NBmax > 30) NBmax = 30;
+    int NB = 0, R = 0, Rf = 0;
+    for (int cand = NBmax; cand >= 24 && !NB; --cand) {
+        const int S = 256 * cand, D = 32 - cand;
+        int rb = 0, rf = 0;
+        for (int r = 1; r <= kRMax && !(rb && rf); ++r) {
+            const int ir = Lg + kM + 256 * r - S + 1, il = Lg - 256 * r;
+            if (ir >= 2 * Lg || il < 0) break;
+            if (!rf && sqrtl(right2[ir]) <= kTailTol * tot) rf = r;
+            if (!rb && sqrtl(left2[il]) <= kTailTol * tot) rb = r;
+        }
+        if (rb && rf && rf <= rb && rb <= D && D + rf <= cand) {
+            NB = cand;
+            R = rb;
+            Rf = rf;
+        }
+    }
+    if (!NB) return T;
+    // LDS behind the cube: fit samples [2 nh], kappa: this block's mu, nu [2][R][NM][2], the
+    // previous block's mu [2 parity][R][NM][2], L [R][NM][2], P [20][NM][2], M [4 NM][2 nh]
+    int nh = 0;
+    for (int cand = 32; cand >= 16 && !nh; cand -= 8) {
+        const int bytes = 8 * (2 * cand + 4 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * 2 * cand);
+        if (bytes <= lds_budget) nh = cand;
+    }
+    if (!nh) return T;
+    const int ns = 2 * nh;
+    std::vector<int> col_mode, col_kind;
+    for (int side = 0; side < 2; ++side)
+        for (int q = 0; q < nm; ++q) {
+            col_mode.push_back(q);
+            col_kind.push_back(2 * side);
+            if (!modes[q].real) {
+                col_mode.push_back(q);
+                col_kind.push_back(2 * side + 1);
+            }
+        }
+    const int nd = (int)col_mode.size();
+    std::vector<ld_t> B((size_t)ns * nd);
+    for (int j = 0; j < nd; ++j)
+        for (int i = 0; i < ns; ++i) {
+            const int l = i < nh ? i : 256 - ns + i;
+            ld_t pr, pi;
+            mode_pow(modes[col_mode[j]], col_kind[j] < 2 ? l : 255 - l, pr, pi);
+            B[(size_t)j * ns + i] = (col_kind[j] & 1) ? -pi : pr;
+        }
+    std::vector<ld_t> Pinv;
+    const ld_t ratio = pinv_qr(B, ns, nd, Pinv);
+    T.fit_ratio = (double)ratio;
+    if (!(ratio > 1e-3L)) return T;
+    T.M.assign((size_t)4 * NM * ns, 0.0);
+    for (int side = 0; side < 2; ++side)
+        for (int q = 0; q < nm; ++q) {
+            int ja = -1, jb = -1;
+            for (int j = 0; j < nd; ++j)
+                if (col_mode[j] == q && col_kind[j] / 2 == side) ((col_kind[j] & 1) ? jb : ja) = j;
+            ld_t cr = -1.0L, ci = 0.0L;                           // nu = -(what the window's end shows)
+            if (side == 0) mode_pow(modes[q], 256, cr, ci);       // mu = gamma lambda^256
+            for (int i = 0; i < ns; ++i) {
+                const ld_t av = Pinv[(size_t)ja * ns + i];
+                const ld_t bv = jb >= 0 ? Pinv[(size_t)jb * ns + i] : 0.0L;
+                T.M[(size_t)((2 * side) * NM + q) * ns + i] = (double)(cr * av - ci * bv);
+                T.M[(size_t)((2 * side + 1) * NM + q) * ns + i] = (double)(ci * av + cr * bv);
+            }
+        }
+    // the composite response at the quarter-shifted bins, / 4096: taps by Horner in z^-1
+    const ld_t PI = acosl(-1.0L);
+    T.H.assign(2 * kN, 0.0);
+    for (int k = 0; k < kN; ++k) {
+        const ld_t ang = -2.0L * PI * ((ld_t)k + 0.25L) / (ld_t)kN;
+        const ld_t zr = cosl(ang), zi = sinl(ang);          // z^-1
+        const ld_t z2r = zr * zr - zi * zi, z2i = 2.0L * zr * zi;
+        ld_t fr = 0.0L, fi = 0.0L;
+        for (int n = wlen - 1; n >= 0; --n) {
+            const ld_t x = fr * zr - fi * zi + (ld_t)taps[n], y = fr * zi + fi * zr;
+            fr = x;
+            fi = y;
+        }
+        ld_t gain = 1.0L;
+        for (int q = 0; q < nsec; ++q) {
+            const ld_t b0 = sos[6 * q], b1 = sos[6 * q + 1], b2 = sos[6 * q + 2];
+            const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+            const ld_t nr = b0 + b1 * zr + b2 * z2r, ni = b1 * zi + b2 * z2i;
+            const ld_t dr = 1.0L + a1 * zr + a2 * z2r, di = a1 * zi + a2 * z2i;
+            gain *= (nr * nr + ni * ni) / (dr * dr + di * di);
+        }
+        T.H[2 * k] = (double)(fr / kN * gain);
+        T.H[2 * k + 1] = (double)(fi / kN * gain);
+    }
+    T.P.assign((size_t)20 * NM * 2, 0.0);
+    T.L.assign((size_t)kRMax * NM * 2, 0.0);
+    for (int q = 0; q < nm; ++q) {
+        for (int i = 0; i < 20; ++i) {
+            ld_t pr, pi;
+            mode_pow(modes[q], i < 8 ? 32 * i : i < 16 ? 4 * (i - 8) : i - 16, pr, pi);
+            T.P[((size_t)i * NM + q) * 2 + 0] = (double)pr;
+            T.P[((size_t)i * NM + q) * 2 + 1] = (double)pi;
+        }
+        for (int r = 0; r < kRMax; ++r) {
+            ld_t pr, pi;
+            mode_pow(modes[q], 256 * r, pr, pi);
+            T.L[((size_t)r * NM + q) * 2 + 0] = (double)pr;
+            T.L[((size_t)r * NM + q) * 2 + 1] = (double)pi;
+        }
+    }
+    T.NR = NB;
+    T.NM = NM;
+    T.nm = nm;
+    T.R = R;
+    T.Rf = Rf;
+    T.nh = nh;
+    T.eligible = true;
+    return T;
+}
+
 }  // namespace spec
 }  // namespace osz

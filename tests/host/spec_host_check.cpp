@@ -1,11 +1,14 @@
 // Builds the host tables of the spectral FIR -> cascade kernel (csrc/spec_tables.h)
 // with g++ and writes them out for tests/test_spec_host.py.
-//   spec_host_check <in.bin> <out.bin> [zp]      (zp: the two-sided tables of chain_zp.hip)
+//   spec_host_check <in.bin> <out.bin> [zp|zpn]  (zp: the two-sided tables of chain_zp.hip;
+//                                                  zpn: those of chain_zpn.hip, one real block per transform)
 // in:  int32 wlen, int32 nsec, int32 forgets, double taps[wlen], double sos[nsec][6]
 // out: int32 eligible, NR, NM, nm, R, double fit_ratio, then H, M, P, L (each: int64 count, doubles)
 #include <cstdint>
 #include <cstdio>
 #include <vector>
+
+#include <cstring>
 
 #include "spec_tables.h"
 
@@ -20,7 +23,9 @@ int main(int argc, char **argv) {
     if (fread(sos.data(), sizeof(double), sos.size(), f) != sos.size()) return 2;
     fclose(f);
     if (argc == 4) {
-        const osz::spec::TablesZp T = osz::spec::build_zp(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0);
+        const osz::spec::TablesZp T = !strcmp(argv[3], "zpn")
+                                          ? osz::spec::build_zpn(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0)
+                                          : osz::spec::build_zp(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0);
         f = fopen(argv[2], "wb");
         if (!f) return 2;
         const int32_t out[8] = {T.eligible, T.NR, T.NM, T.nm, T.R, T.nh, T.Rf, 0};

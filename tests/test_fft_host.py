@@ -32,6 +32,19 @@ def test_fft4096_cube2_host_replay():
     assert "exchange 2 row-local: yes" in out.stdout and "OK" in out.stdout
 
 
+def test_fft4096_nega_host_replay():
+    """fft::nega: one real block of 8192 samples on the 4096-point transform at the odd
+    frequencies (the zero-phase chain kernel of chain_zpn.hip): forward against a direct DFT at
+    2 pi (2 j + 1/2) / 8192, a filter applied bin by bin against the negacyclic convolution."""
+    src = os.path.join(ROOT, "tests", "host", "fft_nega_check.cpp")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "fft_nega_check")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK" in out.stdout
+
+
 def test_fft8_host_replay():
     """fft8.h (N = 512 ... 8192, 8 points per thread): forward against a naive
     long-double DFT, inverse(forward) = N x, the digit-reversal map, the LDS

@@ -72,10 +72,12 @@ def run_stream(dev, x, h, sos, lens, split=False):
 
 
 CASES = [
-    # taps, cascade, channels, chunk lengths (S = 2816 for 1024 taps)
-    (1024, BP, 5, [2 * 2816 * 6 + 1024, 2 * 2816 * 4, 2 * 2816 * 3 + 2816 + 17, 2 * 2816 * 2 + 5,
-                   2 * 2816 * 4 - 1, 2 * 2816 * 3 + 300]),
-    (1024, BP, 256, [2 * 2816 * 30 + 777] * 3),
+    # taps, cascade, channels, chunk lengths (u: what the kernel transforms at once -- a block of
+    # 27 rows = 6912 samples at 1024 taps, a pair of 2 x 2816 on the pair kernel -- = half the
+    # shortest chunk a step takes)
+    (1024, BP, 5, lambda u: [u * 6 + 1024, u * 4, u * 3 + u // 2 + 17, u * 2 + 5, u * 4 - 1, u * 3 + 300, 2 * u,
+                             3 * u + 1]),
+    (1024, BP, 256, lambda u: [u * 30 + 777] * 3),
     (1024, BP, 64, [1 << 18] * 3),
     (300, BP, 7, [150000, 150000, 90001]),
     (513, sps.butter(5, 0.3, output="sos"), 3, [100000] * 3),
@@ -89,6 +91,13 @@ CASES = [
 def test_zero_phase_stream_against_scipy(dev, case, split):
     taps_n, sos, C, lens = CASES[case]
     h = sps.firwin(taps_n, 0.2)
+    if callable(lens):
+        fir, iir = dev.FirStream(h, 1), dev.SosStream(sos, 1)
+        try:
+            lens = lens(dev.chain_zp_min_chunk(fir, iir) // 2)
+        finally:
+            fir.close()
+            iir.close()
     total = sum(lens)
     x = dev.synth_normal(C, total, seed=3 + case)
     got, lag = run_stream(dev, x, h, sos, lens, split)

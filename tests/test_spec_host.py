@@ -202,7 +202,7 @@ def test_what_the_scheme_does_not_take(exe):
 
 
 # ------------------------------------------------------------------ the two-sided scheme
-def tables_zp(exe, taps, sos, forgets=True):
+def tables_zp(exe, taps, sos, forgets=True, mode="zp"):
     taps, sos = np.asarray(taps, np.float64), np.atleast_2d(np.asarray(sos, np.float64))
     with tempfile.TemporaryDirectory() as tmp:
         fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
@@ -210,7 +210,7 @@ def tables_zp(exe, taps, sos, forgets=True):
             f.write(struct.pack("<iii", len(taps), len(sos), int(forgets)))
             f.write(taps.tobytes())
             f.write(sos.tobytes())
-        subprocess.check_call([exe, fin, fout, "zp"])
+        subprocess.check_call([exe, fin, fout, mode])
         raw = open(fout, "rb").read()
     elig, NR, NM, nm, R, nh, Rf, _ = struct.unpack_from("<iiiiiiii", raw, 0)
     ratio, = struct.unpack_from("<d", raw, 32)
@@ -393,3 +393,168 @@ def test_zero_phase_tables_and_block_algorithm(exe, name, ntaps, sos):
     got = np.concatenate(out)                     # got[q] is stream sample q - L
     assert np.isfinite(got).all()
     assert np.max(np.abs(got[L:] - ref[:len(got) - L])) < 1e-12 * np.max(np.abs(ref)), name
+
+
+# ------------------------------------------------- one real block per transform (chain_zpn.hip)
+MW = 8192
+
+
+class ModelZpn:
+    """The dataflow of chain_zpn_kernel on one channel with the tables of the C++ build: a window
+    of 8192 samples per block through the 4096-point transform at the odd frequencies (fft::nega:
+    negacyclic wrap), the fit on row 31, the in-window corrections ADDED (the wrap changes the
+    sign), the right tail's continuation from the previous block's amplitudes, the last R rows
+    of a block held back until the next block has been fitted, runs that start one block early,
+    the opening block (carry, held samples of the previous chunk), the generic closing block
+    (window in an accumulator of 8192, the burst behind it straight into the carry), outputs
+    delayed by L = 256 R samples."""
+
+    def __init__(self, T):
+        self.NB, self.NM, self.R, self.Rf, self.nh = T["NR"], T["NM"], T["R"], T["Rf"], T["nh"]
+        self.S, self.D, self.L = 256 * self.NB, 32 - self.NB, 256 * T["R"]
+        H = T["H"].reshape(N, 2)
+        self.Hq = (H[:, 0] + 1j * H[:, 1]) * N
+        M = T["M"].reshape(4 * self.NM, 2 * self.nh)
+        self.Mmu = M[:self.NM] + 1j * M[self.NM:2 * self.NM]
+        self.Mnu = M[2 * self.NM:3 * self.NM] + 1j * M[3 * self.NM:]
+        P = T["P"].reshape(20, self.NM, 2)
+        P = P[..., 0] + 1j * P[..., 1]
+        t = np.arange(256)
+        self.P = P[t >> 5] * P[8 + ((t >> 2) & 7)] * P[16 + (t & 3)]
+        Lr = T["L"].reshape(5, self.NM, 2)
+        self.Lr = Lr[..., 0] + 1j * Lr[..., 1]
+        self.lsel = np.concatenate([np.arange(self.nh), np.arange(256 - self.nh, 256)])
+        self.tw = np.exp(-1j * np.pi * np.arange(N) / MW)
+
+    def window(self, x):
+        buf = np.zeros(MW)
+        buf[:len(x)] = x
+        z = (buf[:N] - 1j * buf[N:]) * self.tw
+        w = np.fft.ifft(np.fft.fft(z) * self.Hq) * np.conj(self.tw)
+        return np.concatenate([w.real, -w.imag])
+
+    def fit(self, win):
+        y = win[MW - 256 + self.lsel]
+        return self.Mmu @ y, self.Mnu @ y
+
+    def burst(self, amp, e, rows):
+        ok = (e >= 0) & (e < 256 * rows)
+        ee = np.where(ok, e, 0)
+        return np.where(ok, np.real((self.Lr[ee >> 8] * self.P[ee & 255]) @ amp), 0.0)
+
+    def chunk(self, x, carry_in, held_in, nruns):
+        n, S, NB, D, R, L, Rf = len(x), self.S, self.NB, self.D, self.R, self.L, self.Rf
+        W = (n - 1) // S                       # whole blocks; the closing block has 1 .. S samples
+        assert W >= 1
+        lc = n - W * S
+        y, held_out = np.full(n, np.nan), np.full(L, np.nan)
+        t = np.arange(256)
+
+        def put(i, v):
+            q = i + L
+            m = q < n
+            y[q[m]] = v[m]
+            m2 = (~m) & (i < n)
+            held_out[q[m2] - n] = v[m2]
+
+        F = lambda amp, r: self.burst(amp, 256 * r + t, Rf)
+        Bk = lambda amp, r: self.burst(amp, 256 * r + 255 - t, R)
+        nruns = max(1, min(nruns, W))
+        carry_out = None
+        for run in range(nruns):
+            p0, p1 = run * W // nruns, (run + 1) * W // nruns
+            first, lastf = (p0 if run == 0 else p0 - 1), p1 - 1
+            cr = np.zeros((D, 256))
+            mu_p = np.zeros(self.NM, complex)
+            held = None
+            for p in range(first, lastf + 1):
+                o = p * S
+                win = self.window(x[o:o + S])
+                mu, nu = self.fit(win)
+                Y = win.reshape(32, 256).copy()
+                for r in range(Rf):
+                    Y[r] += F(mu, r)                # the wrapped right tail (sign changed) leaves the window
+                for r in range(R):
+                    Y[31 - r] += Bk(nu, r)          # and the wrapped left tail
+                A = Y[:NB].copy()
+                A[:D] += cr
+                cr = Y[NB:].copy()
+                for r in range(Rf):
+                    A[D + r] += F(mu_p, r)          # the previous block's right tail continues here
+                if p == 0:
+                    ci = np.zeros(S)
+                    m = min(len(carry_in), S)
+                    ci[:m] = carry_in[:m]
+                    A += ci.reshape(NB, 256)
+                if held is not None:
+                    for r in range(R):
+                        held[r] += Bk(nu, r)
+                        put((p - 1) * S + 256 * (NB - 1 - r) + t, held[r])
+                elif p == 0:
+                    for rr in range(R):
+                        y[256 * rr + t] = held_in[256 * rr + t] + Bk(nu, R - 1 - rr)
+                if p0 <= p < p1:
+                    for j in range(NB - R):
+                        put(o + 256 * j + t, A[j])
+                held = [A[NB - 1 - r].copy() for r in range(R)]
+                mu_p = mu
+            if run == nruns - 1:
+                o, la = W * S, lc
+                win = self.window(x[o:o + la])
+                mu, nu = self.fit(win)
+                for r in range(R):
+                    held[r] += Bk(nu, r)
+                    put((W - 1) * S + 256 * (NB - 1 - r) + t, held[r])
+                i = np.arange(MW)
+                acc = win.copy()
+                acc[:256 * D] += cr.ravel()
+                acc += self.burst(mu_p, i - 256 * D, Rf)
+                acc += self.burst(mu, i, Rf)
+                acc += self.burst(nu, MW - 1 - i, R)
+                put(o + i[:lc], acc[:lc])
+                k = np.arange(7680)
+                src = lc + k
+                carry_out = np.where(src < MW, acc[np.minimum(src, MW - 1)], self.burst(mu, src - MW, Rf))
+        return y, carry_out, held_out
+
+
+ZPN_CASES = ZP_CASES + [
+    ("the identity as the FIR (plain sosfiltfilt)", 2, sps.butter(6, [0.05, 0.3], "bandpass", output="sos")),
+    ("cheby1 low-pass, 57 taps", 57, sps.cheby1(5, 1, 0.2, output="sos")),
+]
+
+
+@pytest.mark.parametrize("name,ntaps,sos", ZPN_CASES, ids=[c[0] for c in ZPN_CASES])
+def test_single_block_tables_and_block_algorithm(exe, name, ntaps, sos):
+    """The same chain with ONE real block of 8192 samples per transform (odd frequencies,
+    negacyclic wrap): tables of spec::build_zpn through the NumPy restatement of
+    chain_zpn_kernel against scipy, every kind of chunk."""
+    taps = sps.firwin(ntaps, 0.2) if ntaps > 2 else np.array([1.0, 0.0])
+    T = tables_zp(exe, taps, sos, mode="zpn")
+    assert T["eligible"], name
+    NB, R, Rf = T["NR"], T["R"], T["Rf"]
+    assert 24 <= NB <= min((7937 - ntaps) // 256, 30) and 1 <= Rf <= R <= min(32 - NB, 5) and 32 - NB + Rf <= NB
+    wq = 2 * np.pi * (np.arange(N) + 0.25) / N
+    _, h = sps.sosfreqz(sos, worN=wq)
+    Hq = np.polyval(taps[::-1], np.exp(-1j * wq)) * np.abs(h) ** 2 / N
+    H = T["H"].reshape(N, 2)
+    assert np.max(np.abs(H[:, 0] + 1j * H[:, 1] - Hq)) < 1e-12 * np.max(np.abs(Hq))   # (NumPy's polyval is the weak side)
+    m = ModelZpn(T)
+    S, L = m.S, m.L
+    rng = np.random.default_rng(ntaps)
+    lens = [S * 5 + 1024, S * 4, S * 3 + S - 17, S + 5, S * 3 + S, S * 3 + 300, 2 * S]
+    x = rng.standard_normal(sum(lens))
+    u = np.convolve(x, taps)
+    zi0 = sps.sosfilt_zi(sos) * u[0]
+    f, _ = sps.sosfilt(sos, u, zi=zi0)
+    ref = sps.sosfilt(sos, np.concatenate([f, np.zeros(8192)])[::-1])[::-1][:len(f)]
+    zir = sps.sosfilt(sos, np.zeros(7680), zi=zi0)[0]
+    carry, held = sps.sosfilt(sos, zir[::-1])[::-1], np.zeros(L)
+    out, o = [], 0
+    for k, n in enumerate(lens):
+        y, carry, held = m.chunk(x[o:o + n], carry, held, nruns=[1, 2, 3, 1, 2, 2, 1][k])
+        out.append(y)
+        o += n
+    got = np.concatenate(out)
+    assert np.isfinite(got).all()
+    assert np.max(np.abs(got[L:] - ref[:len(got) - L])) < 3e-12 * np.max(np.abs(ref)), name
