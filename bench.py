@@ -5,10 +5,20 @@ Default workload `chain` (BASELINE.json configs[2], the configuration the
 metric is quoted on): 256 channels x float64, chunksize 2^20, 1024-tap FIR
 overlap-add (`firwin(1024, 0.2)`) chained into a 6-section Butterworth
 band-pass `sosfiltfilt` (`butter(6, [0.05, 0.3], 'bandpass')`).  A "step" is one
-chunk (256 x 2^20 channel-samples) through the whole chain in steady state:
+chunk (256 x 2^20 channel-samples) through the whole chain in steady state, and it is
+ONE kernel:
 
-    FIR push(chunk k) -> [SOS forward(chunk k) + SOS backward(chunk k-2;
-    chunk-local warm-up over forward chunk k-1)] in one launch
+    osz_chain_zp_step(chunk k): FIR, forward and backward cascade as one multiplication per
+    bin of the FIR's own transform, plus the cascade's mode bursts (csrc/chain_zpn.hip: one
+    real block of 27 rows x 256 samples per 4096-point transform at the odd frequencies);
+    the stream runs `lag` samples late, the step writes the tail of output chunk k-1 and the
+    head of chunk k; osz_chain_zp_seal(chunk k-2) (NaN reach of sosfiltfilt) is in the step.
+
+`--two-kernel`, `--fused`, `--unfused` time the older sequences (rounds 2 and 1).
+`roofline` prices the kernel by what the fused operation must move -- 8 B read + 8 B written
+per channel-sample -- over its measured duration: `frac` is a physical fraction of the HBM
+peak (<= 1); the 48 B per sample the unfused chain would move (FIR 16 +
+sosfiltfilt 32) appear only as `unfused_equivalent_*`.
 
 Inputs are synthesised on the device before the timed region (a ring of
 resident chunks keyed by (seed, channel, sample)); outputs land in a resident
@@ -60,8 +70,10 @@ RAGGED = 100_000_000 - 95 * CHUNK     # last chunk of the literal 1e8-sample str
 # (chain_fwd = FIR + forward sosfilt in one kernel: 16 + 16 of them; chain_step = that kernel
 # and the backward pass of an earlier chunk side by side on two streams, one osz_chain_step:
 # the whole 48 B of the chain.  What these launches really move is roofline.traffic.)
+# chain_zp: ONE kernel for the whole chain -- it must read a sample and write a sample, 16 B;
+# the 48 B the unfused chain would move are reported apart (unfused_equivalent_*).
 KERNEL_BYTES = {"fir_oa": 16, "sos_dual": 32, "sos_fwd": 16, "sos_bwd": 16, "sos_fwd_split": 16,
-                "sos_bwd_split": 16, "chain_fwd": 32, "chain_step": 48, "chain_zp": 48, "sos_warmup": 0,
+                "sos_bwd_split": 16, "chain_fwd": 32, "chain_step": 48, "chain_zp": 16, "sos_warmup": 0,
                 "fir_seam": 0, "spec_fused": 8, "poly_block": 9.6}
 CHAIN_BYTES = 48         # FIR 16 + sosfiltfilt 32 (the unfused accounting of the metric)
 METRIC = "Msamples/sec/node (FIR+IIR chain, 256ch f64); HBM GB/s vs roofline at 1/2/4/8 GPU"
@@ -101,14 +113,24 @@ def _cpu_stft_worker(args):
 def cpu_baseline(workload, h, sos):
     """The CPU oracle (oracle/: NumPy FFT overlap-add + C DF2T loops; NumPy
     windowed rFFT for Welch) on a bounded sample of the same workload: once on
-    one core, once with one process per available core (at most 16) over
-    channel shards.  Runs BEFORE the GPU is initialised (workers are forked)."""
+    one core, once with one process per core this process may run on
+    (os.sched_getaffinity; fewer only if the host's free memory does not hold
+    that many workers, and the line says so) over channel shards.  Runs BEFORE
+    the GPU is initialised (workers are forked)."""
     import multiprocessing as mp
     from oracle import oracle as orc
     orc.build()
     ch, n = 16, 1 << 21
     avail = len(os.sched_getaffinity(0))
-    procs = max(1, min(16, avail))
+    procs, capped = max(1, avail), ""
+    try:
+        import psutil
+        per_worker = 10 * ch * n * 8            # input, FIR pieces, forward / backward copies
+        fit = int(0.5 * psutil.virtual_memory().available // per_worker)
+        if fit < procs:
+            procs, capped = max(1, fit), f" (memory holds {max(1, fit)} workers of {per_worker >> 20} MiB)"
+    except ImportError:
+        pass
     if workload == "welch":
         worker, work = _cpu_welch_worker, lambda seed: (ch, n, seed)
         what = "Welch PSD nfft 4096, 50 % overlap"
@@ -135,7 +157,7 @@ def cpu_baseline(workload, h, sos):
             "single_core_value": value_1,
             "sample": f"{procs} processes x ({ch} ch x 2^21 samples), same {what}, "
                       f"{wall:.1f} s wall; 1 core alone: {value_1:.1f} Msamples/s; "
-                      f"host exposes {avail} cores"}
+                      f"this process may run on {avail} cores{capped}"}
 
 
 # ------------------------------------------------------------------- launcher
@@ -275,8 +297,16 @@ def roofline_of(kernels, samples_per_step):
         # what the launch really moves against the peak, beside the algorithmic `frac`
         out["frac_physical"] = traffic / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
     if dom == "chain_zp":
-        out["kernel"] = ("chain_zp (FIR, forward and backward cascade as one spectrum multiply: the chain's 48 "
-                         "algorithmic B per sample, 16 of them moved)")
+        out["kernel"] = ("chain_zp (FIR, forward and backward cascade as one spectrum multiply: 8 B read + 8 B "
+                         "written per channel-sample)")
+        # what the three passes of the unfused chain would have had to move in the same time
+        # (SURVEY 8d's 48 B per sample): a rate of work done, not of bytes moved -- may exceed 1
+        ueq = CHAIN_BYTES * samples_per_step / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        out["unfused_equivalent_gbps"] = ueq
+        out["unfused_equivalent_frac"] = ueq / HBM_PEAK_GBPS
+        # the limiter is not HBM: vector issue + LDS latency at two waves per SIMD;
+        # `bound` names the roofline the kernel's bytes are priced against
+        out["limiter"] = "vector issue / LDS latency at 2 waves per SIMD, not HBM (profiles/r04_pmc_bench.json)"
     if dom == "chain_step":
         # two kernels side by side under one call: the duration is that of the pair
         # (HIP events on the caller's stream around osz_chain_step), the bytes are the
@@ -781,10 +811,12 @@ def main():
                    "fir_taps": NTAPS, "sos_sections": int(sos.shape[0]),
                    "parallelism": parallelism},
         "rccl_ranks": R.ranks_seen(),
-        "chain_hbm_gbps": value * 1e6 * bytes_per_sample / 1e9 / R.world,
-        "chain_hbm_frac": value * 1e6 * bytes_per_sample / 1e9 / R.world / HBM_PEAK_GBPS,
         "roofline": roofline, "kernels": kernels,
     }
+    # whole-job rate by the accounting of the workload (chain: SURVEY 8d's 48 B per sample for
+    # the UNFUSED passes -- a measure of work, not of bytes the fused step moves)
+    key = "unfused_equivalent_hbm_gbps" if args.workload == "chain" else "algorithmic_hbm_gbps"
+    out[key] = value * 1e6 * bytes_per_sample / 1e9 / R.world
     if args.dry:
         out["dry"] = True
     if extra:

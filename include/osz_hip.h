@@ -229,7 +229,12 @@ int osz_chain_wait(osz_sos_t sos, void *stream);
  *                           of filters does not take this kernel (poles that repeat,
  *                           ringing longer than the transform's guard rows, FIR longer
  *                           than 1793 taps or partitioned)
- *   osz_chain_zp_min_chunk  shortest chunk osz_chain_zp_step takes (two pairs of blocks)
+ *   osz_chain_zp_tolerance  where the bursts are cut, relative to the norm of the composite
+ *                           impulse response (0: the default, 1e-12; before osz_chain_zp_lag /
+ *                           _open).  What is cut off scales with the INPUT: a stream whose
+ *                           offset is 10^4 times its in-band signal wants 1e-15 (one more burst
+ *                           row each way, +2 % time) to stay at 1e-10 of its output.
+ *   osz_chain_zp_min_chunk  shortest chunk osz_chain_zp_step takes (two blocks)
  *   osz_chain_zp_open       starts a stream at sample 0: the FIR's overlap tail must be
  *                           zero; the forward cascade starts from the state on the SOS
  *                           handle (osz_sos_set_state*) at stream sample `skip` -- the
@@ -259,6 +264,7 @@ int osz_chain_wait(osz_sos_t sos, void *stream);
  *                           samples is not what the continued stream would have there)
  */
 int64_t osz_chain_zp_lag(osz_fir_t fir, osz_sos_t sos);
+int osz_chain_zp_tolerance(osz_fir_t fir, osz_sos_t sos, double tol);
 int64_t osz_chain_zp_min_chunk(osz_fir_t fir, osz_sos_t sos);
 int osz_chain_zp_open(osz_fir_t fir, osz_sos_t sos, int64_t skip, void *stream);
 int osz_chain_zp_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,

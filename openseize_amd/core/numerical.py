@@ -330,6 +330,7 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
             device = first.device if resident else "cuda"
             pipe = None if resident else dev.HostPipe(layout)
             flying = deque()
+            dev.chain_zp_tolerance(fir, iir, dev.zp_tolerance_for(first, axis))
             lag = dev.chain_zp_lag(fir, iir)
             if (lag >= 0 and nchunks >= 6 and os.environ.get("OSZ_CHAIN_ZP", "1") != "0"
                     and cs >= max(4 * (lcut + lag), warm + lcut + lag, 2 * dev.chain_zp_min_chunk(fir, iir))):
@@ -613,6 +614,7 @@ def sosfiltfilt(pro, sos, axis):
                 and stream.warm_len <= cs):
             ident = dev.FirStream(np.array([1.0, 0.0]), layout.nch)
             try:
+                dev.chain_zp_tolerance(ident, stream, dev.zp_tolerance_for(first, layout.axis))
                 lag = dev.chain_zp_lag(ident, stream)
                 if lag >= 0 and cs >= max(4 * lag, stream.warm_len + lag, 2 * dev.chain_zp_min_chunk(ident, stream)):
                     yield from _zero_phase_stream(ident, stream, layout, pipe, flying, first, chunks,

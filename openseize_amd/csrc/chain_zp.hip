@@ -714,7 +714,7 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
             spec::TablesZp T;
             if (zp_nega()) {
                 T = spec::build_zpn(fir->htaps.data(), fir->ntaps, sos->coef, sos->nsec, sos->warm_len <= (1 << 20),
-                                    15360 - 1024);
+                                    15360 - 1024, sos->zp_tol > 0.0 ? (spec::ld_t)sos->zp_tol : spec::kTailTol);
                 s->nega = T.eligible;
             }
             if (!T.eligible)
@@ -864,6 +864,17 @@ int64_t osz_chain_zp_lag(osz_fir_t fir, osz_sos_t sos) {
     ChainZp *s = nullptr;
     if (zp_get(fir, sos, &s) != OSZ_OK || !s->eligible) return -1;
     return 256 * (int64_t)s->R;
+}
+
+int osz_chain_zp_tolerance(osz_fir_t fir, osz_sos_t sos, double tol) {
+    OSZ_REQUIRE(fir && sos, "osz_chain_zp_tolerance: null handle");
+    OSZ_REQUIRE(tol == 0.0 || (tol >= 1e-18 && tol <= 1e-6), "osz_chain_zp_tolerance: tol=%g", tol);
+    if (sos->zp && sos->zp->open) return fail(OSZ_ERR_STATE, "osz_chain_zp_tolerance: a zero-phase stream is open");
+    if (sos->zp_tol != tol) {
+        sos->zp_tol = tol;
+        if (sos->zp) zp_unlink(sos->zp);        // the tables are rebuilt at the next use
+    }
+    return OSZ_OK;
 }
 
 int64_t osz_chain_zp_min_chunk(osz_fir_t fir, osz_sos_t sos) {

@@ -68,6 +68,7 @@ struct osz_sos_s {
     int64_t side_ld[2], side_n[2];
     osz::ChainSpec *spec;                 // see osz_fir_s
     osz::ChainZp *zp;
+    double zp_tol;                        // osz_chain_zp_tolerance: where the bursts are cut (0: the default)
 };
 
 namespace osz {

@@ -1367,6 +1367,7 @@ int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch) {
     p->side_busy = false;
     p->spec = nullptr;
     p->zp = nullptr;
+    p->zp_tol = 0.0;
     p->touch = 0;
     {
         // the trimmed lean body (sos_body2): T = 32, NW = 4, up to 8 sections

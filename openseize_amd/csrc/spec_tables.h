@@ -497,7 +497,7 @@ inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int ns
 //         is MINUS the left tail: the nu rows carry the sign, the kernel sees true amplitudes
 //         and ADDS its in-window corrections
 inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int nsec, bool forgets,
-                          int lds_budget = 15360) {
+                          int lds_budget = 15360, ld_t tail_tol = kTailTol) {
     TablesZp T;
     constexpr int kM = 8192;
     if (wlen < 2 || !forgets) return T;
@@ -554,8 +554,8 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
         for (int r = 1; r <= kRMax && !(rb && rf); ++r) {
             const int ir = Lg + kM + 256 * r - S + 1, il = Lg - 256 * r;
             if (ir >= 2 * Lg || il < 0) break;
-            if (!rf && sqrtl(right2[ir]) <= kTailTol * tot) rf = r;
-            if (!rb && sqrtl(left2[il]) <= kTailTol * tot) rb = r;
+            if (!rf && sqrtl(right2[ir]) <= tail_tol * tot) rf = r;
+            if (!rb && sqrtl(left2[il]) <= tail_tol * tot) rb = r;
         }
         if (rb && rf && rf <= rb && rb <= D && D + rf <= cand) {
             NB = cand;

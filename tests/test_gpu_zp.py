@@ -252,3 +252,59 @@ def test_plain_sosfiltfilt_takes_the_zero_phase_kernel(dev, fed):
         pick = [0, C // 2, C - 1]
         want = orc.sosfiltfilt(xh[pick], sos, cs)
         assert np.max(np.abs(gh[pick] - want)) < RTOL * np.max(np.abs(want)), (C, cs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("after_fir", [True, False])
+def test_large_offset_and_drift(dev, after_fir):
+    """Raw recordings carry offsets thousands of times their in-band signal.  What the
+    zero-phase kernel cuts off (its bursts, at a tolerance relative to the norm of the composite
+    impulse response) scales with the INPUT, so the generators look at the first chunk
+    (dev.zp_tolerance_for) and ask for the tighter cut (osz_chain_zp_tolerance: one more burst
+    row each way, a longer lag): a small in-band signal on an offset of 10^4 with a slow
+    drift stays within 1e-9 of the OUTPUT's scale of the oracle's chunk-local scheme
+    (core/numerical.py:338-411), seam chunks n-3 / n-2 included, behind a FIR and alone."""
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import producer
+    from openseize_amd.core import numerical as nm
+    C, cs = 3, 65536
+    total = cs * 6 + 12345
+    taps = sps.firwin(256, 0.4)
+    noise = dev.synth_normal(C, total, seed=91)
+    ramp = torch.linspace(0.0, 1.0, total, dtype=torch.float64, device="cuda")[None]
+    x = noise + 1e4 + 2e3 * ramp * torch.tensor([[1.0], [-1.0], [0.3]], dtype=torch.float64, device="cuda")
+    lags, plain_open = [], dev.chain_zp_open
+    steps, plain_zp = [], dev.chain_zp_step
+
+    def spy_open(fir, iir, skip=0):
+        lags.append(dev.chain_zp_lag(fir, iir))
+        return plain_open(fir, iir, skip)
+
+    dev.chain_zp_open = spy_open
+    dev.chain_zp_step = lambda *a, **k: (steps.append(1), plain_zp(*a, **k))[1]
+    try:
+        src = producer(x, cs, -1)
+        if after_fir:
+            src = producer(partial(nm.oaconvolve, src, taps, -1, "same"), cs, -1, shape=src.shape)
+        got = torch.cat([c for c in nm.sosfiltfilt(src, BP, -1)], -1).cpu().numpy()
+    finally:
+        dev.chain_zp_open, dev.chain_zp_step = plain_open, plain_zp
+    # the tighter tables (a longer lag than the default cut's), the one-kernel route
+    f0, i0 = dev.FirStream(taps if after_fir else np.array([1.0, 0.0]), 1), dev.SosStream(BP, 1)
+    try:
+        loose = dev.chain_zp_lag(f0, i0)
+        dev.chain_zp_tolerance(f0, i0, 1e-15)
+        tight = dev.chain_zp_lag(f0, i0)
+    finally:
+        f0.close()
+        i0.close()
+    assert lags == [tight] and tight > loose > 0 and len(steps) == 5, (lags, loose, tight, len(steps))
+    xh = x.cpu().numpy()
+    u = np.concatenate(orc.oaconvolve(xh, taps, "same"), -1) if after_fir else xh
+    want = orc.sosfiltfilt(u, BP, cs)
+    lo = 4096                      # (past the reference's own start transient on the offset: its scale is the offset's)
+    scale = np.max(np.abs(want[:, lo:]))
+    assert scale < 50.0            # the output is the in-band signal, the offset is gone
+    assert np.max(np.abs(got[:, lo:] - want[:, lo:])) < RTOL * scale
+    assert np.max(np.abs(got - want)) < RTOL * np.max(np.abs(want))
