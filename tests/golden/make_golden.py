@@ -601,7 +601,36 @@ def g17_responses():
     save("g17_responses.npz", **out)
 
 
+# --------------------------------------------------------------------------
+# G18 the headline chain at a geometry where the build's zero-phase route engages: the
+# reference's oaconvolve('same') -> sosfiltfilt (core/numerical.py:158-298 into :338-411) as
+# chained producers, 1024 taps, the 6-section Butterworth band-pass of cfg-3, chunksize 65 536,
+# six whole chunks + a ragged one.  Channel 1 rides an offset of 10^4 with a slow drift.
+# x is float32-representable (stored as float32, exactly the float64 values the reference saw).
+# --------------------------------------------------------------------------
+def g18_chain_long():
+    rng = np.random.default_rng(1801)
+    cs, total = 65536, 6 * 65536 + 12345
+    x = rng.standard_normal((2, total))
+    x[1] += 1e4 + 2e3 * np.linspace(0.0, 1.0, total)
+    x = x.astype(np.float32).astype(np.float64)
+    h = sps.firwin(1024, 0.2)
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    src = producer(x, cs, axis=-1)
+    fir = producer(partial(nm.oaconvolve, src, h, -1, "same"), cs, axis=-1, shape=x.shape)
+    pieces = list(nm.sosfiltfilt(fir, sos, -1))
+    y = np.concatenate(pieces, axis=-1)
+    assert y.shape == x.shape
+    save("g18_chain_long.npz", x32=x.astype(np.float32), y=y, h=h, sos=sos, chunksize=np.int64(cs),
+         piece_lengths=np.array([p.shape[-1] for p in pieces], dtype=np.int64))
+
+
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1:                      # regenerate the named blocks only
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_producer()
     g2_fir()
     g3_sosfilt()
@@ -619,3 +648,4 @@ if __name__ == "__main__":
     g15_nonfinite()
     g16_remez()
     g17_responses()
+    g18_chain_long()

@@ -118,14 +118,17 @@ def test_cfg2_128ch_1024taps_ragged(nm):
 # ------------------------------------------------------------------- cfg-3
 def test_cfg3_256ch_chain_ragged(nm):
     """cfg-3: 256 channels, FIR(1024) -> 6-section Butterworth band-pass
-    sosfiltfilt at chunksize 2^20 over three whole chunks plus the ragged
+    sosfiltfilt at chunksize 2^20 over six whole chunks plus the ragged
     385 280-sample last chunk (its backward pass starts from sosfilt_zi * last
     sample, reference core/numerical.py:408-411, and the chunk before it warms up
-    over a SHORT next chunk, :397-399)."""
+    over a SHORT next chunk, :397-399): seven chunks, so the route under test is the
+    headline's -- osz_chain_zp_step for chunks 0 .. 4, the separate kernels for the
+    last two -- and the test says so."""
     import scipy.signal as sps
     import torch
     from oracle import oracle as orc
-    C, n = 256, 3 * CS + RAGGED
+    from openseize_amd import _device as dev
+    C, n = 256, 6 * CS + RAGGED
     h = sps.firwin(1024, 0.2)
     sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
     x = _synth(C, n, seed=22)
@@ -133,10 +136,16 @@ def test_cfg3_256ch_chain_ragged(nm):
                    shape=tuple(x.shape))
     pick = [0, 128, 255]
     got, lengths = [], []
-    for out in nm.sosfiltfilt(fir, sos, -1):
-        lengths.append(out.shape[-1])
-        got.append(out[pick].cpu().numpy())
-    assert lengths == [CS] * 3 + [RAGGED]
+    steps, plain = [], dev.chain_zp_step
+    dev.chain_zp_step = lambda *a, **k: (steps.append(1), plain(*a, **k))[1]
+    try:
+        for out in nm.sosfiltfilt(fir, sos, -1):
+            lengths.append(out.shape[-1])
+            got.append(out[pick].cpu().numpy())
+    finally:
+        dev.chain_zp_step = plain
+    assert lengths == [CS] * 6 + [RAGGED]
+    assert len(steps) == 5, len(steps)          # the zero-phase kernel, one launch per chunk
     xh = x[pick].cpu().numpy()
     del x
     torch.cuda.empty_cache()

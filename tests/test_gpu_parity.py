@@ -876,9 +876,15 @@ def test_long_stream_cfg3_direct(osz):
                    shape=tuple(x.shape))
     pick = [0, 101, 255]
     got = []
-    for out in osz.sosfiltfilt(fir, sos, -1):
-        assert out.is_cuda
-        got.append(out[pick].cpu().numpy())
+    steps, plain = [], dev.chain_zp_step
+    dev.chain_zp_step = lambda *a, **k: (steps.append(1), plain(*a, **k))[1]
+    try:
+        for out in osz.sosfiltfilt(fir, sos, -1):
+            assert out.is_cuda
+            got.append(out[pick].cpu().numpy())
+    finally:
+        dev.chain_zp_step = plain
+    assert len(steps) == nchunks - 2, len(steps)     # the headline's route: one zero-phase launch per chunk
     got = np.concatenate(got, -1)
     assert got.shape == (3, n)
     xh = x[pick].cpu().numpy()

@@ -308,3 +308,35 @@ def test_large_offset_and_drift(dev, after_fir):
     assert scale < 50.0            # the output is the in-band signal, the offset is gone
     assert np.max(np.abs(got[:, lo:] - want[:, lo:])) < RTOL * scale
     assert np.max(np.abs(got - want)) < RTOL * np.max(np.abs(want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fed", ["resident", "host"])
+def test_reference_outputs_where_the_route_engages(dev, golden, fed):
+    """g18_chain_long.npz: outputs of the REFERENCE ITSELF (oaconvolve 'same' -> sosfiltfilt as
+    chained producers, core/numerical.py:158-298 into :338-411; tests/golden/make_golden.py) at a
+    geometry the zero-phase route takes -- 1024 taps, the 6-section band-pass of cfg-3, six
+    chunks of 65 536 + a ragged one; channel 1 on an offset of 10^4 with a drift.  The public
+    generators run it with osz_chain_zp_step for chunks 0 .. 4 (asserted) and match the
+    reference's numbers to 1e-9 of each channel's output scale, resident and host-fed."""
+    import torch
+    from openseize_amd import producer
+    from openseize_amd.core import numerical as nm
+    g = golden("g18_chain_long.npz")
+    x, want, h, sos, cs = g["x32"].astype(np.float64), g["y"], g["h"], g["sos"], int(g["chunksize"])
+    src_data = x if fed == "host" else torch.from_numpy(x).cuda()
+    steps, plain = [], dev.chain_zp_step
+    dev.chain_zp_step = lambda *a, **k: (steps.append(1), plain(*a, **k))[1]
+    try:
+        src = producer(src_data, cs, -1)
+        fir = producer(partial(nm.oaconvolve, src, h, -1, "same"), cs, -1, shape=src.shape)
+        pieces = [c for c in nm.sosfiltfilt(fir, sos, -1)]
+    finally:
+        dev.chain_zp_step = plain
+    nchunks = -(-x.shape[1] // cs)
+    assert len(steps) == nchunks - 2 == 5, len(steps)
+    assert [p.shape[-1] for p in pieces] == list(g["piece_lengths"])
+    got = np.concatenate([p if isinstance(p, np.ndarray) else p.cpu().numpy() for p in pieces], -1)
+    for c in range(x.shape[0]):
+        scale = np.max(np.abs(want[c]))
+        assert np.max(np.abs(got[c] - want[c])) < RTOL * scale, (c, np.max(np.abs(got[c] - want[c])) / scale)

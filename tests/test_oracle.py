@@ -200,3 +200,16 @@ def test_nonfinite_reach(golden):
             ok = np.isfinite(want)
             assert np.array_equal(ok, np.isfinite(dec))
             assert np.max(np.abs(dec[ok] - want[ok])) < 1e-12 * np.max(np.abs(want[ok]))
+
+
+def test_oracle_chain_at_the_zero_phase_geometry(golden):
+    """g18: the reference's own outputs for the headline chain at a geometry the build's
+    zero-phase route takes (1024 taps -> 6-section band-pass sosfiltfilt, chunks of 65 536,
+    channel 1 on an offset of 10^4).  The oracle's restatement (core/numerical.py:158-298,
+    :338-411) reproduces them: what the GPU route is held against is pinned here too."""
+    g = golden("g18_chain_long.npz")
+    x, want, h, sos, cs = g["x32"].astype(np.float64), g["y"], g["h"], g["sos"], int(g["chunksize"])
+    u = np.concatenate(orc.oaconvolve(x, h, "same"), axis=-1)
+    got = orc.sosfiltfilt(u, sos, cs)
+    for c in range(x.shape[0]):
+        assert np.max(np.abs(got[c] - want[c])) < 1e-10 * np.max(np.abs(want[c])), c
