@@ -104,8 +104,9 @@ __device__ __forceinline__ void zp_request_rows(const double *src, int nrows, in
 }
 
 
-// chain_zpn.hip: the kernel for NB rows per block (24 .. 30) and NM modes (2, 4, 6)
+// chain_zpn_*.hip: the kernel for NB rows per block (24 .. 30), NM modes (2, 4, 6, 8) of which the
+// first NS (2, 4, 6) are slow
 using zp_kern_t = void (*)(ZpArgs);
-zp_kern_t zpn_kernel_for(int nb, int nm);
+zp_kern_t zpn_kernel_for(int nb, int nm, int ns);
 
 }  // namespace osz

@@ -633,6 +633,7 @@ struct ChainZp {
     bool eligible = false, open = false;
     bool nega = false;             // one real block per transform (chain_zpn.hip); NR is then its rows per block
     int NR = 0, NM = 0, R = 0, Rf = 0, nh = 0;
+    int NS = 0;                    // nega: the slow modes (spec::build_zpn)
     double *dH = nullptr, *dT = nullptr;   // dT: burst rows | mode powers | fit matrix, as the kernel's LDS holds them
     double *dM = nullptr, *dP = nullptr, *dL = nullptr;   // (views into dT)
     double *dcarry[2] = {nullptr, nullptr}, *dheld[2] = {nullptr, nullptr};
@@ -693,7 +694,8 @@ static size_t zp_lds_bytes(const ChainZp *s) {
     const int NM = s->NM, R = s->R, ns = 2 * s->nh;
     if (s->nega)
         return sizeof(fft::cube::C2) * fft::cube::SLOTS +
-               sizeof(double) * (ns + 4 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * ns) + 1024;   // + W256 rows
+               sizeof(double) * (ns + R * (3 * s->NS + NM) * 2 + R * NM * 2 + 20 * NM * 2 + (2 * s->NS + 2 * NM) * ns) +
+               1024;   // + W256 rows
     return sizeof(fft::cube::C2) * fft::cube::SLOTS +
            sizeof(double) * (2 * ns + 8 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * ns);
 }
@@ -727,7 +729,8 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
                 };
                 int rc;
                 // one table, in the order of the kernel's LDS: a workgroup fetches it in one sweep
-                const size_t nl = (size_t)T.R * T.NM * 2, np = (size_t)20 * T.NM * 2, nm = (size_t)4 * T.NM * 2 * T.nh;
+                const size_t nl = (size_t)T.R * T.NM * 2, np = (size_t)20 * T.NM * 2,
+                             nm = (size_t)(s->nega ? 2 * T.NS + 2 * T.NM : 4 * T.NM) * 2 * T.nh;
                 if (T.L.size() < nl || T.P.size() != np || T.M.size() != nm)
                     return fail(OSZ_ERR_STATE, "zero-phase tables: %zu %zu %zu", T.L.size(), T.P.size(), T.M.size());
                 std::vector<double> cat(T.L.begin(), T.L.begin() + nl);
@@ -754,6 +757,7 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
                 s->R = T.R;
                 s->Rf = T.Rf;
                 s->nh = T.nh;
+                s->NS = T.NS;
                 s->eligible = true;
             }
         }
@@ -835,12 +839,12 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
         g.hist = nullptr;
         g.hist_len = 0;
     }
-    zp_kern_t kern = s->nega    ? zpn_kernel_for(NR, s->NM)
+    zp_kern_t kern = s->nega    ? zpn_kernel_for(NR, s->NM, s->NS)
                      : zp_dma() ? (s->NM == 2 ? zp_kernel_for<2, true>(NR) : s->NM == 4 ? zp_kernel_for<4, true>(NR)
                                                                                        : zp_kernel_for<6, true>(NR))
                                 : (s->NM == 2 ? zp_kernel_for<2, false>(NR) : s->NM == 4 ? zp_kernel_for<4, false>(NR)
                                                                                         : zp_kernel_for<6, false>(NR));
-    if (!kern) return fail(OSZ_ERR_STATE, "zero-phase kernel: no instance for %d rows, %d modes", NR, s->NM);
+    if (!kern) return fail(OSZ_ERR_STATE, "zero-phase kernel: no instance for %d rows, %d modes (%d slow)", NR, s->NM, s->NS);
     const size_t lds = zp_lds_bytes(s);
     OSZ_DYN_LDS(kern, lds);
     {

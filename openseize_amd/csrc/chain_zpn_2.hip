@@ -1,0 +1,4 @@
+// The zero-phase chain kernel on one real block per transform (chain_zpn_body.h) for cascades of
+// 2 modes: every block height (24 .. 30 rows) and slow-mode count.
+#define OSZ_ZPN_NM 2
+#include "chain_zpn_body.h"

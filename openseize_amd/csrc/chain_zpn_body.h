@@ -1,4 +1,4 @@
-// chain_zpn.hip -- FIR -> sosfiltfilt of a long stream, ONE real block per transform.
+// chain_zpn_body.h (compiled as chain_zpn_{2,4,6,8}.hip, one per mode count) -- FIR -> sosfiltfilt of a long stream, ONE real block per transform.
 //
 // Same scheme as chain_zp.hip (oaconvolve, core/numerical.py:158-298, into sosfiltfilt,
 // :338-411, as one multiplication per bin by H_fir |H_iir|^2 plus mode bursts for what the
@@ -42,22 +42,26 @@
 namespace osz {
 
 // The fit and the burst amplitudes of a block in one stage.  Sixteen consecutive lanes (one DPP
-// row) share one amplitude (causal / anticausal, mode): each takes a sixteenth of the 2 nh fit
-// samples for the real AND the imaginary row of M, four DPP steps add the parts up in the row's
-// last lane, and that lane writes kappa[r] = amplitude * lambda^(256 r), r < R:
-//   kapA[kind][r][q]   kind = 0 mu, 1 nu            (this block)
-//   kapN[r][q]         mu: what the NEXT block meets as mu of the previous block
-template <int NM, int PER>
+// row) share one amplitude -- the right tail's mu of a slow mode (NS of them) or the left tail's
+// nu of any mode (NM): each lane takes a sixteenth of the 2 nh fit samples for the real AND the
+// imaginary row of M, four DPP steps add the parts up in the row's last lane, and that lane
+// writes kappa[r] = amplitude * lambda^(256 r), r < R:
+//   kmu[r][q], q < NS    this block's mu;  kapN[r][q]: what the NEXT block meets as the previous one's
+//   knu[r][q], q < NM    this block's nu (rows behind the first are read for the slow modes only)
+// M's rows: Re mu [NS], Im mu [NS], Re nu [NM], Im nu [NM].
+template <int NM, int NS, int PER>
 __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fitbuf, const double *mtab,
-                                                const double *lrow, double *kapA, double *kapN) {
+                                                const double *lrow, double *kmu, double *knu, double *kapN) {
     constexpr int ns = 16 * PER;
-    if ((tt & ~63) >= 32 * NM) return;          // whole waves without an amplitude skip the stage
+    if ((tt & ~63) >= 16 * (NS + NM)) return;    // whole waves without an amplitude skip the stage
     const int qd = tt >> 4, p16 = tt & 15;
-    const bool valid = qd < 2 * NM;
-    const int kind = valid ? qd / NM : 0, q = valid ? qd % NM : 0;
+    const bool valid = qd < NS + NM;
+    const bool is_mu = qd < NS;
+    const int q = valid ? (is_mu ? qd : qd - NS) : 0;
+    const int rre = is_mu ? q : 2 * NS + q, rim = is_mu ? NS + q : 2 * NS + NM + q;
     const double *yb = fitbuf + PER * p16;
-    const double *mr = mtab + ns * ((2 * kind) * NM + q) + PER * p16;
-    const double *mi = mtab + ns * ((2 * kind + 1) * NM + q) + PER * p16;
+    const double *mr = mtab + ns * rre + PER * p16;
+    const double *mi = mtab + ns * rim + PER * p16;
     double y[PER], a[PER], b[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -86,11 +90,14 @@ __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fit
             if (r < R) {
                 const double lr = lrow[(r * NM + q) * 2 + 0], li = lrow[(r * NM + q) * 2 + 1];
                 const double kr = sr * lr - si * li, ki = sr * li + si * lr;
-                kapA[((kind * R + r) * NM + q) * 2 + 0] = kr;
-                kapA[((kind * R + r) * NM + q) * 2 + 1] = ki;
-                if (kind == 0) {
-                    kapN[(r * NM + q) * 2 + 0] = kr;
-                    kapN[(r * NM + q) * 2 + 1] = ki;
+                if (is_mu) {
+                    kmu[(r * NS + q) * 2 + 0] = kr;
+                    kmu[(r * NS + q) * 2 + 1] = ki;
+                    kapN[(r * NS + q) * 2 + 0] = kr;
+                    kapN[(r * NS + q) * 2 + 1] = ki;
+                } else {
+                    knu[(r * NM + q) * 2 + 0] = kr;
+                    knu[(r * NM + q) * 2 + 1] = ki;
                 }
             }
         }
@@ -98,12 +105,26 @@ __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fit
 }
 
 // nh is 16, 24 or 32 (spec::build_zpn)
-template <int NM>
+template <int NM, int NS>
 __device__ __forceinline__ void zpn_fit_kappa(int tt, int nh, int R, const double *fitbuf, const double *mtab,
-                                              const double *lrow, double *kapA, double *kapN) {
-    if (nh == 24) zpn_fit_kappa_n<NM, 3>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
-    else if (nh == 32) zpn_fit_kappa_n<NM, 4>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
-    else zpn_fit_kappa_n<NM, 2>(tt, R, fitbuf, mtab, lrow, kapA, kapN);
+                                              const double *lrow, double *kmu, double *knu, double *kapN) {
+    if (nh == 24) zpn_fit_kappa_n<NM, NS, 3>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
+    else if (nh == 32) zpn_fit_kappa_n<NM, NS, 4>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
+    else zpn_fit_kappa_n<NM, NS, 2>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
+}
+
+// lambda_q^e, q = q0 .. q0 + NG - 1, e = 0..255, from the three-level table [20][NM][2]
+template <int NM, int NG>
+__device__ __forceinline__ void zpn_powers(const double *ptab, int q0, int e, double *pr, double *pi) {
+    const double *p1 = ptab + ((e >> 5) * NM + q0) * 2, *p2 = ptab + ((8 + ((e >> 2) & 7)) * NM + q0) * 2,
+                 *p3 = ptab + ((16 + (e & 3)) * NM + q0) * 2;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const double ar = p1[2 * q] * p2[2 * q] - p1[2 * q + 1] * p2[2 * q + 1];
+        const double ai = p1[2 * q] * p2[2 * q + 1] + p1[2 * q + 1] * p2[2 * q];
+        pr[q] = ar * p3[2 * q] - ai * p3[2 * q + 1];
+        pi[q] = ar * p3[2 * q + 1] + ai * p3[2 * q];
+    }
 }
 
 // two bursts of one row at once: Re sum_q k0_q P_q and Re sum_q k1_q P_q
@@ -122,15 +143,15 @@ __device__ __forceinline__ void zpn_dot2(const double *k0, const double *k1, con
     d1 = br - bi;
 }
 
-// The forward bursts (RF rows): this block's mu leaves row r, the previous block's arrives in
-// row D + r (both rows live in re[]: D + r <= 8 + 4).
-template <int D, int NM, int RF>
+// The forward bursts (RF rows, the NS slow modes): this block's mu leaves row r, the previous
+// block's arrives in row D + r (both rows live in re[]: D + r <= 8 + 4).
+template <int D, int NS, int RF>
 __device__ __forceinline__ void zpn_fwd_bursts(double *re, const double *kmu, const double *kpm, const double *Pr,
                                                const double *Pi, double &first) {
 #pragma unroll
     for (int r = 0; r < RF; ++r) {
         double ca, cp;
-        zpn_dot2<NM>(kmu + (r * NM) * 2, kpm + (r * NM) * 2, Pr, Pi, ca, cp);
+        zpn_dot2<NS>(kmu + (r * NS) * 2, kpm + (r * NS) * 2, Pr, Pi, ca, cp);
         re[r] += ca;
         re[D + r] += cp;
         if (r == 0) first = ca;
@@ -138,15 +159,24 @@ __device__ __forceinline__ void zpn_fwd_bursts(double *re, const double *kmu, co
 }
 
 // The backward bursts (RB rows): this block's nu leaves window row 31 - r (im[15 - r]) and
-// arrives, with the same values, in the rows the previous block holds back (c7).
-template <int NM, int RB>
-__device__ __forceinline__ void zpn_bwd_bursts(double *im, double *c7, const double *knu, const double *Pr,
-                                               const double *Pi) {
+// arrives, with the same values, in the rows the previous block holds back (c7).  The slow modes
+// in every row; the fast ones (two at a time: their powers are formed on the spot) in the first.
+template <int NM, int NS, int RB>
+__device__ __forceinline__ void zpn_bwd_bursts(double *im, double *c7, const double *knu, const double *ptab, int e,
+                                               const double *Pr, const double *Pi) {
+    double nb[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) nb[r] = zp_dot<NS>(knu + (r * NM) * 2, Pr, Pi);
+#pragma unroll
+    for (int q0 = NS; q0 < NM; q0 += 2) {
+        double fr[2], fi[2];
+        zpn_powers<NM, 2>(ptab, q0, e, fr, fi);
+        nb[0] += zp_dot<2>(knu + q0 * 2, fr, fi);
+    }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-        const double nb = zp_dot<NM>(knu + (r * NM) * 2, Pr, Pi);
-        im[15 - r] += nb;
-        c7[r] = nb;
+        im[15 - r] += nb[r];
+        c7[r] = nb[r];
     }
 }
 
@@ -203,7 +233,7 @@ struct NegaWindow {
     }
 };
 
-template <int NB, int NM>
+template <int NB, int NM, int NS>
 __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     constexpr int D = 32 - NB, S = 256 * NB, NHI = NB - 16, NP = (NB + 1) / 2;
     static_assert(NB >= 24 && NB <= 30, "rows per block");
@@ -211,12 +241,13 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     const int R = g.R, Rf = g.Rf, nh = g.nh, ns = 2 * nh;
     double *xl = reinterpret_cast<double *>(cube_lds) + 2 * fft::cube::SLOTS;   // behind the cube
     double *fitbuf = xl;                               // [2 nh]
-    double *kapA = fitbuf + ns;                        // [2 kind][R][NM][2]: this block's mu, nu
-    double *kapP = kapA + 2 * R * NM * 2;              // [2 parity][R][NM][2]: the previous block's mu
-    double *lrow = kapP + 2 * R * NM * 2;              // [R][NM][2]
+    double *kmu = fitbuf + ns;                         // [R][NS][2]: this block's mu (slow modes)
+    double *knu = kmu + R * NS * 2;                    // [R][NM][2]: this block's nu
+    double *kapP = knu + R * NM * 2;                   // [2 parity][R][NS][2]: the previous block's mu
+    double *lrow = kapP + 2 * R * NS * 2;              // [R][NM][2]
     double *ptab = lrow + R * NM * 2;                  // [20][NM][2]
-    double *mtab = ptab + 20 * NM * 2;                 // [4 NM][2 nh]
-    fft::cube::C2 *tw2l = reinterpret_cast<fft::cube::C2 *>(mtab + 4 * NM * ns);   // [16][4]
+    double *mtab = ptab + 20 * NM * 2;                 // [2 NS + 2 NM][2 nh]
+    fft::cube::C2 *tw2l = reinterpret_cast<fft::cube::C2 *>(mtab + (2 * NS + 2 * NM) * ns);   // [16][4]
     const FirArgs &a = g.f;
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
     const int L = 256 * R;
@@ -249,11 +280,11 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     if (first <= lastf) zp_request_rows<NP>(xr + (int64_t)first * S, NB, t, cube_lds);
     {
         // lrow | ptab | mtab are one table on the device too (g.Lrow)
-        const int ntab = R * NM * 2 + 20 * NM * 2 + 4 * NM * ns;
+        const int ntab = R * NM * 2 + 20 * NM * 2 + (2 * NS + 2 * NM) * ns;
 #pragma unroll 8
         for (int i = t; i < ntab; i += 256) lrow[i] = g.Lrow[i];
     }
-    for (int i = t; i < 2 * R * NM * 2; i += 256) kapP[i] = 0.0;
+    for (int i = t; i < 2 * R * NS * 2; i += 256) kapP[i] = 0.0;
     double held[kSpecRMax];          // rows NB-1-r of the previous block, one burst short
 #pragma unroll
     for (int r = 0; r < kSpecRMax; ++r) held[r] = 0.0;
@@ -321,36 +352,35 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
 #pragma unroll
         for (int j = 0; j < D; ++j) re[j] += cr[j];
         __syncthreads();
-        zpn_fit_kappa<NM>(tt, nh, R, fitbuf, mtab, lrow, kapA, kapP + (par ^ 1) * (R * NM * 2));
+        zpn_fit_kappa<NM, NS>(tt, nh, R, fitbuf, mtab, lrow, kmu, knu, kapP + (par ^ 1) * (R * NS * 2));
         __syncthreads();
         double c7[kSpecRMax];
 #pragma unroll
         for (int r = 0; r < kSpecRMax; ++r) c7[r] = 0.0;
         {
-            double Pr[NM], Pi[NM];
-            zp_powers<NM>(ptab, tt, Pr, Pi);
-            const double *kpm = kapP + par * (R * NM * 2);
+            double Pr[NS], Pi[NS];
+            zpn_powers<NM, NS>(ptab, 0, tt, Pr, Pi);
+            const double *kpm = kapP + par * (R * NS * 2);
             double ca = 0.0;
             switch (Rf) {
-                case 1: zpn_fwd_bursts<D, NM, 1>(re, kapA, kpm, Pr, Pi, ca); break;
-                case 2: zpn_fwd_bursts<D, NM, 2>(re, kapA, kpm, Pr, Pi, ca); break;
-                case 3: zpn_fwd_bursts<D, NM, 3>(re, kapA, kpm, Pr, Pi, ca); break;
-                case 4: zpn_fwd_bursts<D, NM, 4>(re, kapA, kpm, Pr, Pi, ca); break;
-                default: zpn_fwd_bursts<D, NM, 5>(re, kapA, kpm, Pr, Pi, ca); break;
+                case 1: zpn_fwd_bursts<D, NS, 1>(re, kmu, kpm, Pr, Pi, ca); break;
+                case 2: zpn_fwd_bursts<D, NS, 2>(re, kmu, kpm, Pr, Pi, ca); break;
+                case 3: zpn_fwd_bursts<D, NS, 3>(re, kmu, kpm, Pr, Pi, ca); break;
+                case 4: zpn_fwd_bursts<D, NS, 4>(re, kmu, kpm, Pr, Pi, ca); break;
+                default: zpn_fwd_bursts<D, NS, 5>(re, kmu, kpm, Pr, Pi, ca); break;
             }
             if (!bad && __builtin_amdgcn_readfirstlane((int)sos_not_finite(ca))) {
                 bad = true;
                 bad_at = o;
             }
             __builtin_amdgcn_sched_barrier(0);
-            zp_powers<NM>(ptab, 255 - tt, Pr, Pi);
-            const double *knu = kapA + (R * NM) * 2;
+            zpn_powers<NM, NS>(ptab, 0, 255 - tt, Pr, Pi);
             switch (R) {
-                case 1: zpn_bwd_bursts<NM, 1>(im, c7, knu, Pr, Pi); break;
-                case 2: zpn_bwd_bursts<NM, 2>(im, c7, knu, Pr, Pi); break;
-                case 3: zpn_bwd_bursts<NM, 3>(im, c7, knu, Pr, Pi); break;
-                case 4: zpn_bwd_bursts<NM, 4>(im, c7, knu, Pr, Pi); break;
-                default: zpn_bwd_bursts<NM, 5>(im, c7, knu, Pr, Pi); break;
+                case 1: zpn_bwd_bursts<NM, NS, 1>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
+                case 2: zpn_bwd_bursts<NM, NS, 2>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
+                case 3: zpn_bwd_bursts<NM, NS, 3>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
+                case 4: zpn_bwd_bursts<NM, NS, 4>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
+                default: zpn_bwd_bursts<NM, NS, 5>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
             }
         }
         const double qn = spec_qnan();
@@ -410,11 +440,11 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 else if (!bad && pp - la < kSpecLdc) co[pp - la] = v;
             }
             if (!bad) {
-                double Pr[NM], Pi[NM];
-                zp_powers<NM>(ptab, tt, Pr, Pi);
+                double Pr[NS], Pi[NS];
+                zpn_powers<NM, NS>(ptab, 0, tt, Pr, Pi);
                 for (int r = 0; r < Rf; ++r) {
                     const int k = 8192 + 256 * r + tt - la;
-                    if (k < kSpecLdc) co[k] = zp_dot<NM>(kapA + (r * NM) * 2, Pr, Pi);
+                    if (k < kSpecLdc) co[k] = zp_dot<NS>(kmu + (r * NS) * 2, Pr, Pi);
                 }
             }
             if (g.hist) {
@@ -461,17 +491,37 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     if (bad && t == 0) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
 }
 
-template <int NM>
+// (one translation unit per mode count: chain_zpn_{2,4,6,8}.hip define OSZ_ZPN_NM and include
+// this file; the dispatcher lives with NM = 2)
+template <int NM, int NS>
 static zp_kern_t zpn_kernel_nb(int nb) {
-    static const zp_kern_t k[7] = {chain_zpn_kernel<24, NM>, chain_zpn_kernel<25, NM>, chain_zpn_kernel<26, NM>,
-                                   chain_zpn_kernel<27, NM>, chain_zpn_kernel<28, NM>, chain_zpn_kernel<29, NM>,
-                                   chain_zpn_kernel<30, NM>};
+    static const zp_kern_t k[7] = {chain_zpn_kernel<24, NM, NS>, chain_zpn_kernel<25, NM, NS>,
+                                   chain_zpn_kernel<26, NM, NS>, chain_zpn_kernel<27, NM, NS>,
+                                   chain_zpn_kernel<28, NM, NS>, chain_zpn_kernel<29, NM, NS>,
+                                   chain_zpn_kernel<30, NM, NS>};
     return k[nb - 24];
 }
 
-zp_kern_t zpn_kernel_for(int nb, int nm) {
+#define OSZ_ZPN_CAT2(a, b) a##b
+#define OSZ_ZPN_CAT(a, b) OSZ_ZPN_CAT2(a, b)
+// zpn_kernel_nm2 / 4 / 6 / 8 (nb, ns)
+zp_kern_t OSZ_ZPN_CAT(zpn_kernel_nm, OSZ_ZPN_NM)(int nb, int ns) {
+    constexpr int NM = OSZ_ZPN_NM;
     if (nb < 24 || nb > 30) return nullptr;
-    return nm == 2 ? zpn_kernel_nb<2>(nb) : nm == 4 ? zpn_kernel_nb<4>(nb) : nm == 6 ? zpn_kernel_nb<6>(nb) : nullptr;
+    if (ns == 2) return zpn_kernel_nb<NM, 2>(nb);
+    if (NM >= 4 && ns == 4) return zpn_kernel_nb<NM, (NM >= 4 ? 4 : 2)>(nb);
+    if (NM >= 6 && ns == 6) return zpn_kernel_nb<NM, (NM >= 6 ? 6 : 2)>(nb);
+    return nullptr;
 }
+
+#if OSZ_ZPN_NM == 2
+zp_kern_t zpn_kernel_nm4(int nb, int ns);
+zp_kern_t zpn_kernel_nm6(int nb, int ns);
+zp_kern_t zpn_kernel_nm8(int nb, int ns);
+zp_kern_t zpn_kernel_for(int nb, int nm, int ns) {
+    return nm == 2 ? zpn_kernel_nm2(nb, ns) : nm == 4 ? zpn_kernel_nm4(nb, ns) : nm == 6 ? zpn_kernel_nm6(nb, ns)
+           : nm == 8 ? zpn_kernel_nm8(nb, ns) : nullptr;
+}
+#endif
 
 }  // namespace osz

@@ -310,6 +310,7 @@ inline Tables build(const double *taps, int wlen, const double *sos, int nsec, b
 struct TablesZp {
     bool eligible = false;
     int NR = 0, NM = 0, nm = 0, R = 0, Rf = 0, nh = 0;
+    int NS = 0;   // build_zpn: the slow modes (the first NS of NM, slowest first) -- the only ones alive a row away
     double fit_ratio = 0.0;
     std::vector<double> H, M, P, L;
 };
@@ -493,11 +494,18 @@ inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int ns
 //   NB    rows per block: the largest with 256 NB + wlen - 1 <= 7936 (row 31 holds nothing but
 //         ringing) whose guard rows hold the bursts (R <= D = 32 - NB, D + Rf <= NB); 24 .. 30
 //   H     [4096][2]  the zero-phase composite response at 2 pi (j + 1/4) / 4096, / 4096
-//   M     as above, fitted on row 31; the wrap is NEGACYCLIC, so what sits at the window's end
-//         is MINUS the left tail: the nu rows carry the sign, the kernel sees true amplitudes
-//         and ADDS its in-window corrections
+//   M     fitted on row 31; the wrap is NEGACYCLIC, so what sits at the window's end is MINUS
+//         the left tail: the nu rows carry the sign, the kernel sees true amplitudes and ADDS
+//         its in-window corrections
+//   NS    the modes are sorted by radius, slowest first, and NS of them are "slow": still above
+//         the tolerance a guard row (257 samples) behind where they start.  Every burst but the
+//         left tail's first row starts at least that far out, so the right tail's amplitudes
+//         mu are kept for the slow modes only (M: [2 NS] rows mu, then [2 NM] rows nu) and the
+//         bursts run over NS modes -- all NM only in the left tail's first row.  (The FIT still
+//         has every mode in its basis: the fast ones are alive in row 31's first samples.)
+//         NM is 2, 4, 6 or 8, NS 2, 4 or 6.
 inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int nsec, bool forgets,
-                          int lds_budget = 15360, ld_t tail_tol = kTailTol) {
+                          int lds_budget = 15360, ld_t tail_tol = kTailTol, ld_t fit_floor = 3e-7L) {
     TablesZp T;
     constexpr int kM = 8192;
     if (wlen < 2 || !forgets) return T;
@@ -520,9 +528,12 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
         }
     }
     const int nm = (int)modes.size();
-    if (nm < 1 || nm > 6) return T;
+    if (nm < 1 || nm > 8) return T;
     for (auto &m : modes)
         if (!(m.re * m.re + m.im * m.im < 1.0L)) return T;
+    std::stable_sort(modes.begin(), modes.end(), [](const Mode &a, const Mode &b) {
+        return a.re * a.re + a.im * a.im > b.re * b.re + b.im * b.im;
+    });
     const int NM = (nm + 1) & ~1;
     const int Lg = kM + 256 * 17;
     std::vector<ld_t> g2(2 * Lg, 0.0L);
@@ -564,11 +575,58 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
         }
     }
     if (!NB) return T;
-    // LDS behind the cube: fit samples [2 nh], kappa: this block's mu, nu [2][R][NM][2], the
-    // previous block's mu [2 parity][R][NM][2], L [R][NM][2], P [20][NM][2], M [4 NM][2 nh]
+    // Slow modes: the two tails of the composite response are exact mode sums, g2[wlen - 1 + n] =
+    // Re sum c_q lambda^n and g2[-1 - n] = Re sum d_q lambda^n (n >= 0); with the residues from
+    // a least-squares fit on 64 samples of each, mode q's share of a tail beyond distance 257 is
+    // at most |c_q| |lambda_q|^257 / sqrt(1 - |lambda_q|^2).
+    int ns_needed = 0;
+    {
+        std::vector<int> cm, ck;
+        for (int q = 0; q < nm; ++q) {
+            cm.push_back(q);
+            ck.push_back(0);
+            if (!modes[q].real) {
+                cm.push_back(q);
+                ck.push_back(1);
+            }
+        }
+        const int ndh = (int)cm.size(), nfit = 64;
+        std::vector<ld_t> Bh((size_t)nfit * ndh);
+        for (int j = 0; j < ndh; ++j)
+            for (int i = 0; i < nfit; ++i) {
+                ld_t pr, pi;
+                mode_pow(modes[cm[j]], i, pr, pi);
+                Bh[(size_t)j * nfit + i] = ck[j] ? -pi : pr;
+            }
+        std::vector<ld_t> Ph;
+        if (pinv_qr(Bh, nfit, ndh, Ph) == 0.0L) return T;
+        for (int q = 0; q < nm; ++q) {
+            ld_t worst = 0.0L;
+            for (int side = 0; side < 2; ++side) {
+                ld_t cr = 0.0L, ci = 0.0L;
+                for (int j = 0; j < ndh; ++j)
+                    if (cm[j] == q)
+                        for (int i = 0; i < nfit; ++i) {
+                            const ld_t gv = side == 0 ? g2[Lg + wlen - 1 + i] : g2[Lg - 1 - i];
+                            (ck[j] ? ci : cr) += Ph[(size_t)j * nfit + i] * gv;
+                        }
+                worst = std::max(worst, sqrtl(cr * cr + ci * ci));
+            }
+            const ld_t rad2 = modes[q].re * modes[q].re + modes[q].im * modes[q].im;
+            const ld_t share = worst * powl(sqrtl(rad2), 257.0L) / sqrtl(1.0L - rad2);
+            if (share > tail_tol * tot / (ld_t)(4 * nm)) ns_needed = q + 1;     // (sorted: slow modes first)
+        }
+    }
+    int NS = (std::max(ns_needed, 1) + 1) & ~1;
+    if (NS > NM) NS = NM;
+    if (NS > 6) return T;                 // (eight slow modes: no instance)
+    // LDS behind the cube: fit samples [2 nh], kappa: this block's mu [R][NS][2] and nu
+    // [R][NM][2], the previous block's mu [2 parity][R][NS][2], L [R][NM][2], P [20][NM][2],
+    // M [2 NS + 2 NM][2 nh]
     int nh = 0;
     for (int cand = 32; cand >= 16 && !nh; cand -= 8) {
-        const int bytes = 8 * (2 * cand + 4 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * 2 * cand);
+        const int bytes = 8 * (2 * cand + R * (3 * NS + NM) * 2 + R * NM * 2 + 20 * NM * 2 +
+                               (2 * NS + 2 * NM) * 2 * cand);
         if (bytes <= lds_budget) nh = cand;
     }
     if (!nh) return T;
@@ -595,20 +653,28 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
     std::vector<ld_t> Pinv;
     const ld_t ratio = pinv_qr(B, ns, nd, Pinv);
     T.fit_ratio = (double)ratio;
-    if (!(ratio > 1e-3L)) return T;
-    T.M.assign((size_t)4 * NM * ns, 0.0);
+    // (the fit's conditioning: the transform's rounding, 1e-16 of the signal, reaches the amplitudes
+    // multiplied by about 1 / ratio -- tests/test_spec_host.py measures 3e-17 / ratio of the output
+    // scale; 3e-7 keeps that at 1e-10.  The pair kernel's floor of 1e-3 refused six-section
+    // band-passes below 0.03 of Nyquist and every eight-section one.)
+    if (!(ratio > fit_floor)) return T;
+    // rows: Re mu [NS], Im mu [NS], Re nu [NM], Im nu [NM]
+    T.M.assign((size_t)(2 * NS + 2 * NM) * ns, 0.0);
     for (int side = 0; side < 2; ++side)
         for (int q = 0; q < nm; ++q) {
+            if (side == 0 && q >= NS) continue;                   // a fast mode's mu is nothing a row away
             int ja = -1, jb = -1;
             for (int j = 0; j < nd; ++j)
                 if (col_mode[j] == q && col_kind[j] / 2 == side) ((col_kind[j] & 1) ? jb : ja) = j;
             ld_t cr = -1.0L, ci = 0.0L;                           // nu = -(what the window's end shows)
             if (side == 0) mode_pow(modes[q], 256, cr, ci);       // mu = gamma lambda^256
+            const size_t rre = side == 0 ? (size_t)q : (size_t)(2 * NS + q);
+            const size_t rim = side == 0 ? (size_t)(NS + q) : (size_t)(2 * NS + NM + q);
             for (int i = 0; i < ns; ++i) {
                 const ld_t av = Pinv[(size_t)ja * ns + i];
                 const ld_t bv = jb >= 0 ? Pinv[(size_t)jb * ns + i] : 0.0L;
-                T.M[(size_t)((2 * side) * NM + q) * ns + i] = (double)(cr * av - ci * bv);
-                T.M[(size_t)((2 * side + 1) * NM + q) * ns + i] = (double)(ci * av + cr * bv);
+                T.M[rre * ns + i] = (double)(cr * av - ci * bv);
+                T.M[rim * ns + i] = (double)(ci * av + cr * bv);
             }
         }
     // the composite response at the quarter-shifted bins, / 4096: taps by Horner in z^-1
@@ -657,6 +723,7 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
     T.R = R;
     T.Rf = Rf;
     T.nh = nh;
+    T.NS = NS;
     T.eligible = true;
     return T;
 }

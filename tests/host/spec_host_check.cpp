@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <vector>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "spec_tables.h"
@@ -24,11 +25,11 @@ int main(int argc, char **argv) {
     fclose(f);
     if (argc == 4) {
         const osz::spec::TablesZp T = !strcmp(argv[3], "zpn")
-                                          ? osz::spec::build_zpn(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0)
+                                          ? osz::spec::build_zpn(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0, 15360 - 1024)
                                           : osz::spec::build_zp(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0);
         f = fopen(argv[2], "wb");
         if (!f) return 2;
-        const int32_t out[8] = {T.eligible, T.NR, T.NM, T.nm, T.R, T.nh, T.Rf, 0};
+        const int32_t out[8] = {T.eligible, T.NR, T.NM, T.nm, T.R, T.nh, T.Rf, T.NS};
         fwrite(out, sizeof(int32_t), 8, f);
         fwrite(&T.fit_ratio, sizeof(double), 1, f);
         for (const std::vector<double> *v : {&T.H, &T.M, &T.P, &T.L}) {

@@ -340,3 +340,48 @@ def test_reference_outputs_where_the_route_engages(dev, golden, fed):
     for c in range(x.shape[0]):
         scale = np.max(np.abs(want[c]))
         assert np.max(np.abs(got[c] - want[c])) < RTOL * scale, (c, np.max(np.abs(got[c] - want[c])) / scale)
+
+
+def _coverage_filters():
+    from openseize_amd.core import numerical as nm
+    from openseize_amd.filtering import iir
+    return [
+        ("headline", sps.butter(6, [0.05, 0.3], "bandpass", output="sos"), True),
+        ("Butter [8, 30] / [3, 60] Hz at 500 Hz", iir.Butter(fpass=[8, 30], fstop=[3, 60], fs=500, gpass=1, gstop=40).coeffs, True),
+        ("Cheby1 [200, 600] / [150, 650] Hz at 2500 Hz", iir.Cheby1(fpass=[200, 600], fstop=[150, 650], fs=2500).coeffs, False),
+        ("0.5-4 Hz at 5 kHz", sps.butter(4, [0.0002, 0.0016], "bandpass", output="sos"), False),
+        ("eight sections", sps.butter(8, [0.05, 0.3], "bandpass", output="sos"), True),
+        ("Notch(60, 8, 500)", nm._ba_to_sos(iir.Notch(60, 8, 500).coeffs)[0], True),
+    ]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", range(6))
+def test_routes_and_parity_of_realistic_cascades(dev, which):
+    """The six cascades of profiles/r04_zp_coverage.jsonl behind a 1024-tap FIR through the public
+    generators, against the oracle's oaconvolve('same') -> chunk-local sosfiltfilt
+    (core/numerical.py:158-298, :338-411) at 1e-9: the headline, the class-API cfg-3 of SURVEY 8d,
+    the reference's own Cheby1 test filter (tests/test_iir.py:132-158: nine sections), SURVEY 7's
+    stress filter, an eight-section band-pass, the Notch.  Four of them take the one-kernel
+    route (asserted); nine sections and a band 0.0002 of Nyquist wide stay on the separate kernels."""
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import producer
+    from openseize_amd.core import numerical as nm
+    name, sos, zp = _coverage_filters()[which]
+    sos = np.atleast_2d(np.asarray(sos, dtype=np.float64))
+    C, cs = 3, 65536
+    total = 6 * cs + 4321
+    taps = sps.firwin(1024, 0.2)
+    x = dev.synth_normal(C, total, seed=300 + which)
+    steps, plain = [], dev.chain_zp_step
+    dev.chain_zp_step = lambda *a, **k: (steps.append(1), plain(*a, **k))[1]
+    try:
+        src = producer(x, cs, -1)
+        fir = producer(partial(nm.oaconvolve, src, taps, -1, "same"), cs, -1, shape=src.shape)
+        got = torch.cat([c for c in nm.sosfiltfilt(fir, sos, -1)], -1).cpu().numpy()
+    finally:
+        dev.chain_zp_step = plain
+    assert len(steps) == (5 if zp else 0), (name, len(steps))
+    want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(x.cpu().numpy(), taps, "same"), -1), sos, cs)
+    assert np.max(np.abs(got - want)) < RTOL * np.max(np.abs(want)), name

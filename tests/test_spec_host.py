@@ -212,15 +212,15 @@ def tables_zp(exe, taps, sos, forgets=True, mode="zp"):
             f.write(sos.tobytes())
         subprocess.check_call([exe, fin, fout, mode])
         raw = open(fout, "rb").read()
-    elig, NR, NM, nm, R, nh, Rf, _ = struct.unpack_from("<iiiiiiii", raw, 0)
+    elig, NR, NM, nm, R, nh, Rf, NS = struct.unpack_from("<iiiiiiii", raw, 0)
     ratio, = struct.unpack_from("<d", raw, 32)
     pos, arrs = 40, []
     for _ in range(4):
         n, = struct.unpack_from("<q", raw, pos)
         arrs.append(np.frombuffer(raw, np.float64, n, pos + 8).copy())
         pos += 8 + 8 * n
-    return dict(eligible=bool(elig), NR=NR, NM=NM, nm=nm, R=R, Rf=Rf, nh=nh, ratio=ratio, H=arrs[0], M=arrs[1],
-                P=arrs[2], L=arrs[3])
+    return dict(eligible=bool(elig), NR=NR, NM=NM, nm=nm, R=R, Rf=Rf, nh=nh, NS=NS, ratio=ratio, H=arrs[0],
+                M=arrs[1], P=arrs[2], L=arrs[3])
 
 
 class ModelZp:
@@ -411,12 +411,13 @@ class ModelZpn:
 
     def __init__(self, T):
         self.NB, self.NM, self.R, self.Rf, self.nh = T["NR"], T["NM"], T["R"], T["Rf"], T["nh"]
+        self.NS = NS = T["NS"]
         self.S, self.D, self.L = 256 * self.NB, 32 - self.NB, 256 * T["R"]
         H = T["H"].reshape(N, 2)
         self.Hq = (H[:, 0] + 1j * H[:, 1]) * N
-        M = T["M"].reshape(4 * self.NM, 2 * self.nh)
-        self.Mmu = M[:self.NM] + 1j * M[self.NM:2 * self.NM]
-        self.Mnu = M[2 * self.NM:3 * self.NM] + 1j * M[3 * self.NM:]
+        M = T["M"].reshape(2 * NS + 2 * self.NM, 2 * self.nh)
+        self.Mmu = M[:NS] + 1j * M[NS:2 * NS]                        # the slow modes' right tails only
+        self.Mnu = M[2 * NS:2 * NS + self.NM] + 1j * M[2 * NS + self.NM:]
         P = T["P"].reshape(20, self.NM, 2)
         P = P[..., 0] + 1j * P[..., 1]
         t = np.arange(256)
@@ -438,9 +439,15 @@ class ModelZpn:
         return self.Mmu @ y, self.Mnu @ y
 
     def burst(self, amp, e, rows):
+        """Re sum_q amp_q lambda_q^e over the modes `amp` names -- mu: the NS slow ones; nu: all NM
+        in its first row of 256 samples, the slow ones behind it"""
         ok = (e >= 0) & (e < 256 * rows)
         ee = np.where(ok, e, 0)
-        return np.where(ok, np.real((self.Lr[ee >> 8] * self.P[ee & 255]) @ amp), 0.0)
+        nq = len(amp)
+        terms = (self.Lr[ee >> 8, :nq] * self.P[ee & 255, :nq]) * amp
+        if nq > self.NS:
+            terms[ee >= 256, self.NS:] = 0.0
+        return np.where(ok, np.real(terms.sum(-1)), 0.0)
 
     def chunk(self, x, carry_in, held_in, nruns):
         n, S, NB, D, R, L, Rf = len(x), self.S, self.NB, self.D, self.R, self.L, self.Rf
@@ -465,7 +472,7 @@ class ModelZpn:
             p0, p1 = run * W // nruns, (run + 1) * W // nruns
             first, lastf = (p0 if run == 0 else p0 - 1), p1 - 1
             cr = np.zeros((D, 256))
-            mu_p = np.zeros(self.NM, complex)
+            mu_p = np.zeros(self.NS, complex)
             held = None
             for p in range(first, lastf + 1):
                 o = p * S
@@ -521,6 +528,9 @@ class ModelZpn:
 ZPN_CASES = ZP_CASES + [
     ("the identity as the FIR (plain sosfiltfilt)", 2, sps.butter(6, [0.05, 0.3], "bandpass", output="sos")),
     ("cheby1 low-pass, 57 taps", 57, sps.cheby1(5, 1, 0.2, output="sos")),
+    ("eight sections (eight modes), 1024 taps", 1024, sps.butter(8, [0.05, 0.3], "bandpass", output="sos")),
+    ("Butter [8, 30] / [3, 60] Hz at 500 Hz (SURVEY 8d's class-API cfg-3), 1024 taps", 1024,
+     sps.butter(6, [8 / 250, 30 / 250], "bandpass", output="sos")),
 ]
 
 
@@ -534,6 +544,7 @@ def test_single_block_tables_and_block_algorithm(exe, name, ntaps, sos):
     assert T["eligible"], name
     NB, R, Rf = T["NR"], T["R"], T["Rf"]
     assert 24 <= NB <= min((7937 - ntaps) // 256, 30) and 1 <= Rf <= R <= min(32 - NB, 5) and 32 - NB + Rf <= NB
+    assert T["NS"] in (2, 4, 6) and T["NS"] <= T["NM"] <= 8
     wq = 2 * np.pi * (np.arange(N) + 0.25) / N
     _, h = sps.sosfreqz(sos, worN=wq)
     Hq = np.polyval(taps[::-1], np.exp(-1j * wq)) * np.abs(h) ** 2 / N
@@ -547,7 +558,7 @@ def test_single_block_tables_and_block_algorithm(exe, name, ntaps, sos):
     u = np.convolve(x, taps)
     zi0 = sps.sosfilt_zi(sos) * u[0]
     f, _ = sps.sosfilt(sos, u, zi=zi0)
-    ref = sps.sosfilt(sos, np.concatenate([f, np.zeros(8192)])[::-1])[::-1][:len(f)]
+    ref = sps.sosfilt(sos, np.concatenate([f, np.zeros(32768)])[::-1])[::-1][:len(f)]
     zir = sps.sosfilt(sos, np.zeros(7680), zi=zi0)[0]
     carry, held = sps.sosfilt(sos, zir[::-1])[::-1], np.zeros(L)
     out, o = [], 0
@@ -557,4 +568,7 @@ def test_single_block_tables_and_block_algorithm(exe, name, ntaps, sos):
         o += n
     got = np.concatenate(out)
     assert np.isfinite(got).all()
-    assert np.max(np.abs(got[L:] - ref[:len(got) - L])) < 3e-12 * np.max(np.abs(ref)), name
+    # the fit's conditioning sets the floor: the transform's rounding reaches the amplitudes
+    # multiplied by about 1 / ratio (spec::build_zpn admits ratio > 3e-7)
+    tol = max(3e-12, 1e-16 / T["ratio"])
+    assert tol < 4e-10 and np.max(np.abs(got[L:] - ref[:len(got) - L])) < tol * np.max(np.abs(ref)), name
