@@ -8,6 +8,7 @@
 #include "fft4096.h"
 #include "fir_pair.h"
 #include "handles.h"
+#include "nega_window.h"
 
 namespace osz {
 
@@ -70,39 +71,6 @@ __device__ __forceinline__ double zp_dot(const double *kk, const double *pr, con
     for (int q = 0; q < NM; ++q) c = fma(kk[2 * q], pr[q], fma(-kk[2 * q + 1], pi[q], c));
     return c;
 }
-
-// A block's (a pair's) rows of 256 samples, requested by LDS-DMA into the cube.  A wave
-// owns, in every 4 KB plane of the cube, the 1 KB piece [1024 w, 1024 w + 1024) -- the slots it
-// reads last in a transform (inverse pass 1, view A) and writes first in the next one (pass 1) --
-// so between the two nobody else touches it: piece m takes the wave's 64 samples of rows 2 m and
-// 2 m + 1 (one 16-byte request per lane: lanes 0-31 row 2 m, lanes 32-63 row 2 m + 1), and the
-// wave reads its own requests back behind its own vmcnt wait -- no barrier, no registers held
-// while the samples are on their way.
-// NP pieces = 2 NP rows from src on; rows >= nrows (an odd count's last half piece) lie behind the
-// descriptor's range: their lanes request nothing.
-template <int NP>
-__device__ __forceinline__ void zp_request_rows(const double *src, int nrows, int t, const void *cube) {
-    int tq = t;
-    asm volatile("" : "+v"(tq));     // per block, not hoisted
-    const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(src), 0, 2048 * nrows, 0x00020000);
-    const unsigned voff = 2048u * (((unsigned)tq >> 5) & 1u) + 512u * ((unsigned)tq >> 6) + 16u * ((unsigned)tq & 31u);
-    const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(cube) +
-                                                         1024u * ((unsigned)tq >> 6));
-#pragma unroll
-    for (int m = 0; m < NP; ++m) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %1\n\t"
-                     "s_nop 0\n\t"
-                     "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "s"(ldsb + 4096u * m), "v"(voff + 4096u * m), "s"(rx)   // (the range check sees the lane offset)
-                     : "memory");
-    }
-}
-
 
 // chain_zpn_*.hip: the kernel for NB rows per block (24 .. 30), NM modes (2, 4, 6, 8) of which the
 // first NS (2, 4, 6) are slow

@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include "chain_zp.h"
+#include "nega_window.h"
 
 namespace osz {
 
@@ -180,59 +181,6 @@ __device__ __forceinline__ void zpn_bwd_bursts(double *im, double *c7, const dou
     }
 }
 
-// the transform of a block's window in place: pack, forward, x spectrum, inverse, unpack
-template <int NHI>
-struct NegaWindow {
-    using C2 = fft::cube::C2;
-    const FirArgs &a;
-    C2 *L;
-    const C2 *tw2l;               // [16 n0][4]: W256^(n0 2^q) in LDS (sixteen distinct rows: not worth registers)
-    fft::nega::TwPowN tw1;
-
-    __device__ __forceinline__ void load_tw2(int t, fft::cube::TwPow &w) const {
-        const C2 *p = tw2l + 4 * (t & 15);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const C2 v = p[q];
-            w.r[q] = v.re;
-            w.i[q] = v.im;
-        }
-    }
-
-    __device__ __forceinline__ void transform(int t_in, double *re, double *im) {
-        // LDS slot numbers are recomputed per block from an opaque copy of the thread index:
-        // hoisted out of the loop they would pin registers
-        int t = t_in;
-        asm volatile("" : "+v"(t));
-        fft::nega::f1<NHI>(t, re, im, tw1, L);
-        __syncthreads();
-        fft::cube::TwPow tw2;
-        load_tw2(t, tw2);
-        fft::cube2::f2(t, re, im, tw2, L);
-        // the spectrum of the pair's sixteen bins is requested before the fence (from L2: resident
-        // it spills); base and bin row in scalar registers, one 32-bit lane offset (buf_rsrc)
-        double hr[16], hi[16];
-        const unsigned lane16 = 16u * ((unsigned)t & 255u);
-        const __amdgpu_buffer_rsrc_t rh = buf_rsrc(a.H);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const buf_d2 h = buf_load2(rh, lane16, 4096u * r);
-            hr[r] = h.x;
-            hi[r] = h.y;
-        }
-        wave_lds_fence();
-        fft::cube2::f3(t, re, im, L);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) fft::cube::cmul(re[r], im[r], hr[r], hi[r]);
-        fft::cube2::i3(t, re, im, L);
-        wave_lds_fence();
-        load_tw2(t, tw2);
-        fft::cube2::i2(t, re, im, tw2, L);
-        __syncthreads();
-        fft::nega::i1(t, re, im, tw1, L);
-    }
-};
-
 template <int NB, int NM, int NS>
 __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     constexpr int D = 32 - NB, S = 256 * NB, NHI = NB - 16, NP = (NB + 1) / 2;
@@ -336,13 +284,9 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 im[j] = (j < NHI && 4096 + 256 * j + t < la) ? xc[4096 + 256 * j] : 0.0;
             }
         }
-        P.transform(t, re, im);
-        if (!closing && p < lastf) {
-            // inverse pass 1 has read this wave's pieces of the cube: the next block's samples can
-            // land there while fit, bursts and stores run
-            asm volatile("s_waitcnt lgkmcnt(0) ; osz:dma" ::: "memory");
-            zp_request_rows<NP>(xr + o + S, NB, t, cube_lds);
-        }
+        // (the next block's samples are requested inside, once inverse pass 1 has read this wave's
+        // pieces of the cube: they land while its arithmetic, fit, bursts and stores run)
+        P.template transform<NP>(t, re, im, (!closing && p < lastf) ? xr + o + S : nullptr, NB);
         int nst = 0;             // row stores of this block, -1: some went another way
         int tt = t;
         asm volatile("" : "+v"(tt));

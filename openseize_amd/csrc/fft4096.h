@@ -536,16 +536,26 @@ OSZ_HD void f1(int t, double *re, double *im, const TwPowN &w1, C2 *L) {
     for (int r = 0; r < 16; ++r) L[cube2::slot_a(t, dr(r))] = C2{re[r], im[r]};
 }
 
-OSZ_HD void i1(int t, double *re, double *im, const TwPowN &w1, const C2 *L) {
+// (in two halves: once the loads have returned the thread's slots of the cube are free -- the
+// kernels request the next block's samples into them before the arithmetic below)
+OSZ_HD void i1_load(int t, double *re, double *im, const C2 *L) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const C2 v = L[cube2::slot_a(t, dr(r))];
         re[r] = v.re;
         im[r] = v.im;
     }
+}
+
+OSZ_HD void i1_finish(double *re, double *im, const TwPowN &w1) {
     tw_mul<true>(re, im, w1);
     inv16(re, im);
     unpack(re, im);
+}
+
+OSZ_HD void i1(int t, double *re, double *im, const TwPowN &w1, const C2 *L) {
+    i1_load(t, re, im, L);
+    i1_finish(re, im, w1);
 }
 
 }  // namespace nega

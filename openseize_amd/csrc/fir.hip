@@ -32,6 +32,7 @@
 #include "fir_pair.h"
 #include "fir_pf_table.h"
 #include "handles.h"
+#include "nega_window.h"
 
 namespace osz {
 
@@ -103,6 +104,130 @@ __global__ __launch_bounds__(256, 2) void fir_oa_kernel(FirArgs a) {
     for (int j = 0; j < 16 - NR; ++j) {
         const int p = 256 * j + t;
         if (p < P.wm1) tl[p] = P.cr[j];
+    }
+}
+
+
+// ---- one real block per transform (fft::nega, fft4096.h) -------------------------------
+// The pair kernel above pays the filter's tail (ntaps - 1 samples) once per 4096-sample window:
+// 12 of 16 rows carry samples at 1024 taps.  Here a window is 8192 samples of ONE real block on
+// the same 4096-point transform (odd frequencies, negacyclic wrap -- nothing wraps, the block is
+// NB <= (8193 - ntaps) / 256 rows): 28 of 32 rows at 1024 taps.  A block's rows come in by
+// LDS-DMA behind the previous block's transform (zp_request_rows, nega_window.h: into the
+// wave's own pieces of the cube, read back behind the wave's own vmcnt wait), the spectrum is
+// requested per block from L2, the W256 twiddle rows live in LDS.  Runs, tails and the seam
+// kernel are the pair kernel's: a run starts with a zero tail and publishes its last one.
+// Blocks start at multiples of 256 samples, so a block's tail rows are the next block's first
+// rows in the SAME thread: ragged and cut blocks need no staging through LDS either.
+template <int NB>
+__global__ __launch_bounds__(256, 2) void fir_nega_kernel(FirArgs a) {
+    constexpr int D = 32 - NB, S = 256 * NB, NHI = NB - 16, NP = (NB + 1) / 2;
+    static_assert(NB >= 24 && NB <= 31, "rows per block");
+    extern __shared__ fft::cube::C2 cube_lds[];
+    fft::cube::C2 *tw2l = cube_lds + fft::cube::SLOTS;                 // [16][4]
+    const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
+    const int wm1 = a.wlen - 1;
+    const double *xr = a.x + (int64_t)c * a.ldx;
+    double *yr = a.y + (int64_t)c * a.ldy;
+    const int blk0 = (int)fir_run_start(run, a.nblocks, a.nruns);
+    const int blk1 = (int)fir_run_start(run + 1, a.nblocks, a.nruns);
+    NegaWindow<NHI> P{a, cube_lds, tw2l};
+    {
+        fft::cube::TwPow w2;
+        fft::nega::tw_load(t, a.tb, P.tw1, w2);
+        if (t < 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tw2l[4 * t + q] = fft::cube::C2{w2.r[q], w2.i[q]};
+        }
+    }
+    double cr[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) cr[j] = 0.0;
+    auto whole = [&](int blk) { return (int64_t)(blk + 1) * S <= a.n && (int64_t)blk * S >= a.skip && !a.accum; };
+    bool requested = false;          // this block's rows are on their way into the cube
+    int younger = -1;                // vector-memory operations issued behind that request
+    bool tail_in_cr = true;
+    if (blk0 < blk1 && whole(blk0)) {
+        zp_request_rows<NP>(xr + (int64_t)blk0 * S, NB, t, cube_lds);
+        requested = true;
+        younger = 0;
+    }
+    __syncthreads();
+    for (int blk = blk0; blk < blk1; ++blk) {
+        const int64_t o = (int64_t)blk * S;
+        double re[16], im[16];
+        int tq = t;
+        asm volatile("" : "+v"(tq));
+        const bool fast = whole(blk);
+        const int64_t rem = a.n - o;
+        const int len = rem < S ? (int)rem : S;
+        if (requested) {
+            if (younger == NB) asm volatile("s_waitcnt vmcnt(%0) ; osz:dma" ::"n"(NB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) ; osz:dma" ::: "memory");
+            const double *xs = reinterpret_cast<const double *>(cube_lds) + 128 * (tq >> 6) + (tq & 63);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = xs[512 * (j >> 1) + 64 * (j & 1)];
+                im[j] = j < NHI ? xs[512 * ((j + 16) >> 1) + 64 * ((j + 16) & 1)] : 0.0;
+            }
+        } else {
+            const double *xc = xr + o + tq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = 256 * j + tq < len ? xc[256 * j] : 0.0;
+                im[j] = (j < NHI && 4096 + 256 * j + tq < len) ? xc[4096 + 256 * j] : 0.0;
+            }
+        }
+        requested = blk + 1 < blk1 && whole(blk + 1);
+        P.template transform<NP>(t, re, im, requested ? xr + o + S : nullptr, NB);
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        // the previous block's tail: rows NB .. 31 of its window are rows 0 .. D-1 of this one
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (256 * j + tt < wm1) re[j] += cr[j];
+        if (fast) {
+            const unsigned lane8 = 8u * (unsigned)tt;
+            const __amdgpu_buffer_rsrc_t ry = buf_rsrc(yr + (o - a.skip));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                buf_store(re[j], ry, lane8, 2048u * j);
+                if (j < NHI) buf_store(im[j], ry, lane8, 2048u * (j + 16));
+            }
+            younger = NB;
+        } else {
+            // ragged (the push's last block), cut on the left ('same' / 'valid') or accumulating
+            // (a piece of a partitioned filter)
+            younger = -1;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int pp = 256 * j + tt;
+                const double v = j < 16 ? re[j & 15] : im[j & 15];
+                const int64_t oq = o + pp - a.skip;
+                if (pp < len && oq >= 0) yr[oq] = a.accum ? yr[oq] + v : v;
+            }
+        }
+        if (len == S) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) cr[j] = im[NHI + j];
+        } else {
+            // the push ends inside this block: its tail starts at sample `len`, off the rows
+            tail_in_cr = false;
+            double *tl = a.tails + ((int64_t)c * a.nruns + run) * wm1;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int q = 256 * j + tt - len;
+                if (q >= 0 && q < wm1) tl[q] = j < 16 ? re[j & 15] : im[j & 15];
+            }
+        }
+    }
+    if (tail_in_cr) {
+        double *tl = a.tails + ((int64_t)c * a.nruns + run) * wm1;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int p = 256 * j + t;
+            if (p < wm1) tl[p] = cr[j];
+        }
     }
 }
 
@@ -290,6 +415,47 @@ static int fir_build_part(FirPart &pt, const double *taps, int ntaps, int nch) {
         H[2 * k] = (double)(fr[k] / fft::N);
         H[2 * k + 1] = (double)(fi[k] / fft::N);
     }
+    // the same response at the quarter-shifted bins 2 pi (j + 1/4) / 4096 for fir_nega_kernel: the
+    // taps twisted by e^{-i 2 pi m / 16384}, the same transform; stored in the order fft::cube2
+    // leaves the bins in ([r][t])
+    pt.dHn = nullptr;
+    pt.stepn = 0;
+    if (ntaps >= 2 && ntaps <= kFirMaxTaps) {
+        int nb = (2 * fft::N + 1 - ntaps) / 256;
+        if (nb > 31) nb = 31;
+        pt.stepn = 256 * nb;
+        std::fill(fr.begin(), fr.end(), 0.0L);
+        std::fill(fi.begin(), fi.end(), 0.0L);
+        for (int m = 0; m < ntaps; ++m) {
+            unsigned r = 0;
+            for (int b = 0; b < 12; ++b) r |= ((unsigned)(m >> b) & 1u) << (11 - b);
+            const long double ang = -2.0L * PI * (long double)m / (4.0L * fft::N);
+            fr[r] = (long double)taps[m] * cosl(ang);
+            fi[r] = (long double)taps[m] * sinl(ang);
+        }
+        for (int len = 2; len <= fft::N; len <<= 1) {
+            const int half = len >> 1, tstep = fft::N / len;
+            for (int base = 0; base < fft::N; base += len)
+                for (int j = 0; j < half; ++j) {
+                    const long double c = wc[j * tstep], sn = ws[j * tstep];
+                    const int u = base + j, v = u + half;
+                    const long double tr = fr[v] * c - fi[v] * sn, ti = fr[v] * sn + fi[v] * c;
+                    fr[v] = fr[u] - tr;
+                    fi[v] = fi[u] - ti;
+                    fr[u] += tr;
+                    fi[u] += ti;
+                }
+        }
+        std::vector<double> Hn(2 * fft::N);
+        for (int r = 0; r < 16; ++r)
+            for (int t = 0; t < 256; ++t) {
+                const int k = fft::cube2::bin(t, r);
+                Hn[2 * (256 * r + t)] = (double)(fr[k] / fft::N);
+                Hn[2 * (256 * r + t) + 1] = (double)(fi[k] / fft::N);
+            }
+        OSZ_HIP(hipMalloc(&pt.dHn, Hn.size() * sizeof(double)));
+        OSZ_HIP(hipMemcpy(pt.dHn, Hn.data(), Hn.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     const size_t sb = sizeof(double) * (size_t)nch * (ntaps > 1 ? ntaps - 1 : 1);
     OSZ_HIP(hipMalloc(&pt.dH, H.size() * sizeof(double)));
     OSZ_HIP(hipMalloc(&pt.dstate[0], sb));
@@ -304,7 +470,15 @@ static int fir_build_part(FirPart &pt, const double *taps, int ntaps, int nch) {
 static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx, int64_t n,
                          double *y, int64_t ldy, int64_t skip, int accum, hipStream_t st) {
     const int wm1 = pt.ntaps - 1;
-    const int64_t nblocks = (n + pt.step - 1) / pt.step;
+    // one real block per transform (fir_nega_kernel) where its tables exist; OSZ_FIR_NEGA=0: the
+    // pair kernel, for comparison
+    static const bool nega_on = [] {
+        const char *e = getenv("OSZ_FIR_NEGA");
+        return !(e && e[0] == '0');
+    }();
+    const bool nega = nega_on && pt.dHn != nullptr && wm1 >= 1;
+    const int step = nega ? pt.stepn : pt.step;
+    const int64_t nblocks = (n + step - 1) / step;
     // run length: long runs (every workgroup pays for its twiddle loads, its tail
     // and its seam) as long as about 3/4 of the 512 workgroup slots stay busy --
     // measured at 16..256 channels, runs of an even number of blocks
@@ -364,15 +538,25 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
     a.n = n;
     a.skip = skip;
     a.wlen = pt.ntaps;
-    a.step = pt.step;
+    a.step = step;
     a.R = (int)R;
     a.nruns = (int)nruns;
     a.accum = accum;
     a.nblocks = nblocks;
-    a.H = pt.dH;
+    a.H = nega ? pt.dHn : pt.dH;
     a.tb = h->tb;
     a.tails = h->dtails;
-    {
+    if (nega) {
+        using kern_t = void (*)(FirArgs);
+        static const kern_t kn[8] = {fir_nega_kernel<24>, fir_nega_kernel<25>, fir_nega_kernel<26>,
+                                     fir_nega_kernel<27>, fir_nega_kernel<28>, fir_nega_kernel<29>,
+                                     fir_nega_kernel<30>, fir_nega_kernel<31>};
+        const int nb = step / 256;
+        const size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS + 1024;
+        OSZ_DYN_LDS(kn[nb - 24], lds);
+        KernelTimer kt("fir_oa", st);
+        hipLaunchKernelGGL(kn[nb - 24], dim3((unsigned)nruns, h->nch), dim3(256), lds, st, a);
+    } else {
         using kern_t = void (*)(FirArgs);
         // rows per block: 8 (2049 taps) .. 15 (<= 257 taps)
         static const kern_t kerns0[8] = {fir_oa_kernel<8>,  fir_oa_kernel<9>,  fir_oa_kernel<10>,
@@ -409,7 +593,7 @@ static int fir_part_push(osz_fir_s *h, FirPart &pt, const double *x, int64_t ldx
         s.n = n;
         s.skip = skip;
         s.wlen = pt.ntaps;
-        s.step = pt.step;
+        s.step = step;
         s.nruns = (int)nruns;
         s.nblocks = nblocks;
         s.tails = h->dtails;
@@ -480,6 +664,7 @@ int osz_fir_destroy(osz_fir_t h) {
     zp_unlink(h->zp);
     for (auto &pt : h->parts) {
         (void)hipFree(pt.dH);
+        (void)hipFree(pt.dHn);
         (void)hipFree(pt.dstate[0]);
         (void)hipFree(pt.dstate[1]);
     }

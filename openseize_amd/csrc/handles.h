@@ -18,6 +18,8 @@ struct ChainZp;     // chain_zp.hip: the same pair on the zero-phase kernel
 struct FirPart {
     int ntaps, step;
     double *dH;         // [4096][2]
+    double *dHn;        // fir_nega_kernel: the response at the quarter-shifted bins, [r][t] (fft::cube2::bin), or null
+    int stepn;          // its block length: 256 rows-per-block
     double *dstate[2];  // ping-pong carried tails [nch][ntaps-1]
     int cur;
 };

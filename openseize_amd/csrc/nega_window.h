@@ -1,0 +1,112 @@
+// nega_window.h -- one real block of up to 8192 samples through fft::nega (fft4096.h) inside a
+// 256-thread workgroup: what the zero-phase chain kernel (chain_zpn_body.h) and the overlap-add
+// FIR kernel on one block per transform (fir.hip: fir_nega_kernel) share -- the window's
+// transform with the filter's spectrum applied, and the request of a block's rows by LDS-DMA
+// (zp_request_rows, chain_zp.h).
+#pragma once
+
+#include "common.h"
+#include "fft4096.h"
+#include "fir_pair.h"
+
+namespace osz {
+
+// A block's (a pair's) rows of 256 samples, requested by LDS-DMA into the cube.  A wave
+// owns, in every 4 KB plane of the cube, the 1 KB piece [1024 w, 1024 w + 1024) -- the slots it
+// reads last in a transform (inverse pass 1, view A) and writes first in the next one (pass 1) --
+// so between the two nobody else touches it: piece m takes the wave's 64 samples of rows 2 m and
+// 2 m + 1 (one 16-byte request per lane: lanes 0-31 row 2 m, lanes 32-63 row 2 m + 1), and the
+// wave reads its own requests back behind its own vmcnt wait -- no barrier, no registers held
+// while the samples are on their way.
+// NP pieces = 2 NP rows from src on; rows >= nrows (an odd count's last half piece) lie behind the
+// descriptor's range: their lanes request nothing.
+template <int NP>
+__device__ __forceinline__ void zp_request_rows(const double *src, int nrows, int t, const void *cube) {
+    int tq = t;
+    asm volatile("" : "+v"(tq));     // per block, not hoisted
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(src), 0, 2048 * nrows, 0x00020000);
+    const unsigned voff = 2048u * (((unsigned)tq >> 5) & 1u) + 512u * ((unsigned)tq >> 6) + 16u * ((unsigned)tq & 31u);
+    const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(cube) +
+                                                         1024u * ((unsigned)tq >> 6));
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(ldsb + 4096u * m), "v"(voff + 4096u * m), "s"(rx)   // (the range check sees the lane offset)
+                     : "memory");
+    }
+}
+
+
+
+// the transform of a block's window in place: pack, forward, x spectrum, inverse, unpack
+template <int NHI>
+struct NegaWindow {
+    using C2 = fft::cube::C2;
+    const FirArgs &a;
+    C2 *L;
+    const C2 *tw2l;               // [16 n0][4]: W256^(n0 2^q) in LDS (sixteen distinct rows: not worth registers)
+    fft::nega::TwPowN tw1;
+
+    __device__ __forceinline__ void load_tw2(int t, fft::cube::TwPow &w) const {
+        const C2 *p = tw2l + 4 * (t & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const C2 v = p[q];
+            w.r[q] = v.re;
+            w.i[q] = v.im;
+        }
+    }
+
+    // next: where the NEXT block's rows begin (nrows of them), or null -- requested by LDS-DMA as
+    // soon as inverse pass 1 has read this wave's pieces of the cube, ahead of its arithmetic:
+    // they land while that, the caller's epilogue and its stores run
+    template <int NP = 1>
+    __device__ __forceinline__ void transform(int t_in, double *re, double *im, const double *next = nullptr,
+                                              int nrows = 0) {
+        // LDS slot numbers are recomputed per block from an opaque copy of the thread index:
+        // hoisted out of the loop they would pin registers
+        int t = t_in;
+        asm volatile("" : "+v"(t));
+        fft::nega::f1<NHI>(t, re, im, tw1, L);
+        __syncthreads();
+        fft::cube::TwPow tw2;
+        load_tw2(t, tw2);
+        fft::cube2::f2(t, re, im, tw2, L);
+        // the spectrum of the pair's sixteen bins is requested before the fence (from L2: resident
+        // it spills); base and bin row in scalar registers, one 32-bit lane offset (buf_rsrc)
+        double hr[16], hi[16];
+        const unsigned lane16 = 16u * ((unsigned)t & 255u);
+        const __amdgpu_buffer_rsrc_t rh = buf_rsrc(a.H);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const buf_d2 h = buf_load2(rh, lane16, 4096u * r);
+            hr[r] = h.x;
+            hi[r] = h.y;
+        }
+        wave_lds_fence();
+        fft::cube2::f3(t, re, im, L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fft::cube::cmul(re[r], im[r], hr[r], hi[r]);
+        fft::cube2::i3(t, re, im, L);
+        wave_lds_fence();
+        load_tw2(t, tw2);
+        fft::cube2::i2(t, re, im, tw2, L);
+        __syncthreads();
+        fft::nega::i1_load(t, re, im, L);
+        if (next) {
+            asm volatile("s_waitcnt lgkmcnt(0) ; osz:dma" ::: "memory");
+            zp_request_rows<NP>(next, nrows, t_in, L);
+        }
+        fft::nega::i1_finish(re, im, tw1);
+    }
+};
+
+
+}  // namespace osz
