@@ -29,7 +29,8 @@ int main() {
     hipMalloc(&st, nst * 8);
     hipMemset(st, 0, nst * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(osz::g_sos_stamps), &st, sizeof(st));
-    setenv("OSZ_SOS_WGS", "1", 1);   // no time split: one workgroup per channel
+    // (256 channels: the launch is one workgroup per channel and segment as the library cuts it;
+    // the OSZ_SOS_WGS knob that forced one workgroup per channel left with the other knobs)
     osz_sos_forward(h, x, n, y, n, n, nullptr);
     hipDeviceSynchronize();
     hipEvent_t e0, e1;

@@ -356,13 +356,17 @@ def _threaded_copy(dst, src):
     if dst.size < (1 << 16):
         np.copyto(dst, src)
         return
-    if (src.ndim == 2 and src.dtype == dst.dtype and src.shape == dst.shape and cols > 0
+    fast = (src.ndim == 2 and src.dtype == dst.dtype and src.shape == dst.shape and cols > 0
             and src.strides[1] == src.itemsize and dst.strides[1] == dst.itemsize
-            and src.strides[0] >= cols * src.itemsize and dst.strides[0] >= cols * dst.itemsize):
+            and src.strides[0] >= cols * src.itemsize and dst.strides[0] >= cols * dst.itemsize)
+    if fast:
         # a column range of a C-ordered array: rows a pitch apart -- the library's own threads
         # (Python's pool spends most of a 4 MB copy waking its workers)
         _lib.check(_lib.load().osz_host_copy2d(dst.ctypes.data, dst.strides[0], src.ctypes.data, src.strides[0],
                                                rows, cols * src.itemsize))
+        return
+    if dst.size < (1 << 18):       # (Python's pool costs more than it gains below a couple of MB)
+        np.copyto(dst, src)
         return
     parts = 8
     if rows >= parts:

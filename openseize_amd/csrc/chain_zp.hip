@@ -645,6 +645,8 @@ struct ChainZp {
     int hcur = 0;
     int64_t hist_n = 0;
     double *dscratch = nullptr;
+    double *dfin = nullptr;        // osz_chain_zp_finish: the kernel's outputs for the head of what follows
+    size_t fin_cap = 0;            // doubles
     double *dzero = nullptr;       // (nsec, nch, 2) zeros: start state of the opening's backward pass
 };
 
@@ -679,6 +681,7 @@ static void zp_free(ChainZp *s) {
     }
     (void)hipFree(s->dnanpos);
     (void)hipFree(s->dscratch);
+    (void)hipFree(s->dfin);
     (void)hipFree(s->dzero);
     delete s;
 }
@@ -974,17 +977,24 @@ int osz_chain_zp_finish(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t l
         OSZ_REQUIRE(x && y && m >= zp_min_chunk(s) && ldx >= m && ny <= m - zp_min_chunk(s) / 2 &&
                         ldy >= ny,
                     "osz_chain_zp_finish: %lld output samples from %lld input samples", (long long)ny, (long long)m);
-        // through a scratch output: the kernel writes all m of them
-        double *tmp = nullptr;
-        OSZ_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)nch * m));
-        int rc = zp_launch(s, x, ldx, m, nullptr, 0, 0, tmp, m, st);
-        if (rc == OSZ_OK)
-            rc = hipMemcpy2DAsync(y, sizeof(double) * ldy, tmp, sizeof(double) * m, sizeof(double) * ny, nch,
-                                  hipMemcpyDeviceToDevice, st) == hipSuccess ? OSZ_OK
-                                                                            : fail(OSZ_ERR_HIP, "osz_chain_zp_finish: copy");
-        (void)hipStreamSynchronize(st);
-        (void)hipFree(tmp);
+        // through a scratch output of the link's own (the kernel writes all m of them), grown on
+        // demand and kept: nothing here waits for the stream
+        const size_t want = (size_t)nch * (size_t)m;
+        if (want > s->fin_cap) {
+            if (s->dfin) {
+                OSZ_HIP(hipStreamSynchronize(st));        // an earlier finish may still read it
+                OSZ_HIP(hipFree(s->dfin));
+                s->dfin = nullptr;
+                s->fin_cap = 0;
+            }
+            if (hipMalloc(&s->dfin, sizeof(double) * want) != hipSuccess)
+                return fail(OSZ_ERR_NOMEM, "osz_chain_zp_finish: scratch of %zu doubles", want);
+            s->fin_cap = want;
+        }
+        int rc = zp_launch(s, x, ldx, m, nullptr, 0, 0, s->dfin, m, st);
         if (rc) return rc;
+        OSZ_HIP(hipMemcpy2DAsync(y, sizeof(double) * ldy, s->dfin, sizeof(double) * m, sizeof(double) * ny, nch,
+                                 hipMemcpyDeviceToDevice, st));
     }
     s->open = false;
     return OSZ_OK;

@@ -74,7 +74,7 @@ struct osz_sos_s {
 };
 
 namespace osz {
-// false under OSZ_SOS_NANFIX=0 (A/B knob, sos.hip)
+// the NaN reach of the reference is reproduced (always; the A/B knob of round 2 is gone)
 bool sos_nanfix();
 // NaN reach of a forward pass cut into runs (sos.hip): a small launch behind the pass
 int sos_seal_launch(double *y, int64_t ldy, int64_t n, int nseg, int64_t A, int64_t B, int64_t C, double *state,

@@ -4,8 +4,15 @@
 // an H2D stream it has to be packed into a pinned staging buffer, and at the reference's own
 // chunk size (30 000 samples, cfg-1) that packing IS the per-chunk cost of the host-fed path:
 // Python's thread pool spends 0.3 ms per 3.8 MB chunk mostly on waking its workers.  Here
-// the workers spin briefly for the next job before they sleep, a job is a handful of memcpy
-// calls per worker, and the call returns when the rows are in place.
+// the workers sleep on a condition variable between jobs, a job is a handful of memcpy calls per
+// worker (the caller takes its share), and the call returns when the rows are in place.
+//
+// fork(): the workers exist in the process that created them only.  The pool is never destroyed
+// (no join at exit: a forked child that runs static destructors would wait for threads it does
+// not have), and a child made by fork() copies single-threaded: pthread_atfork marks the pool it
+// inherited as without workers and gives it fresh locks (the parent may have forked mid-job).
+#include <pthread.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -20,10 +27,14 @@ namespace osz {
 class CopyPool {
   public:
     static CopyPool &get() {
-        static CopyPool p;
-        return p;
+        static CopyPool *p = [] {
+            CopyPool *q = new CopyPool();           // leaked on purpose, see above
+            pthread_atfork(nullptr, nullptr, [] { child_ = true; });
+            return q;
+        }();
+        return *p;
     }
-    int workers() const { return (int)threads_.size(); }
+    int workers() const { return child_ ? 0 : (int)threads_.size(); }
 
     // rows of row_bytes bytes from src (pitch sp) to dst (pitch dp), split over the workers
     // and the caller
@@ -31,7 +42,7 @@ class CopyPool {
         const int64_t total = rows * row_bytes;
         int parts = (int)(total / (512 << 10));                 // at least 512 KB per part
         if (parts > workers() + 1) parts = workers() + 1;
-        if (parts <= 1) {
+        if (parts <= 1) {      // (also every copy of a forked child: it has no workers and touches no lock)
             run_part(dst, dp, src, sp, rows, row_bytes, 0, 1);
             return;
         }
@@ -66,16 +77,10 @@ class CopyPool {
     CopyPool() {
         unsigned hw = std::thread::hardware_concurrency();
         int n = hw >= 16 ? 7 : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;
-        for (int i = 0; i < n; ++i) threads_.emplace_back([this] { loop(); });
-    }
-    ~CopyPool() {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
-            ++epoch_;
+        for (int i = 0; i < n; ++i) {
+            threads_.emplace_back([this] { loop(); });
+            threads_.back().detach();
         }
-        cv_.notify_all();
-        for (auto &t : threads_) t.join();
     }
 
     // A part is claimed together with the job's number: a worker that comes back late from the
@@ -117,7 +122,6 @@ class CopyPool {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return epoch_ != seen; });
                 seen = epoch_;
-                if (stop_) return;
                 j = job_;
             }
             for (int p; claim(seen, j.parts, p);) {
@@ -127,12 +131,12 @@ class CopyPool {
         }
     }
 
+    static inline bool child_ = false;    // set in a fork()ed child: no workers there
     std::vector<std::thread> threads_;
     std::mutex m_, submit_;
     std::condition_variable cv_;
     Job job_{};
     uint64_t epoch_ = 0;
-    bool stop_ = false;
     std::atomic<uint64_t> ticket_{0};   // (job number << 32) | next part
     std::atomic<int> done_{0};
 };

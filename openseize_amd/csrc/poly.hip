@@ -309,7 +309,10 @@ int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M, 
             // (i, e) = (w div M, w mod M), so the best pitch depends on M: take, among the 16
             // pitches from the needed one up, the one with the fewest extra LDS cycles over the
             // first steps of a tile (it was "any odd pitch": 30 % of the LDS cycles were conflicts).
-            const int nth = p->nt * ((L == 1 && p->nt <= 128 && M >= 2) ? 2 : 1);
+            // (threads per workgroup as osz_poly_push launches it: its phase-group rule)
+            const size_t blds0 = ((size_t)M * p->se + (L == 1 ? 0 : (size_t)p->nt * kPolyR * L)) * sizeof(double);
+            const int eg_on0 = blds0 > 53 * 1024 ? 4 : 2;
+            const int nth = p->nt * ((L == 1 && p->nt <= 128) ? (eg_on0 >= 4 && M >= 4 ? 4 : M >= 2 ? 2 : 1) : 1);
             const int stepw = nth - nth % M, dqs = M <= nth ? stepw / M : 0;
             auto extra_cycles = [&](int se) {
                 long cost = 0;
@@ -443,7 +446,7 @@ int osz_poly_push(osz_poly_t h, const double *x, int64_t ldx, int64_t n, int fin
             static const kern_t kerns[2][3] = {
                 {poly_block_kernel<false, 256>, poly_block_kernel<false, 128>, poly_block_kernel<false, 64>},
                 {poly_block_kernel<true, 256>, poly_block_kernel<true, 128>, poly_block_kernel<true, 64>}};
-            // decimators on a 128- or 64-thread tile: two phase groups (OSZ_POLY_EG=1: off)
+            // decimators on a 128- or 64-thread tile: two (or four) phase groups
             static const kern_t kerns2[2][2] = {
                 {poly_block_kernel<true, 128, 2>, poly_block_kernel<true, 64, 2>},
                 {poly_block_kernel<true, 128, 4>, poly_block_kernel<true, 64, 4>}};

@@ -1149,8 +1149,8 @@ static int sos_launch_one(const SosArgs &a, hipStream_t st) {
 // over the ragged remainder; the cascade state travels through `carry`
 // (nsec, nch, 2) between the two launches.
 // lean bodies (no register prefetch, half-tile staging) at three workgroups
-// per CU: default on (measured 3-5 % faster); OSZ_SOS_LEAN=0 selects the
-// prefetching bodies at two workgroups per CU
+// per CU (measured 3-5 % faster than the prefetching bodies at two; the switch
+// between them is gone)
 static constexpr bool sos_lean() { return true; }
 
 // whole-tile pass, cut into time segments when there are too few channels to

@@ -542,3 +542,34 @@ def test_host_copy2d_packs_column_ranges():
     d = np.zeros((2, 8))
     assert lib.osz_host_copy2d(d.ctypes.data, 32, base.ctypes.data, base.strides[0], 2, 64) != 0   # pitch < row
     assert b"osz_host_copy2d" in lib.osz_last_error()
+
+
+def test_host_copy_pool_survives_fork():
+    """osz_host_copy2d's worker threads exist in the process that made them only: a fork()ed
+    child copies single-threaded (no lock of the parent's is touched) and exits through exit()
+    -- static destructors and all -- without waiting for threads it does not have."""
+    import multiprocessing as mp
+    from openseize_amd import _lib
+    lib = _lib.load()
+
+    def big_copy():
+        src = np.arange(4 * 600_000, dtype=np.float64).reshape(4, 600_000)
+        dst = np.zeros((4, 500_000))
+        _lib.check(lib.osz_host_copy2d(dst.ctypes.data, dst.strides[0], src[:, 1000:].ctypes.data, src.strides[0],
+                                       4, 500_000 * 8))
+        return bool(np.array_equal(dst, src[:, 1000:501_000]))
+
+    assert big_copy()                          # the parent's pool is up
+
+    def child(q):
+        q.put(big_copy())
+        # falls off the end: a normal interpreter exit, the library's static destructors run
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=child, args=(q,))
+    p.start()
+    assert q.get(timeout=60) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert big_copy()                          # and the parent's is unharmed
