@@ -83,13 +83,13 @@ def main():
             # the big launches only (the same kernels run tiny warm-up launches)
             if "sos_dual" in name and hbm > 1e9:
                 traffic["sos_dual"] = hbm
-            elif "fir_oa_kernel" in name and hbm > 1e9:
+            elif ("fir_oa_kernel" in name or "fir_nega_kernel" in name) and hbm > 1e9:
                 traffic["fir_oa"] = hbm
             elif "sos_kernel" in name and "false, false" in name and hbm > 1e9:
                 traffic["sos_fwd"] = hbm
             elif ("chain_kernel" in name or "chain_spec_kernel" in name) and hbm > 1e9:
                 traffic["chain_fwd"] = hbm
-            elif "chain_zp_kernel" in name and hbm > 1e9:
+            elif ("chain_zp_kernel" in name or "chain_zpn_kernel" in name) and hbm > 1e9:
                 traffic["chain_zp"] = hbm
             elif "sos_split2_kernel<32, 4, true" in name and hbm > 1e9:
                 traffic["sos_bwd_split"] = hbm

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void fir_nega_kernel(FirArgs a) {
         fft::nega::tw_load(t, a.tb, P.tw1, w2);
         if (t < 16) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) tw2l[4 * t + q] = fft::cube::C2{w2.r[q], w2.i[q]};
+            for (int q = 0; q < 4; ++q) tw2l[16 * q + t] = fft::cube::C2{w2.r[q], w2.i[q]};
         }
     }
     double cr[D];

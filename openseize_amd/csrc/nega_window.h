@@ -51,14 +51,14 @@ struct NegaWindow {
     using C2 = fft::cube::C2;
     const FirArgs &a;
     C2 *L;
-    const C2 *tw2l;               // [16 n0][4]: W256^(n0 2^q) in LDS (sixteen distinct rows: not worth registers)
+    const C2 *tw2l;               // [4 q][16 n0]: W256^(n0 2^q) in LDS (sixteen distinct rows: not worth registers)
     fft::nega::TwPowN tw1;
 
     __device__ __forceinline__ void load_tw2(int t, fft::cube::TwPow &w) const {
-        const C2 *p = tw2l + 4 * (t & 15);
+        const C2 *p = tw2l + (t & 15);        // [q][n0]: a 16-lane row reads 16 consecutive slots
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const C2 v = p[q];
+            const C2 v = p[16 * q];
             w.r[q] = v.re;
             w.i[q] = v.im;
         }
