@@ -110,6 +110,31 @@ def _cpu_stft_worker(args):
     return time.perf_counter() - t0
 
 
+def _cpu_share():
+    """(processes to run, how that number came about): one per core this process may run on
+    (os.sched_getaffinity), capped by the container's CPU quota (cgroup cpu.max / cfs_quota):
+    the GPU boxes expose all 256 host cores in the affinity mask but schedule the job on a
+    quota of a few of them -- 256 workers on that quota run slower than 16."""
+    avail = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()          # cgroup v2: "max 100000" | "1600000 100000"
+        if txt and txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < avail:
+        n = max(1, int(quota + 0.5))
+        return n, f"affinity lists {avail} cores, the container's CPU quota is {quota:.1f}: {n} processes"
+    return avail, f"affinity lists {avail} cores, no smaller CPU quota: {avail} processes"
+
+
 def cpu_baseline(workload, h, sos):
     """The CPU oracle (oracle/: NumPy FFT overlap-add + C DF2T loops; NumPy
     windowed rFFT for Welch) on a bounded sample of the same workload: once on
@@ -122,7 +147,8 @@ def cpu_baseline(workload, h, sos):
     orc.build()
     ch, n = 16, 1 << 21
     avail = len(os.sched_getaffinity(0))
-    procs, capped = max(1, avail), ""
+    procs, share_note = _cpu_share()
+    capped = ""
     try:
         import psutil
         per_worker = 10 * ch * n * 8            # input, FIR pieces, forward / backward copies
@@ -157,7 +183,7 @@ def cpu_baseline(workload, h, sos):
             "single_core_value": value_1,
             "sample": f"{procs} processes x ({ch} ch x 2^21 samples), same {what}, "
                       f"{wall:.1f} s wall; 1 core alone: {value_1:.1f} Msamples/s; "
-                      f"this process may run on {avail} cores{capped}"}
+                      f"{share_note}{capped}"}
 
 
 # ------------------------------------------------------------------- launcher
@@ -627,6 +653,7 @@ def run_fir(args, R, h):
     if roof is not None and roof.get("traffic"):
         roof["traffic"] = roof["traffic"] * C / C_PER_GPU      # the counters were collected at 256 channels
         roof["traffic_source"] += " (scaled from the 256-channel launch)"
+        roof["frac_physical"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
     return elapsed, kernels, roof, {"output_checksum": {"bits": f"{bits:#018x}", "sum": fsum}}
 
 

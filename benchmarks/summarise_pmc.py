@@ -35,8 +35,15 @@ def main():
     for group in ("bench", "sec"):
         rows = defaultdict(lambda: defaultdict(list))    # kernel -> counter -> [(grid, value, dur)]
         meta = {}
+        # the newest file of every pass: gpurun merges a run's outputs into gpurun_out/ beside
+        # those of earlier runs
+        newest = {}
         for path in glob.glob(os.path.join(root, f"{group}_*", "**", "*counter_collection.csv"),
                               recursive=True):
+            key = os.path.relpath(path, root).split(os.sep)[0]
+            if key not in newest or os.path.getmtime(path) > os.path.getmtime(newest[key]):
+                newest[key] = path
+        for path in newest.values():
             with open(path, newline="") as fh:
                 for r in csv.DictReader(fh):
                     k = short(r["Kernel_Name"])

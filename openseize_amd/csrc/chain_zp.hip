@@ -789,8 +789,8 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
     const int64_t W = s->nega ? (n - 1) / S : rem == 0 ? npw - 1 : npw;
     const int64_t nlast = s->nega ? n - W * S : n - W * pair;
     // one round of resident workgroups (two per CU); a run has a pair of its own
-    static const int wgs = getenv("OSZ_ZP_WGS") ? atoi(getenv("OSZ_ZP_WGS")) : 512;   // (experiment)
-    int64_t nruns = wgs / fir->nch;
+    // (256, 384, 768 and 1024 workgroups measured slower at 16 - 64 channels, profiles/README.md)
+    int64_t nruns = 512 / fir->nch;
     if (nruns > W) nruns = W;
     if (nruns < 1) nruns = 1;
     ZpArgs g{};
