@@ -44,8 +44,11 @@ struct Tables {
     std::vector<double> H, M, P, L;
 };
 
-// FFT of the zero-padded taps, 4096 points, decimation in time
-inline void fir_spectrum(const double *taps, int ntaps, std::vector<ld_t> &fr, std::vector<ld_t> &fi) {
+// FFT of the zero-padded taps, 4096 points, decimation in time.  quarter: the response at the
+// quarter-shifted bins 2 pi (k + 1/4) / 4096 instead (the taps twisted by e^{-i 2 pi m / 16384}
+// first): what fft::nega's odd-frequency transform multiplies by.
+inline void fir_spectrum(const double *taps, int ntaps, std::vector<ld_t> &fr, std::vector<ld_t> &fi,
+                         bool quarter = false) {
     const ld_t PI = acosl(-1.0L);
     std::vector<ld_t> wc(kN / 2), ws(kN / 2);
     for (int j = 0; j < kN / 2; ++j) {
@@ -58,7 +61,13 @@ inline void fir_spectrum(const double *taps, int ntaps, std::vector<ld_t> &fr, s
     for (int m = 0; m < ntaps && m < kN; ++m) {           // bit-reversed load
         unsigned r = 0;
         for (int b = 0; b < 12; ++b) r |= ((unsigned)(m >> b) & 1u) << (11 - b);
-        fr[r] = (ld_t)taps[m];
+        if (quarter) {
+            const ld_t ang = -2.0L * PI * (ld_t)m / (4.0L * kN);
+            fr[r] = (ld_t)taps[m] * cosl(ang);
+            fi[r] = (ld_t)taps[m] * sinl(ang);
+        } else {
+            fr[r] = (ld_t)taps[m];
+        }
     }
     for (int len = 2; len <= kN; len <<= 1) {
         const int half = len >> 1, tstep = kN / len;
@@ -677,19 +686,17 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
                 T.M[rim * ns + i] = (double)(ci * av + cr * bv);
             }
         }
-    // the composite response at the quarter-shifted bins, / 4096: taps by Horner in z^-1
+    // the composite response at the quarter-shifted bins, / 4096 (the taps' part by the twisted
+    // transform: a Horner sum per bin costs 4096 x wlen long-double products, 20 ms per stream)
     const ld_t PI = acosl(-1.0L);
+    std::vector<ld_t> frq, fiq;
+    fir_spectrum(taps, wlen, frq, fiq, true);
     T.H.assign(2 * kN, 0.0);
     for (int k = 0; k < kN; ++k) {
         const ld_t ang = -2.0L * PI * ((ld_t)k + 0.25L) / (ld_t)kN;
         const ld_t zr = cosl(ang), zi = sinl(ang);          // z^-1
         const ld_t z2r = zr * zr - zi * zi, z2i = 2.0L * zr * zi;
-        ld_t fr = 0.0L, fi = 0.0L;
-        for (int n = wlen - 1; n >= 0; --n) {
-            const ld_t x = fr * zr - fi * zi + (ld_t)taps[n], y = fr * zi + fi * zr;
-            fr = x;
-            fi = y;
-        }
+        const ld_t fr = frq[k], fi = fiq[k];
         ld_t gain = 1.0L;
         for (int q = 0; q < nsec; ++q) {
             const ld_t b0 = sos[6 * q], b1 = sos[6 * q + 1], b2 = sos[6 * q + 2];
