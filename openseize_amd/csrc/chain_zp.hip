@@ -659,15 +659,6 @@ static bool zp_nega() {
     }();
     return on;
 }
-// OSZ_ZP_DMA=0: the pair's samples by plain row loads (the kernel of round 3), for comparison
-static bool zp_dma() {
-    static const bool on = [] {
-        const char *e = getenv("OSZ_ZP_DMA");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
-
 // the shortest chunk a step takes: two pairs of blocks / two blocks
 static int64_t zp_min_chunk(const ChainZp *s) { return (s->nega ? 2 : 4) * 256 * (int64_t)s->NR; }
 
@@ -844,10 +835,9 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
         g.hist_len = 0;
     }
     zp_kern_t kern = s->nega    ? zpn_kernel_for(NR, s->NM, s->NS)
-                     : zp_dma() ? (s->NM == 2 ? zp_kernel_for<2, true>(NR) : s->NM == 4 ? zp_kernel_for<4, true>(NR)
-                                                                                       : zp_kernel_for<6, true>(NR))
-                                : (s->NM == 2 ? zp_kernel_for<2, false>(NR) : s->NM == 4 ? zp_kernel_for<4, false>(NR)
-                                                                                        : zp_kernel_for<6, false>(NR));
+                     : s->NM == 2 ? zp_kernel_for<2, true>(NR)
+                     : s->NM == 4 ? zp_kernel_for<4, true>(NR)
+                                  : zp_kernel_for<6, true>(NR);     // (rows by LDS-DMA, as the one-block kernel's)
     if (!kern) return fail(OSZ_ERR_STATE, "zero-phase kernel: no instance for %d rows, %d modes (%d slow)", NR, s->NM, s->NS);
     const size_t lds = zp_lds_bytes(s);
     OSZ_DYN_LDS(kern, lds);

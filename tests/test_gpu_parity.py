@@ -1210,3 +1210,22 @@ def test_polyphase_large_decimation_stays_on_the_tiled_kernel(osz):
         ref = sps.resample_poly(x.cpu().numpy(), 1, M, axis=-1, window=h)
         assert got.shape == ref.shape, (M, got.shape, ref.shape)
         assert np.max(np.abs(got - ref)) < 1e-12 * np.max(np.abs(ref)), M
+
+
+@pytest.mark.parametrize("taps_n", [2, 257, 258, 1536, 2049, 2050])
+def test_fir_block_heights_of_the_one_block_kernel(osz, taps_n):
+    """fir_nega_kernel (csrc/fir.hip: one real block of 24 ... 31 rows per 4096-point transform)
+    at the ends of its range of tap counts and just beyond (2050 taps: a partitioned filter on
+    the pair kernel), three modes, ragged chunks, against numpy.convolve
+    (core/numerical.py:158-298 equals it for every mode)."""
+    import scipy.signal as sps
+    from openseize_amd import _device as dev
+    C, n, cs = 3, 200_003, 70_001
+    x = dev.synth_normal(C, n, seed=800 + taps_n)
+    h = sps.firwin(taps_n, 0.3) if taps_n > 2 else np.array([0.75, -0.25])
+    xh = x.cpu().numpy()
+    for mode in ("full", "same", "valid"):
+        got = np.concatenate([c.cpu().numpy() for c in osz.oaconvolve(producer(x, cs, -1), h, -1, mode)], -1)
+        want = np.stack([np.convolve(row, h, mode) for row in xh])
+        assert got.shape == want.shape, (taps_n, mode)
+        assert rel_err(got, want) < RTOL, (taps_n, mode)

@@ -83,13 +83,19 @@ CASES = [
     (513, sps.butter(5, 0.3, output="sos"), 3, [100000] * 3),
     (777, sps.cheby1(3, 1, [0.16, 0.48], "bandpass", output="sos"), 4, [65536, 70000, 65537]),
     (64, sps.ellip(4, 0.5, 50, 0.25, "highpass", output="sos"), 2, [80000, 80001]),
+    # a long FIR: blocks of 24 rows (the shortest the one-block kernel has)
+    (1700, BP, 3, lambda u: [u * 7 + 33, u * 5, u * 6 - 1]),
+    # eight modes (two of them slow): the fit of sixteen two-sided modes is the worst-conditioned the
+    # tables admit (spec::build_zpn: 3e-17 / ratio of the output scale, here 3e-11) -- 5e-10 asserted
+    (1024, sps.butter(8, [0.05, 0.3], "bandpass", output="sos"), 3, lambda u: [u * 6 + 1000, u * 7, u * 5 + 5], 5e-10),
 ]
 
 
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_zero_phase_stream_against_scipy(dev, case, split):
-    taps_n, sos, C, lens = CASES[case]
+    taps_n, sos, C, lens = CASES[case][:4]
+    tol = CASES[case][4] if len(CASES[case]) > 4 else 1e-11
     h = sps.firwin(taps_n, 0.2)
     if callable(lens):
         fir, iir = dev.FirStream(h, 1), dev.SosStream(sos, 1)
@@ -107,7 +113,7 @@ def test_zero_phase_stream_against_scipy(dev, case, split):
     assert np.isfinite(g[:, lag:]).all()
     hi = total - lag - 6000                       # the stream's end is the caller's
     err = np.max(np.abs(g[:, lag:lag + hi] - ref[:, :hi])) / np.max(np.abs(ref))
-    assert err < 1e-11, (taps_n, C, err)
+    assert err < tol, (taps_n, C, err)
 
 
 def test_what_the_kernel_refuses(dev):
