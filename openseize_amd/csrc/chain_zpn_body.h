@@ -261,6 +261,12 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
         const int64_t o = (int64_t)p * S;
         double re[16], im[16];
         take_turns();
+#ifdef OSZ_NEGA_STAMPS
+#define OSZ_BSTAMP(slot_) OSZ_NSTAMP(P.sacc, P.slast, slot_)
+#else
+#define OSZ_BSTAMP(slot_) do { } while (0)
+#endif
+        OSZ_BSTAMP(16);   // the previous block's stores issued (+ loop overhead)
         if (!closing) {
             // the block's samples were requested behind the previous block's transform: younger
             // than they are only that block's stores (requests and stores retire in order on one
@@ -284,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 im[j] = (j < NHI && 4096 + 256 * j + t < la) ? xc[4096 + 256 * j] : 0.0;
             }
         }
+        OSZ_BSTAMP(0);    // the wait for this block's samples + their read from LDS
         // (the next block's samples are requested inside, once inverse pass 1 has read this wave's
         // pieces of the cube: they land while its arithmetic, fit, bursts and stores run)
         P.template transform<NP>(t, re, im, (!closing && p < lastf) ? xr + o + S : nullptr, NB);
@@ -295,9 +302,12 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
         else if (tt >= 256 - nh) fitbuf[tt - 256 + ns] = im[15];
 #pragma unroll
         for (int j = 0; j < D; ++j) re[j] += cr[j];
+        OSZ_BSTAMP(11);   // fit samples to LDS + overlap add
         __syncthreads();
+        OSZ_BSTAMP(12);   // barrier 5
         zpn_fit_kappa<NM, NS>(tt, nh, R, fitbuf, mtab, lrow, kmu, knu, kapP + (par ^ 1) * (R * NS * 2));
         __syncthreads();
+        OSZ_BSTAMP(13);   // fit + barrier 6
         double c7[kSpecRMax];
 #pragma unroll
         for (int r = 0; r < kSpecRMax; ++r) c7[r] = 0.0;
@@ -327,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 default: zpn_bwd_bursts<NM, NS, 5>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
             }
         }
+        OSZ_BSTAMP(14);   // bursts
         const double qn = spec_qnan();
         const bool own = p >= p0;                      // (a run's first block may be its neighbour's)
         const bool edge = p >= g.W - 1;                // its samples may be among the chunk's last L
@@ -427,7 +438,18 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
         par ^= 1;
         younger = nst;
     };
+#ifdef OSZ_NEGA_STAMPS
+    for (int q = 0; q < 24; ++q) P.sacc[q] = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.slast)::"memory");
+#endif
     for (int p = first; p <= lastf; ++p) block(p, std::false_type{});
+#ifdef OSZ_NEGA_STAMPS
+    if (g_nega_stamps && (t & 63) == 0) {
+        unsigned long long *so = g_nega_stamps + (((int64_t)c * g.nruns + run) * 4 + (t >> 6)) * 24;
+        for (int q = 0; q < 24; ++q) so[q] = P.sacc[q];
+        so[23] = (unsigned long long)(lastf - first + 1);
+    }
+#endif
     if (closes) block(lastf + 1, std::true_type{});
 #undef OSZ_ZP_PUT
     // where the forward stream of this channel first went bad (chain_zp.hip: later launches start

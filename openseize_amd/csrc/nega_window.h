@@ -11,6 +11,23 @@
 
 namespace osz {
 
+// In-kernel phase stamps for the diagnostic build only (benchmarks/zpn_stamps.hip defines
+// OSZ_NEGA_STAMPS); the library build has none.  Slots: see that file.
+#ifdef OSZ_NEGA_STAMPS
+__device__ unsigned long long *g_nega_stamps = nullptr;   // [waves][24] cycle sums
+#define OSZ_NSTAMP(acc_, last_, slot_)                                                \
+    do {                                                                              \
+        unsigned long long now_;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");  \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        (acc_)[slot_] += now_ - (last_);                                              \
+        (last_) = now_;                                                               \
+    } while (0)
+#else
+#define OSZ_NSTAMP(acc_, last_, slot_) do { } while (0)
+#endif
+
 // A block's (a pair's) rows of 256 samples, requested by LDS-DMA into the cube.  A wave
 // owns, in every 4 KB plane of the cube, the 1 KB piece [1024 w, 1024 w + 1024) -- the slots it
 // reads last in a transform (inverse pass 1, view A) and writes first in the next one (pass 1) --
@@ -53,6 +70,14 @@ struct NegaWindow {
     C2 *L;
     const C2 *tw2l;               // [4 q][16 n0]: W256^(n0 2^q) in LDS (sixteen distinct rows: not worth registers)
     fft::nega::TwPowN tw1;
+#ifdef OSZ_NEGA_STAMPS
+    unsigned long long sacc[24], slast;
+#endif
+#ifndef OSZ_NEGA_STAMPS
+#define OSZ_WSTAMP(slot_) do { } while (0)
+#else
+#define OSZ_WSTAMP(slot_) OSZ_NSTAMP(sacc, slast, slot_)
+#endif
 
     __device__ __forceinline__ void load_tw2(int t, fft::cube::TwPow &w) const {
         const C2 *p = tw2l + (t & 15);        // [q][n0]: a 16-lane row reads 16 consecutive slots
@@ -75,7 +100,9 @@ struct NegaWindow {
         int t = t_in;
         asm volatile("" : "+v"(t));
         fft::nega::f1<NHI>(t, re, im, tw1, L);
+        OSZ_WSTAMP(1);    // pack + pass 1 + stores
         __syncthreads();
+        OSZ_WSTAMP(2);    // barrier 1
         fft::cube::TwPow tw2;
         load_tw2(t, tw2);
         fft::cube2::f2(t, re, im, tw2, L);
@@ -90,21 +117,29 @@ struct NegaWindow {
             hr[r] = h.x;
             hi[r] = h.y;
         }
+        OSZ_WSTAMP(3);    // pass 2 + spectrum requests
         wave_lds_fence();
         fft::cube2::f3(t, re, im, L);
+        OSZ_WSTAMP(4);    // pass 3
 #pragma unroll
         for (int r = 0; r < 16; ++r) fft::cube::cmul(re[r], im[r], hr[r], hi[r]);
+        OSZ_WSTAMP(5);    // spectrum lands + multiply
         fft::cube2::i3(t, re, im, L);
         wave_lds_fence();
+        OSZ_WSTAMP(6);    // inverse pass 3
         load_tw2(t, tw2);
         fft::cube2::i2(t, re, im, tw2, L);
+        OSZ_WSTAMP(7);    // inverse pass 2
         __syncthreads();
+        OSZ_WSTAMP(8);    // barrier 4
         fft::nega::i1_load(t, re, im, L);
         if (next) {
             asm volatile("s_waitcnt lgkmcnt(0) ; osz:dma" ::: "memory");
             zp_request_rows<NP>(next, nrows, t_in, L);
         }
+        OSZ_WSTAMP(9);    // inverse pass 1's loads + the next block's requests
         fft::nega::i1_finish(re, im, tw1);
+        OSZ_WSTAMP(10);   // inverse pass 1 + unpack
     }
 };
 
