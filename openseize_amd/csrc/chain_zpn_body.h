@@ -161,18 +161,19 @@ __device__ __forceinline__ void zpn_fwd_bursts(double *re, const double *kmu, co
 
 // The backward bursts (RB rows): this block's nu leaves window row 31 - r (im[15 - r]) and
 // arrives, with the same values, in the rows the previous block holds back (c7).  The slow modes
-// in every row; the fast ones (two at a time: their powers are formed on the spot) in the first.
+// in every row; the fast ones (all at once: one more round of table reads, not one per pair)
+// in the first.
 template <int NM, int NS, int RB>
 __device__ __forceinline__ void zpn_bwd_bursts(double *im, double *c7, const double *knu, const double *ptab, int e,
                                                const double *Pr, const double *Pi) {
     double nb[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) nb[r] = zp_dot<NS>(knu + (r * NM) * 2, Pr, Pi);
-#pragma unroll
-    for (int q0 = NS; q0 < NM; q0 += 2) {
-        double fr[2], fi[2];
-        zpn_powers<NM, 2>(ptab, q0, e, fr, fi);
-        nb[0] += zp_dot<2>(knu + q0 * 2, fr, fi);
+    if (NM > NS) {
+        constexpr int NF = NM > NS ? NM - NS : 1;
+        double fr[NF], fi[NF];
+        zpn_powers<NM, NF>(ptab, NS, e, fr, fi);
+        nb[0] += zp_dot<NF>(knu + NS * 2, fr, fi);
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -323,18 +324,22 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 case 4: zpn_fwd_bursts<D, NS, 4>(re, kmu, kpm, Pr, Pi, ca); break;
                 default: zpn_fwd_bursts<D, NS, 5>(re, kmu, kpm, Pr, Pi, ca); break;
             }
+            // (no fence between the two halves: with two slow modes both sets of powers fit beside
+            // the data, and the backward half's table reads go out behind the forward half's)
+            double Qr[NS], Qi[NS];
+            zpn_powers<NM, NS>(ptab, 0, 255 - tt, Qr, Qi);
+            switch (R) {
+                case 1: zpn_bwd_bursts<NM, NS, 1>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                case 2: zpn_bwd_bursts<NM, NS, 2>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                case 3: zpn_bwd_bursts<NM, NS, 3>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                case 4: zpn_bwd_bursts<NM, NS, 4>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                default: zpn_bwd_bursts<NM, NS, 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+            }
+            // non-finite samples are everywhere behind the transform: every amplitude of the fit
+            // and with it every lane's burst values (looked at once, behind both halves)
             if (!bad && __builtin_amdgcn_readfirstlane((int)sos_not_finite(ca))) {
                 bad = true;
                 bad_at = o;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            zpn_powers<NM, NS>(ptab, 0, 255 - tt, Pr, Pi);
-            switch (R) {
-                case 1: zpn_bwd_bursts<NM, NS, 1>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
-                case 2: zpn_bwd_bursts<NM, NS, 2>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
-                case 3: zpn_bwd_bursts<NM, NS, 3>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
-                case 4: zpn_bwd_bursts<NM, NS, 4>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
-                default: zpn_bwd_bursts<NM, NS, 5>(im, c7, knu, ptab, 255 - tt, Pr, Pi); break;
             }
         }
         OSZ_BSTAMP(14);   // bursts
