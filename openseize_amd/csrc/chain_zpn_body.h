@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     double *lrow = kapP + 2 * R * NS * 2;              // [R][NM][2]
     double *ptab = lrow + R * NM * 2;                  // [20][NM][2]
     double *mtab = ptab + 20 * NM * 2;                 // [2 NS + 2 NM][2 nh]
-    fft::cube::C2 *tw2l = reinterpret_cast<fft::cube::C2 *>(mtab + (2 * NS + 2 * NM) * ns);   // [16][4]
+    fft::cube::C2 *tw2l = reinterpret_cast<fft::cube::C2 *>(mtab + (2 * NS + 2 * NM) * ns);   // [4 q][16 n0]
     const FirArgs &a = g.f;
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
     const int L = 256 * R;

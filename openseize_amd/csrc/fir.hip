@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void fir_nega_kernel(FirArgs a) {
     constexpr int D = 32 - NB, S = 256 * NB, NHI = NB - 16, NP = (NB + 1) / 2;
     static_assert(NB >= 24 && NB <= 31, "rows per block");
     extern __shared__ fft::cube::C2 cube_lds[];
-    fft::cube::C2 *tw2l = cube_lds + fft::cube::SLOTS;                 // [16][4]
+    fft::cube::C2 *tw2l = cube_lds + fft::cube::SLOTS;                 // [4 q][16 n0]
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
     const int wm1 = a.wlen - 1;
     const double *xr = a.x + (int64_t)c * a.ldx;
