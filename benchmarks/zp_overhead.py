@@ -36,7 +36,7 @@ def step_time(C, cs, steps=30, warm=6):
 
 
 if __name__ == "__main__":
-    S2 = 2 * 2816
+    S2 = 27 * 256      # samples per transform: a block of 27 rows (the pair kernel: 2 * 2816)
     for C in (32, 256):
         nruns = 512 // C
         rows = []
