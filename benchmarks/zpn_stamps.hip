@@ -13,7 +13,7 @@
 #include "../openseize_amd/csrc/chain_zpn_body.h"
 namespace osz {
 // (the six-mode instances only: the headline's cascade)
-zp_kern_t zpn_kernel_for(int nb, int nm, int ns) { return nm == 6 ? zpn_kernel_nm6(nb, ns) : nullptr; }
+zp_kern_t zpn_kernel_for(int nb, int nm, int ns, int r) { return nm == 6 ? zpn_kernel_nm6(nb, ns, r) : nullptr; }
 }
 
 #include <vector>

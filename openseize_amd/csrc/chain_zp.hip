@@ -834,7 +834,7 @@ static int zp_launch(ChainZp *s, const double *x, int64_t ldx, int64_t n, double
         g.hist = nullptr;
         g.hist_len = 0;
     }
-    zp_kern_t kern = s->nega    ? zpn_kernel_for(NR, s->NM, s->NS)
+    zp_kern_t kern = s->nega    ? zpn_kernel_for(NR, s->NM, s->NS, s->R)
                      : s->NM == 2 ? zp_kernel_for<2, true>(NR)
                      : s->NM == 4 ? zp_kernel_for<4, true>(NR)
                                   : zp_kernel_for<6, true>(NR);     // (rows by LDS-DMA, as the one-block kernel's)

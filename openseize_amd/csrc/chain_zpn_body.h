@@ -50,7 +50,7 @@ namespace osz {
 //   kmu[r][q], q < NS    this block's mu;  kapN[r][q]: what the NEXT block meets as the previous one's
 //   knu[r][q], q < NM    this block's nu (rows behind the first are read for the slow modes only)
 // M's rows: Re mu [NS], Im mu [NS], Re nu [NM], Im nu [NM].
-template <int NM, int NS, int PER>
+template <int NM, int NS, int PER, int RM>
 __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fitbuf, const double *mtab,
                                                 const double *lrow, double *kmu, double *knu, double *kapN) {
     constexpr int ns = 16 * PER;
@@ -87,7 +87,7 @@ __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fit
     si += dpp_row_shr0<8>(si);
     if (p16 == 15 && valid) {
 #pragma unroll
-        for (int r = 0; r < kSpecRMax; ++r) {
+        for (int r = 0; r < RM; ++r) {
             if (r < R) {
                 const double lr = lrow[(r * NM + q) * 2 + 0], li = lrow[(r * NM + q) * 2 + 1];
                 const double kr = sr * lr - si * li, ki = sr * li + si * lr;
@@ -106,12 +106,12 @@ __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fit
 }
 
 // nh is 16, 24 or 32 (spec::build_zpn)
-template <int NM, int NS>
+template <int NM, int NS, int RM>
 __device__ __forceinline__ void zpn_fit_kappa(int tt, int nh, int R, const double *fitbuf, const double *mtab,
                                               const double *lrow, double *kmu, double *knu, double *kapN) {
-    if (nh == 24) zpn_fit_kappa_n<NM, NS, 3>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
-    else if (nh == 32) zpn_fit_kappa_n<NM, NS, 4>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
-    else zpn_fit_kappa_n<NM, NS, 2>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
+    if (nh == 24) zpn_fit_kappa_n<NM, NS, 3, RM>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
+    else if (nh == 32) zpn_fit_kappa_n<NM, NS, 4, RM>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
+    else zpn_fit_kappa_n<NM, NS, 2, RM>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
 }
 
 // lambda_q^e, q = q0 .. q0 + NG - 1, e = 0..255, from the three-level table [20][NM][2]
@@ -182,7 +182,9 @@ __device__ __forceinline__ void zpn_bwd_bursts(double *im, double *c7, const dou
     }
 }
 
-template <int NB, int NM, int NS>
+// RM: burst rows the instance holds registers for (5, or 8 for the long left tails of blocks of
+// 24 ... 26 rows)
+template <int NB, int NM, int NS, int RM = kSpecRMax>
 __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     constexpr int D = 32 - NB, S = 256 * NB, NHI = NB - 16, NP = (NB + 1) / 2;
     static_assert(NB >= 24 && NB <= 30, "rows per block");
@@ -234,9 +236,9 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
         for (int i = t; i < ntab; i += 256) lrow[i] = g.Lrow[i];
     }
     for (int i = t; i < 2 * R * NS * 2; i += 256) kapP[i] = 0.0;
-    double held[kSpecRMax];          // rows NB-1-r of the previous block, one burst short
+    double held[RM];                 // rows NB-1-r of the previous block, one burst short
 #pragma unroll
-    for (int r = 0; r < kSpecRMax; ++r) held[r] = 0.0;
+    for (int r = 0; r < RM; ++r) held[r] = 0.0;
     // `bad` is uniform (a scalar), and sticky: the stream went bad in an earlier chunk, or a block
     // of this run held non-finite samples -- behind the transform they are everywhere
     bool bad = g.nanpos[c] != 0x7fffffffffffffffLL;
@@ -306,12 +308,12 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
         OSZ_BSTAMP(11);   // fit samples to LDS + overlap add
         __syncthreads();
         OSZ_BSTAMP(12);   // barrier 5
-        zpn_fit_kappa<NM, NS>(tt, nh, R, fitbuf, mtab, lrow, kmu, knu, kapP + (par ^ 1) * (R * NS * 2));
+        zpn_fit_kappa<NM, NS, RM>(tt, nh, R, fitbuf, mtab, lrow, kmu, knu, kapP + (par ^ 1) * (R * NS * 2));
         __syncthreads();
         OSZ_BSTAMP(13);   // fit + barrier 6
-        double c7[kSpecRMax];
+        double c7[RM];
 #pragma unroll
-        for (int r = 0; r < kSpecRMax; ++r) c7[r] = 0.0;
+        for (int r = 0; r < RM; ++r) c7[r] = 0.0;
         {
             double Pr[NS], Pi[NS];
             zpn_powers<NM, NS>(ptab, 0, tt, Pr, Pi);
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 case 2: zpn_fwd_bursts<D, NS, 2>(re, kmu, kpm, Pr, Pi, ca); break;
                 case 3: zpn_fwd_bursts<D, NS, 3>(re, kmu, kpm, Pr, Pi, ca); break;
                 case 4: zpn_fwd_bursts<D, NS, 4>(re, kmu, kpm, Pr, Pi, ca); break;
-                default: zpn_fwd_bursts<D, NS, 5>(re, kmu, kpm, Pr, Pi, ca); break;
+                default: zpn_fwd_bursts<D, NS, 5>(re, kmu, kpm, Pr, Pi, ca); break;   // (Rf <= 5: the tables)
             }
             // (no fence between the two halves: with two slow modes both sets of powers fit beside
             // the data, and the backward half's table reads go out behind the forward half's)
@@ -333,7 +335,10 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 case 2: zpn_bwd_bursts<NM, NS, 2>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
                 case 3: zpn_bwd_bursts<NM, NS, 3>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
                 case 4: zpn_bwd_bursts<NM, NS, 4>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
-                default: zpn_bwd_bursts<NM, NS, 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                case 5: zpn_bwd_bursts<NM, NS, 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                case 6: zpn_bwd_bursts<NM, NS, RM >= 6 ? 6 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                case 7: zpn_bwd_bursts<NM, NS, RM >= 7 ? 7 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                default: zpn_bwd_bursts<NM, NS, RM >= 8 ? 8 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
             }
             // non-finite samples are everywhere behind the transform: every amplitude of the fit
             // and with it every lane's burst values (looked at once, behind both halves)
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
             }
             const double *hi = g.held_in + (int64_t)c * L + tt;
 #pragma unroll
-            for (int r = 0; r < kSpecRMax; ++r)
+            for (int r = 0; r < RM; ++r)
                 if (r < R) {
                     const int64_t q = 256 * (R - 1 - r) + tt;
                     (q < n0 ? y0r : yr)[q] = bad ? qn : hi[256 * (R - 1 - r)] + c7[r];
@@ -374,14 +379,14 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
             if (!bad && !closing && o - S + L >= n0) {
                 const __amdgpu_buffer_rsrc_t ry = buf_rsrc(yr + (o - S + L));
 #pragma unroll
-                for (int r = 0; r < kSpecRMax; ++r)
+                for (int r = 0; r < RM; ++r)
                     if (r < R) buf_store(held[r] + c7[r], ry, lane8, 2048u * (NB - 1 - r));
                 if (nst >= 0) nst += R;
             } else {
                 nst = -1;
                 const int64_t ob = o - S + tt;
 #pragma unroll
-                for (int r = 0; r < kSpecRMax; ++r)
+                for (int r = 0; r < RM; ++r)
                     if (r < R) OSZ_ZP_PUT(ob + 256 * (NB - 1 - r), bad ? qn : held[r] + c7[r]);
             }
         }
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < kSpecRMax; ++r)
+            for (int r = 0; r < RM; ++r)
                 if (r < R) held[r] = im[(NHI - 1 - r) & 15];
 #pragma unroll
             for (int j = 0; j < D; ++j) cr[j] = im[NHI + j];
@@ -465,33 +470,37 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
 // (one translation unit per mode count: chain_zpn_{2,4,6,8}.hip define OSZ_ZPN_NM and include
 // this file; the dispatcher lives with NM = 2)
 template <int NM, int NS>
-static zp_kern_t zpn_kernel_nb(int nb) {
+static zp_kern_t zpn_kernel_nb(int nb, int r) {
     static const zp_kern_t k[7] = {chain_zpn_kernel<24, NM, NS>, chain_zpn_kernel<25, NM, NS>,
                                    chain_zpn_kernel<26, NM, NS>, chain_zpn_kernel<27, NM, NS>,
                                    chain_zpn_kernel<28, NM, NS>, chain_zpn_kernel<29, NM, NS>,
                                    chain_zpn_kernel<30, NM, NS>};
+    // more than five burst rows: blocks of 24 ... 26 rows (R <= 32 - NB)
+    static const zp_kern_t k8[3] = {chain_zpn_kernel<24, NM, NS, 8>, chain_zpn_kernel<25, NM, NS, 8>,
+                                    chain_zpn_kernel<26, NM, NS, 8>};
+    if (r > kSpecRMax) return nb <= 26 && r <= 8 ? k8[nb - 24] : nullptr;
     return k[nb - 24];
 }
 
 #define OSZ_ZPN_CAT2(a, b) a##b
 #define OSZ_ZPN_CAT(a, b) OSZ_ZPN_CAT2(a, b)
-// zpn_kernel_nm2 / 4 / 6 / 8 (nb, ns)
-zp_kern_t OSZ_ZPN_CAT(zpn_kernel_nm, OSZ_ZPN_NM)(int nb, int ns) {
+// zpn_kernel_nm2 / 4 / 6 / 8 (nb, ns, r)
+zp_kern_t OSZ_ZPN_CAT(zpn_kernel_nm, OSZ_ZPN_NM)(int nb, int ns, int r) {
     constexpr int NM = OSZ_ZPN_NM;
     if (nb < 24 || nb > 30) return nullptr;
-    if (ns == 2) return zpn_kernel_nb<NM, 2>(nb);
-    if (NM >= 4 && ns == 4) return zpn_kernel_nb<NM, (NM >= 4 ? 4 : 2)>(nb);
-    if (NM >= 6 && ns == 6) return zpn_kernel_nb<NM, (NM >= 6 ? 6 : 2)>(nb);
+    if (ns == 2) return zpn_kernel_nb<NM, 2>(nb, r);
+    if (NM >= 4 && ns == 4) return zpn_kernel_nb<NM, (NM >= 4 ? 4 : 2)>(nb, r);
+    if (NM >= 6 && ns == 6) return zpn_kernel_nb<NM, (NM >= 6 ? 6 : 2)>(nb, r);
     return nullptr;
 }
 
 #if OSZ_ZPN_NM == 2
-zp_kern_t zpn_kernel_nm4(int nb, int ns);
-zp_kern_t zpn_kernel_nm6(int nb, int ns);
-zp_kern_t zpn_kernel_nm8(int nb, int ns);
-zp_kern_t zpn_kernel_for(int nb, int nm, int ns) {
-    return nm == 2 ? zpn_kernel_nm2(nb, ns) : nm == 4 ? zpn_kernel_nm4(nb, ns) : nm == 6 ? zpn_kernel_nm6(nb, ns)
-           : nm == 8 ? zpn_kernel_nm8(nb, ns) : nullptr;
+zp_kern_t zpn_kernel_nm4(int nb, int ns, int r);
+zp_kern_t zpn_kernel_nm6(int nb, int ns, int r);
+zp_kern_t zpn_kernel_nm8(int nb, int ns, int r);
+zp_kern_t zpn_kernel_for(int nb, int nm, int ns, int r) {
+    return nm == 2 ? zpn_kernel_nm2(nb, ns, r) : nm == 4 ? zpn_kernel_nm4(nb, ns, r) : nm == 6 ? zpn_kernel_nm6(nb, ns, r)
+           : nm == 8 ? zpn_kernel_nm8(nb, ns, r) : nullptr;
 }
 #endif
 

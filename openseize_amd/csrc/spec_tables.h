@@ -31,7 +31,8 @@ namespace spec {
 typedef long double ld_t;
 
 constexpr int kFit = 64;      // samples of row 15 the fit reads (one wave)
-constexpr int kRMax = 5;      // burst rows supported
+constexpr int kRMax = 5;      // burst rows supported (the pair kernels)
+constexpr int kRMaxN = 8;     // ... by the one-block kernel (chain_zpn_body.h: its instances hold 5 or 8 rows)
 // where a burst is cut off, relative to the norm of the composite impulse response (see the
 // two-sided tables below for what it costs and buys)
 constexpr ld_t kTailTol = 1e-12L;
@@ -513,8 +514,12 @@ inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int ns
 //         bursts run over NS modes -- all NM only in the left tail's first row.  (The FIT still
 //         has every mode in its basis: the fast ones are alive in row 31's first samples.)
 //         NM is 2, 4, 6 or 8, NS 2, 4 or 6.
+//   R     up to kRMaxN = 8 rows (a left tail of 2048 samples) where the guard rows hold them:
+//         R <= D = 32 - NB, i.e. blocks of 24 rows for R = 8 -- the cascade alone (the identity
+//         as the FIR: nothing but the guard row in front of the left tail) needs them first.
 inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int nsec, bool forgets,
-                          int lds_budget = 15360, ld_t tail_tol = kTailTol, ld_t fit_floor = 3e-7L) {
+                          int lds_budget = 15360, ld_t tail_tol = kTailTol, ld_t fit_floor = 3e-7L,
+                          int rmax = kRMaxN) {
     TablesZp T;
     constexpr int kM = 8192;
     if (wlen < 2 || !forgets) return T;
@@ -571,13 +576,13 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
     for (int cand = NBmax; cand >= 24 && !NB; --cand) {
         const int S = 256 * cand, D = 32 - cand;
         int rb = 0, rf = 0;
-        for (int r = 1; r <= kRMax && !(rb && rf); ++r) {
+        for (int r = 1; r <= rmax && !(rb && rf); ++r) {
             const int ir = Lg + kM + 256 * r - S + 1, il = Lg - 256 * r;
             if (ir >= 2 * Lg || il < 0) break;
             if (!rf && sqrtl(right2[ir]) <= tail_tol * tot) rf = r;
             if (!rb && sqrtl(left2[il]) <= tail_tol * tot) rb = r;
         }
-        if (rb && rf && rf <= rb && rb <= D && D + rf <= cand) {
+        if (rb && rf && rf <= rb && rf <= kRMax && rb <= D && D + rf <= cand) {   // (the right tail: five rows at most)
             NB = cand;
             R = rb;
             Rf = rf;
@@ -663,8 +668,8 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
     const ld_t ratio = pinv_qr(B, ns, nd, Pinv);
     T.fit_ratio = (double)ratio;
     // (the fit's conditioning: the transform's rounding, 1e-16 of the signal, reaches the amplitudes
-    // multiplied by about 1 / ratio -- tests/test_spec_host.py measures 3e-17 / ratio of the output
-    // scale; 3e-7 keeps that at 1e-10.  The pair kernel's floor of 1e-3 refused six-section
+    // multiplied by about 1 / ratio -- tests/test_spec_host.py measures up to 1e-16 / ratio of the
+    // output scale (tests/test_gpu_zp.py); 3e-7 keeps that at 3e-10.  The pair kernel's floor of 1e-3 refused six-section
     // band-passes below 0.03 of Nyquist and every eight-section one.)
     if (!(ratio > fit_floor)) return T;
     // rows: Re mu [NS], Im mu [NS], Re nu [NM], Im nu [NM]
@@ -709,7 +714,7 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
         T.H[2 * k + 1] = (double)(fi / kN * gain);
     }
     T.P.assign((size_t)20 * NM * 2, 0.0);
-    T.L.assign((size_t)kRMax * NM * 2, 0.0);
+    T.L.assign((size_t)rmax * NM * 2, 0.0);
     for (int q = 0; q < nm; ++q) {
         for (int i = 0; i < 20; ++i) {
             ld_t pr, pi;
@@ -717,7 +722,7 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
             T.P[((size_t)i * NM + q) * 2 + 0] = (double)pr;
             T.P[((size_t)i * NM + q) * 2 + 1] = (double)pi;
         }
-        for (int r = 0; r < kRMax; ++r) {
+        for (int r = 0; r < rmax; ++r) {
             ld_t pr, pi;
             mode_pow(modes[q], 256 * r, pr, pi);
             T.L[((size_t)r * NM + q) * 2 + 0] = (double)pr;

@@ -86,7 +86,7 @@ CASES = [
     # a long FIR: blocks of 24 rows (the shortest the one-block kernel has)
     (1700, BP, 3, lambda u: [u * 7 + 33, u * 5, u * 6 - 1]),
     # eight modes (two of them slow): the fit of sixteen two-sided modes is the worst-conditioned the
-    # tables admit (spec::build_zpn: 3e-17 / ratio of the output scale, here 3e-11) -- 5e-10 asserted
+    # tables admit for eight modes (spec::build_zpn: up to 1e-16 / ratio of the output scale, here 6e-11) -- 5e-10 asserted
     (1024, sps.butter(8, [0.05, 0.3], "bandpass", output="sos"), 3, lambda u: [u * 6 + 1000, u * 7, u * 5 + 5], 5e-10),
 ]
 
@@ -223,9 +223,14 @@ def test_plain_sosfiltfilt_takes_the_zero_phase_kernel(dev, fed):
         return [c for c in nm.sosfiltfilt(producer(x, cs, axis), sos, axis)]
 
     narrow = sps.butter(4, [0.01, 0.02], "bandpass", output="sos")
+    # (the last-but-two: the worst-conditioned fit the tables admit, 1e-16 / ratio = 3e-10 of the
+    # output scale: 1e-9 asserted chunk for chunk where the others hold 1e-11)
     for sos, C, cs, total, axis, zp in ((BP, 64, 131072, 131072 * 6 + 4321, -1, True),
                                         (sps.butter(5, 0.3, output="sos"), 5, 70000, 70000 * 7, 0, True),
                                         (sps.cheby1(6, 0.5, 0.2, output="sos"), 3, 100001, 100001 * 6 + 17, -1, True),
+                                        # a left tail of seven rows: blocks of 25, the eight-row instance
+                                        (sps.butter(6, [8 / 250, 30 / 250], "bandpass", output="sos"), 4, 131072,
+                                         131072 * 6 + 77, -1, True),
                                         (narrow, 4, 131072, 131072 * 6 + 5, -1, False),
                                         (BP, 4, 131072, 131072 * 5, -1, False)):
         xd = dev.synth_normal(C, total, seed=71)
@@ -248,9 +253,10 @@ def test_plain_sosfiltfilt_takes_the_zero_phase_kernel(dev, fed):
         assert [g.shape for g in got] == [r.shape for r in ref]
         assert all(isinstance(g, np.ndarray) == (fed == "host") for g in got)
         to_np = (lambda a: a) if fed == "host" else (lambda a: a.cpu().numpy())
+        tol = 1e-9 if (C, cs) == (4, 131072) and zp else 1e-11
         for k, (a, b) in enumerate(zip(got, ref)):
             a, b = to_np(a), to_np(b)
-            assert np.max(np.abs(a - b)) < 1e-11 * np.max(np.abs(b)), (C, cs, k)
+            assert np.max(np.abs(a - b)) < tol * np.max(np.abs(b)), (C, cs, k)
         gh = np.concatenate([to_np(g) for g in got], axis)
         xh = xd.cpu().numpy()
         if axis == 0:

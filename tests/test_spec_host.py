@@ -422,7 +422,7 @@ class ModelZpn:
         P = P[..., 0] + 1j * P[..., 1]
         t = np.arange(256)
         self.P = P[t >> 5] * P[8 + ((t >> 2) & 7)] * P[16 + (t & 3)]
-        Lr = T["L"].reshape(5, self.NM, 2)
+        Lr = T["L"].reshape(-1, self.NM, 2)                            # (eight rows: spec::kRMaxN)
         self.Lr = Lr[..., 0] + 1j * Lr[..., 1]
         self.lsel = np.concatenate([np.arange(self.nh), np.arange(256 - self.nh, 256)])
         self.tw = np.exp(-1j * np.pi * np.arange(N) / MW)
@@ -531,6 +531,7 @@ ZPN_CASES = ZP_CASES + [
     ("eight sections (eight modes), 1024 taps", 1024, sps.butter(8, [0.05, 0.3], "bandpass", output="sos")),
     ("Butter [8, 30] / [3, 60] Hz at 500 Hz (SURVEY 8d's class-API cfg-3), 1024 taps", 1024,
      sps.butter(6, [8 / 250, 30 / 250], "bandpass", output="sos")),
+    ("a cascade alone whose left tail takes eight rows (blocks of 24)", 2, sps.cheby1(5, 1, 0.2, output="sos")),
 ]
 
 
@@ -543,7 +544,7 @@ def test_single_block_tables_and_block_algorithm(exe, name, ntaps, sos):
     T = tables_zp(exe, taps, sos, mode="zpn")
     assert T["eligible"], name
     NB, R, Rf = T["NR"], T["R"], T["Rf"]
-    assert 24 <= NB <= min((7937 - ntaps) // 256, 30) and 1 <= Rf <= R <= min(32 - NB, 5) and 32 - NB + Rf <= NB
+    assert 24 <= NB <= min((7937 - ntaps) // 256, 30) and 1 <= Rf <= R <= min(32 - NB, 8) and 32 - NB + Rf <= NB
     assert T["NS"] in (2, 4, 6) and T["NS"] <= T["NM"] <= 8
     wq = 2 * np.pi * (np.arange(N) + 0.25) / N
     _, h = sps.sosfreqz(sos, worN=wq)
