@@ -55,6 +55,7 @@
 #include "handles.h"
 #include "sos_tile.h"
 #include "chain_spec.h"
+#include "chain_zp.h"
 
 namespace osz {
 
@@ -400,6 +401,11 @@ struct ChainSpec {
     int64_t hist_n = 0, since_import = 0;
     double *dsnap_fir = nullptr, *dsnap_sos = nullptr;
     double *dscratch = nullptr;    // (nch, hist_cap)
+    // one real block per transform (chain_zpn_body.h, ZP = false; tables of spec::build_specn): NR is
+    // then its rows per block, R its burst rows; dT = L | P | M as the kernel's LDS holds them
+    bool nega = false;
+    int NS = 0, nh = 0;
+    double *dT = nullptr;
 };
 
 static void spec_free(ChainSpec *s) {
@@ -414,6 +420,7 @@ static void spec_free(ChainSpec *s) {
     (void)hipFree(s->dsnap_fir);
     (void)hipFree(s->dsnap_sos);
     (void)hipFree(s->dscratch);
+    (void)hipFree(s->dT);
     delete s;
 }
 
@@ -432,14 +439,47 @@ static int spec_build(ChainSpec *s) {
     s->eligible = false;
     if (fir->parts.size() != 1 || fir->nch != sos->nch) return OSZ_OK;
     const int wlen = fir->ntaps, nsec = sos->nsec;
-    const spec::Tables T = spec::build(fir->htaps.data(), wlen, sos->coef, nsec, sos->warm_len <= (1 << 20));
-    if (!T.eligible) return OSZ_OK;
     auto up = [](double **d, const std::vector<double> &v) -> int {
         OSZ_HIP(hipMalloc(d, v.size() * sizeof(double)));
         OSZ_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
         return OSZ_OK;
     };
     int rcu;
+    // one real block per transform where its tables exist (OSZ_SPEC_NEGA=0: the pair kernel below)
+    static const bool nega_on = [] {
+        const char *e = getenv("OSZ_SPEC_NEGA");
+        return !(e && e[0] == '0');
+    }();
+    if (nega_on) {
+        const spec::TablesZp Tn = spec::build_specn(fir->htaps.data(), wlen, sos->coef, nsec, sos->warm_len <= (1 << 20));
+        if (Tn.eligible) {
+            const size_t nl = (size_t)Tn.R * Tn.NM * 2;
+            std::vector<double> cat(Tn.L.begin(), Tn.L.begin() + nl);
+            cat.insert(cat.end(), Tn.P.begin(), Tn.P.end());
+            cat.insert(cat.end(), Tn.M.begin(), Tn.M.end());
+            if ((rcu = up(&s->dH, spec_permuted_spectrum(Tn.H))) || (rcu = up(&s->dT, cat))) return rcu;
+            const size_t cbn = sizeof(double) * (size_t)fir->nch * kSpecLdc;
+            for (int q = 0; q < 2; ++q) {
+                OSZ_HIP(hipMalloc(&s->dcarry[q], cbn));
+                OSZ_HIP(hipMemset(s->dcarry[q], 0, cbn));
+            }
+            s->hist_cap = (wlen - 1) + (int)sos->warm_len;
+            for (int q = 0; q < 2; ++q)
+                OSZ_HIP(hipMalloc(&s->dhist[q], sizeof(double) * (size_t)fir->nch * s->hist_cap));
+            OSZ_HIP(hipMalloc(&s->dsnap_fir, sizeof(double) * (size_t)fir->nch * (wlen - 1)));
+            OSZ_HIP(hipMalloc(&s->dsnap_sos, sizeof(double) * (size_t)nsec * fir->nch * 2));
+            s->NR = Tn.NR;
+            s->NM = Tn.NM;
+            s->NS = Tn.NS;
+            s->R = Tn.R;
+            s->nh = Tn.nh;
+            s->nega = true;
+            s->eligible = true;
+            return OSZ_OK;
+        }
+    }
+    const spec::Tables T = spec::build(fir->htaps.data(), wlen, sos->coef, nsec, sos->warm_len <= (1 << 20));
+    if (!T.eligible) return OSZ_OK;
     if ((rcu = up(&s->dH, spec_permuted_spectrum(T.H))) || (rcu = up(&s->dM, T.M)) || (rcu = up(&s->dP, T.P)) || (rcu = up(&s->dL, T.L)))
         return rcu;
     const size_t cb = sizeof(double) * (size_t)fir->nch * kSpecLdc;
@@ -537,6 +577,86 @@ static spec_kern_t spec_kernel_for(int nr) {
     return k[nr - 8];
 }
 
+// the same on one real block per transform: chain_zpn_kernel<NB, NM, NS, 5, false>
+static int specn_forward(ChainSpec *s, const double *x, int64_t ldx, int64_t n, double *f, int64_t ldf,
+                         hipStream_t st, const std::function<int()> &between, bool *taken) {
+    osz_fir_s *fir = s->fir;
+    const int NB = s->NR, S = 256 * NB;
+    if (n < 2 * (int64_t)S) return OSZ_OK;                // a whole block and a closing one at least
+    if (!s->carry_valid) {
+        int rc = spec_import(s, st);
+        if (rc) return rc;
+    }
+    {
+        int rc = between();
+        if (rc) return rc;
+    }
+    const int64_t W = (n - 1) / S;                        // whole blocks; the closing one has 1 .. S samples
+    int64_t nruns = 512 / fir->nch;
+    if (nruns > W) nruns = W;
+    if (nruns < 1) nruns = 1;
+    ZpArgs g{};
+    g.f.x = x;
+    g.f.y = f;
+    g.f.ldx = ldx;
+    g.f.ldy = ldf;
+    g.f.n = n;
+    g.f.skip = 0;
+    g.f.wlen = fir->ntaps;
+    g.f.step = S;
+    g.f.H = s->dH;
+    g.f.tb = fir->tb;
+    g.n = n;
+    g.W = W;
+    g.nruns = (int)nruns;
+    g.la = (int)(n - W * S);
+    g.R = s->R;
+    g.Rf = s->R;
+    g.nh = s->nh;
+    g.Lrow = s->dT;
+    g.carry_in = s->dcarry[s->cur];
+    g.carry_out = s->dcarry[s->cur ^ 1];
+    if (n >= s->hist_cap) {
+        g.hist = s->dhist[s->hcur];
+        g.hist_len = s->hist_cap;
+        s->hist_n = s->hist_cap;
+    } else {
+        const int64_t keep = std::min<int64_t>(s->hist_n, s->hist_cap - n);
+        double *dst = s->dhist[s->hcur ^ 1];
+        if (keep > 0)
+            OSZ_HIP(hipMemcpy2DAsync(dst, sizeof(double) * s->hist_cap,
+                                     s->dhist[s->hcur] + (s->hist_n - keep), sizeof(double) * s->hist_cap,
+                                     sizeof(double) * keep, fir->nch, hipMemcpyDeviceToDevice, st));
+        OSZ_HIP(hipMemcpy2DAsync(dst + keep, sizeof(double) * s->hist_cap, x, sizeof(double) * ldx,
+                                 sizeof(double) * n, fir->nch, hipMemcpyDeviceToDevice, st));
+        s->hcur ^= 1;
+        s->hist_n = keep + n;
+    }
+    s->since_import += n;
+    zp_kern_t kern = zpn_fwd_kernel_for(NB, s->NM, s->NS);
+    if (!kern) return fail(OSZ_ERR_STATE, "forward chain kernel: no instance for %d rows, %d modes (%d slow)", NB, s->NM, s->NS);
+    const int ns = 2 * s->nh;
+    const size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS +
+                       sizeof(double) * (ns + 3 * s->R * s->NS * 2 + s->R * s->NM * 2 + 20 * s->NM * 2 + 2 * s->NS * ns) + 1024;
+    OSZ_DYN_LDS(kern, lds);
+    {
+        KernelTimer kt("chain_fwd", st);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nruns, fir->nch), dim3(256), lds, st, g);
+    }
+    OSZ_HIP(hipGetLastError());
+    {
+        // NaN reach of the forward pass across runs (sos_tile.h): runs of (r W) / nruns blocks of S samples
+        int rcs = sos_seal_launch(g.f.y, g.f.ldy, n, (int)nruns, W, nruns, (int64_t)S, nullptr, 0, fir->nch,
+                                  g.carry_out, kSpecLdc, kSpecLdc, st);
+        if (rcs) return rcs;
+    }
+    s->cur ^= 1;
+    s->true_valid = false;
+    *taken = true;
+    return OSZ_OK;
+}
+
+
 // FIR + forward cascade of one chunk by the spectral kernel, if it applies to this
 // pair of handles and this chunk (*taken says); `between` runs before the launch
 // (osz_chain_step starts the backward pass on its side stream there)
@@ -568,6 +688,7 @@ int spec_try_forward(osz_fir_s *fir, osz_sos_s *sos, const double *x, int64_t ld
         }
     }
     if (!s->eligible) return OSZ_OK;
+    if (s->nega) return specn_forward(s, x, ldx, n, f, ldf, st, between, taken);
     const int NR = s->NR, S = 256 * NR;
     const int64_t pair = 2 * (int64_t)S;
     if (n < 2 * pair) return OSZ_OK;                      // an opening and a closing pair at least

@@ -76,5 +76,7 @@ __device__ __forceinline__ double zp_dot(const double *kk, const double *pr, con
 // first NS (2, 4, 6) are slow
 using zp_kern_t = void (*)(ZpArgs);
 zp_kern_t zpn_kernel_for(int nb, int nm, int ns, int r);
+// ... and its forward-chain instances (FIR -> sosfilt, no left tail; chain_spec.hip launches them)
+zp_kern_t zpn_fwd_kernel_for(int nb, int nm, int ns);
 
 }  // namespace osz

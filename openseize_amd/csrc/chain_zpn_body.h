@@ -50,13 +50,14 @@ namespace osz {
 //   kmu[r][q], q < NS    this block's mu;  kapN[r][q]: what the NEXT block meets as the previous one's
 //   knu[r][q], q < NM    this block's nu (rows behind the first are read for the slow modes only)
 // M's rows: Re mu [NS], Im mu [NS], Re nu [NM], Im nu [NM].
-template <int NM, int NS, int PER, int RM>
+template <int NM, int NS, int PER, int RM, bool ZP>
 __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fitbuf, const double *mtab,
                                                 const double *lrow, double *kmu, double *knu, double *kapN) {
     constexpr int ns = 16 * PER;
-    if ((tt & ~63) >= 16 * (NS + NM)) return;    // whole waves without an amplitude skip the stage
+    constexpr int NA = NS + (ZP ? NM : 0);       // amplitudes: the forward chain has no left tail
+    if ((tt & ~63) >= 16 * NA) return;           // whole waves without an amplitude skip the stage
     const int qd = tt >> 4, p16 = tt & 15;
-    const bool valid = qd < NS + NM;
+    const bool valid = qd < NA;
     const bool is_mu = qd < NS;
     const int q = valid ? (is_mu ? qd : qd - NS) : 0;
     const int rre = is_mu ? q : 2 * NS + q, rim = is_mu ? NS + q : 2 * NS + NM + q;
@@ -106,12 +107,12 @@ __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fit
 }
 
 // nh is 16, 24 or 32 (spec::build_zpn)
-template <int NM, int NS, int RM>
+template <int NM, int NS, int RM, bool ZP>
 __device__ __forceinline__ void zpn_fit_kappa(int tt, int nh, int R, const double *fitbuf, const double *mtab,
                                               const double *lrow, double *kmu, double *knu, double *kapN) {
-    if (nh == 24) zpn_fit_kappa_n<NM, NS, 3, RM>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
-    else if (nh == 32) zpn_fit_kappa_n<NM, NS, 4, RM>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
-    else zpn_fit_kappa_n<NM, NS, 2, RM>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
+    if (nh == 24) zpn_fit_kappa_n<NM, NS, 3, RM, ZP>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
+    else if (nh == 32) zpn_fit_kappa_n<NM, NS, 4, RM, ZP>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
+    else zpn_fit_kappa_n<NM, NS, 2, RM, ZP>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
 }
 
 // lambda_q^e, q = q0 .. q0 + NG - 1, e = 0..255, from the three-level table [20][NM][2]
@@ -183,22 +184,28 @@ __device__ __forceinline__ void zpn_bwd_bursts(double *im, double *c7, const dou
 }
 
 // RM: burst rows the instance holds registers for (5, or 8 for the long left tails of blocks of
-// 24 ... 26 rows)
-template <int NB, int NM, int NS, int RM = kSpecRMax>
+// 24 ... 26 rows).  ZP = false: the FORWARD chain (FIR -> sosfilt, chain_spec.hip's
+// osz_chain_forward): no left tail -- no backward bursts, no rows held back, no output lag, the
+// fit reads the right tail's amplitudes only (tables of spec::build_specn), the runs are cut
+// evenly (the NaN seal behind the launch finds their ends that way).
+template <int NB, int NM, int NS, int RM = kSpecRMax, bool ZP = true>
 __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     constexpr int D = 32 - NB, S = 256 * NB, NHI = NB - 16, NP = (NB + 1) / 2;
     static_assert(NB >= 24 && NB <= 30, "rows per block");
     extern __shared__ fft::cube::C2 cube_lds[];
-    const int R = g.R, Rf = g.Rf, nh = g.nh, ns = 2 * nh;
+    const int Rt = g.R;                                // rows of the amplitude tables
+    const int R = ZP ? g.R : 0;                        // rows of the left tail, and of the lag
+    const int Rf = g.Rf, nh = g.nh, ns = 2 * nh;
+    constexpr int NMROWS = 2 * NS + (ZP ? 2 * NM : 0);  // rows of the fit matrix
     double *xl = reinterpret_cast<double *>(cube_lds) + 2 * fft::cube::SLOTS;   // behind the cube
     double *fitbuf = xl;                               // [2 nh]
-    double *kmu = fitbuf + ns;                         // [R][NS][2]: this block's mu (slow modes)
-    double *knu = kmu + R * NS * 2;                    // [R][NM][2]: this block's nu
-    double *kapP = knu + R * NM * 2;                   // [2 parity][R][NS][2]: the previous block's mu
-    double *lrow = kapP + 2 * R * NS * 2;              // [R][NM][2]
-    double *ptab = lrow + R * NM * 2;                  // [20][NM][2]
-    double *mtab = ptab + 20 * NM * 2;                 // [2 NS + 2 NM][2 nh]
-    fft::cube::C2 *tw2l = reinterpret_cast<fft::cube::C2 *>(mtab + (2 * NS + 2 * NM) * ns);   // [4 q][16 n0]
+    double *kmu = fitbuf + ns;                         // [Rt][NS][2]: this block's mu (slow modes)
+    double *knu = kmu + Rt * NS * 2;                   // [Rt][NM][2]: this block's nu (ZP)
+    double *kapP = knu + (ZP ? Rt * NM * 2 : 0);       // [2 parity][Rt][NS][2]: the previous block's mu
+    double *lrow = kapP + 2 * Rt * NS * 2;             // [Rt][NM][2]
+    double *ptab = lrow + Rt * NM * 2;                 // [20][NM][2]
+    double *mtab = ptab + 20 * NM * 2;                 // [2 NS (+ 2 NM)][2 nh]
+    fft::cube::C2 *tw2l = reinterpret_cast<fft::cube::C2 *>(mtab + NMROWS * ns);   // [4 q][16 n0]
     const FirArgs &a = g.f;
     const int t = threadIdx.x, run = blockIdx.x, c = blockIdx.y;
     const int L = 256 * R;
@@ -210,8 +217,10 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     double *ho = g.held_out + (int64_t)c * L;
     // (the partition's 64-bit divisions run on the vector unit: their results, uniform, go back to
     // scalar registers -- a chunk has far fewer than 2^31 blocks)
-    const int p0 = __builtin_amdgcn_readfirstlane((int)zp_run_start(run, g.W, g.nruns, g.wclose));
-    const int p1 = __builtin_amdgcn_readfirstlane((int)zp_run_start(run + 1, g.W, g.nruns, g.wclose));
+    const int p0 = __builtin_amdgcn_readfirstlane(
+        (int)(ZP ? zp_run_start(run, g.W, g.nruns, g.wclose) : ((int64_t)run * g.W) / g.nruns));
+    const int p1 = __builtin_amdgcn_readfirstlane(
+        (int)(ZP ? zp_run_start(run + 1, g.W, g.nruns, g.wclose) : ((int64_t)(run + 1) * g.W) / g.nruns));
     const int first = run == 0 ? 0 : p0 - 1;
     const int lastf = p1 - 1;
     const bool closes = run == g.nruns - 1;
@@ -231,17 +240,17 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     if (first <= lastf) zp_request_rows<NP>(xr + (int64_t)first * S, NB, t, cube_lds);
     {
         // lrow | ptab | mtab are one table on the device too (g.Lrow)
-        const int ntab = R * NM * 2 + 20 * NM * 2 + (2 * NS + 2 * NM) * ns;
+        const int ntab = Rt * NM * 2 + 20 * NM * 2 + NMROWS * ns;
 #pragma unroll 8
         for (int i = t; i < ntab; i += 256) lrow[i] = g.Lrow[i];
     }
-    for (int i = t; i < 2 * R * NS * 2; i += 256) kapP[i] = 0.0;
+    for (int i = t; i < 2 * Rt * NS * 2; i += 256) kapP[i] = 0.0;
     double held[RM];                 // rows NB-1-r of the previous block, one burst short
 #pragma unroll
     for (int r = 0; r < RM; ++r) held[r] = 0.0;
     // `bad` is uniform (a scalar), and sticky: the stream went bad in an earlier chunk, or a block
     // of this run held non-finite samples -- behind the transform they are everywhere
-    bool bad = g.nanpos[c] != 0x7fffffffffffffffLL;
+    bool bad = ZP ? g.nanpos[c] != 0x7fffffffffffffffLL : false;
     int64_t bad_at = 0;
     int par = 0;
     int younger = -1;                // vector-memory operations behind the pending requests
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
         OSZ_BSTAMP(11);   // fit samples to LDS + overlap add
         __syncthreads();
         OSZ_BSTAMP(12);   // barrier 5
-        zpn_fit_kappa<NM, NS, RM>(tt, nh, R, fitbuf, mtab, lrow, kmu, knu, kapP + (par ^ 1) * (R * NS * 2));
+        zpn_fit_kappa<NM, NS, RM, ZP>(tt, nh, Rt, fitbuf, mtab, lrow, kmu, knu, kapP + (par ^ 1) * (Rt * NS * 2));
         __syncthreads();
         OSZ_BSTAMP(13);   // fit + barrier 6
         double c7[RM];
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
         {
             double Pr[NS], Pi[NS];
             zpn_powers<NM, NS>(ptab, 0, tt, Pr, Pi);
-            const double *kpm = kapP + par * (R * NS * 2);
+            const double *kpm = kapP + par * (Rt * NS * 2);
             double ca = 0.0;
             switch (Rf) {
                 case 1: zpn_fwd_bursts<D, NS, 1>(re, kmu, kpm, Pr, Pi, ca); break;
@@ -329,8 +338,8 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
             // (no fence between the two halves: with two slow modes both sets of powers fit beside
             // the data, and the backward half's table reads go out behind the forward half's)
             double Qr[NS], Qi[NS];
-            zpn_powers<NM, NS>(ptab, 0, 255 - tt, Qr, Qi);
-            switch (R) {
+            if (ZP) zpn_powers<NM, NS>(ptab, 0, 255 - tt, Qr, Qi);
+            if (ZP) switch (R) {
                 case 1: zpn_bwd_bursts<NM, NS, 1>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
                 case 2: zpn_bwd_bursts<NM, NS, 2>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
                 case 3: zpn_bwd_bursts<NM, NS, 3>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
@@ -366,14 +375,16 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 re[j] += ci[256 * j];
                 if (j < NHI) im[j] += ci[4096 + 256 * j];
             }
-            const double *hi = g.held_in + (int64_t)c * L + tt;
+            if (ZP) {
+                const double *hi = g.held_in + (int64_t)c * L + tt;
 #pragma unroll
-            for (int r = 0; r < RM; ++r)
-                if (r < R) {
-                    const int64_t q = 256 * (R - 1 - r) + tt;
-                    (q < n0 ? y0r : yr)[q] = bad ? qn : hi[256 * (R - 1 - r)] + c7[r];
-                }
-        } else if (p > first) {
+                for (int r = 0; r < RM; ++r)
+                    if (r < R) {
+                        const int64_t q = 256 * (R - 1 - r) + tt;
+                        (q < n0 ? y0r : yr)[q] = bad ? qn : hi[256 * (R - 1 - r)] + c7[r];
+                    }
+            }
+        } else if (ZP && p > first) {
             // the previous block's last R rows, complete now (also those of the block a run
             // starts early with: the run before this one leaves them to us)
             if (!bad && !closing && o - S + L >= n0) {
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
 #undef OSZ_ZP_PUT
     // where the forward stream of this channel first went bad (chain_zp.hip: later launches start
     // bad, osz_chain_zp_seal settles the chunks the reference loses)
-    if (bad && t == 0) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
+    if (ZP && bad && t == 0) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
 }
 
 // (one translation unit per mode count: chain_zpn_{2,4,6,8}.hip define OSZ_ZPN_NM and include
@@ -494,7 +505,33 @@ zp_kern_t OSZ_ZPN_CAT(zpn_kernel_nm, OSZ_ZPN_NM)(int nb, int ns, int r) {
     return nullptr;
 }
 
+// the forward chain's instances (ZP = false, five burst rows): zpn_fwd_kernel_nm2 / 4 / 6 / 8 (nb, ns)
+template <int NM, int NS>
+static zp_kern_t zpn_fwd_kernel_nb(int nb) {
+    static const zp_kern_t k[7] = {
+        chain_zpn_kernel<24, NM, NS, kSpecRMax, false>, chain_zpn_kernel<25, NM, NS, kSpecRMax, false>,
+        chain_zpn_kernel<26, NM, NS, kSpecRMax, false>, chain_zpn_kernel<27, NM, NS, kSpecRMax, false>,
+        chain_zpn_kernel<28, NM, NS, kSpecRMax, false>, chain_zpn_kernel<29, NM, NS, kSpecRMax, false>,
+        chain_zpn_kernel<30, NM, NS, kSpecRMax, false>};
+    return k[nb - 24];
+}
+zp_kern_t OSZ_ZPN_CAT(zpn_fwd_kernel_nm, OSZ_ZPN_NM)(int nb, int ns) {
+    constexpr int NM = OSZ_ZPN_NM;
+    if (nb < 24 || nb > 30) return nullptr;
+    if (ns == 2) return zpn_fwd_kernel_nb<NM, 2>(nb);
+    if (NM >= 4 && ns == 4) return zpn_fwd_kernel_nb<NM, (NM >= 4 ? 4 : 2)>(nb);
+    if (NM >= 6 && ns == 6) return zpn_fwd_kernel_nb<NM, (NM >= 6 ? 6 : 2)>(nb);
+    return nullptr;
+}
+
 #if OSZ_ZPN_NM == 2
+zp_kern_t zpn_fwd_kernel_nm4(int nb, int ns);
+zp_kern_t zpn_fwd_kernel_nm6(int nb, int ns);
+zp_kern_t zpn_fwd_kernel_nm8(int nb, int ns);
+zp_kern_t zpn_fwd_kernel_for(int nb, int nm, int ns) {
+    return nm == 2 ? zpn_fwd_kernel_nm2(nb, ns) : nm == 4 ? zpn_fwd_kernel_nm4(nb, ns) : nm == 6 ? zpn_fwd_kernel_nm6(nb, ns)
+           : nm == 8 ? zpn_fwd_kernel_nm8(nb, ns) : nullptr;
+}
 zp_kern_t zpn_kernel_nm4(int nb, int ns, int r);
 zp_kern_t zpn_kernel_nm6(int nb, int ns, int r);
 zp_kern_t zpn_kernel_nm8(int nb, int ns, int r);

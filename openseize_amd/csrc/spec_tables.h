@@ -740,5 +740,212 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
     return T;
 }
 
+
+// ---- the forward chain (FIR -> sosfilt) on one real block per transform ------------------
+// The causal half of build_zpn: the composite response is the taps through the cascade, one
+// sided; only the right tail rings, wraps (negacyclic: with its sign changed) and is fitted --
+// on row 31, which holds nothing else -- and continued into the next block.  No left tail: no
+// output lag, no rows held back.
+//   NR    rows per block (24 .. 30): the largest with 256 NR + wlen - 1 <= 7936 and D + Rf <= NR
+//   R=Rf  burst rows of the right tail (<= 5)
+//   H     [4096][2]  H_fir H_iir at 2 pi (j + 1/4) / 4096, / 4096
+//   M     [2 NS][2 nh]  mu of the slow modes (Re rows, Im rows) from the first and last nh samples
+//         of row 31, every mode in the fit's basis
+//   P, L  as above
+inline TablesZp build_specn(const double *taps, int wlen, const double *sos, int nsec, bool forgets,
+                            int lds_budget = 15360 - 1024, ld_t tail_tol = kTailTol, ld_t fit_floor = 3e-7L) {
+    TablesZp T;
+    constexpr int kM = 8192;
+    if (wlen < 2 || !forgets) return T;
+    std::vector<Mode> modes;
+    for (int q = 0; q < nsec; ++q) {
+        const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+        if (a1 == 0.0L && a2 == 0.0L) continue;
+        if (a2 == 0.0L) {
+            modes.push_back({-a1, 0.0L, true});
+            continue;
+        }
+        const ld_t disc = a1 * a1 - 4.0L * a2;
+        if (disc < 0.0L) {
+            modes.push_back({-a1 / 2, sqrtl(-disc) / 2, false});
+        } else if (disc > 0.0L) {
+            modes.push_back({(-a1 + sqrtl(disc)) / 2, 0.0L, true});
+            modes.push_back({(-a1 - sqrtl(disc)) / 2, 0.0L, true});
+        } else {
+            return T;
+        }
+    }
+    const int nm = (int)modes.size();
+    if (nm < 1 || nm > 8) return T;
+    for (auto &m : modes)
+        if (!(m.re * m.re + m.im * m.im < 1.0L)) return T;
+    std::stable_sort(modes.begin(), modes.end(), [](const Mode &a, const Mode &b) {
+        return a.re * a.re + a.im * a.im > b.re * b.re + b.im * b.im;
+    });
+    const int NM = (nm + 1) & ~1;
+    const int glen = kM + 256 * 17;
+    std::vector<ld_t> g(glen, 0.0L);
+    for (int i = 0; i < wlen && i < glen; ++i) g[i] = taps[i];
+    for (int q = 0; q < nsec; ++q) {
+        const ld_t b0 = sos[6 * q], b1 = sos[6 * q + 1], b2 = sos[6 * q + 2];
+        const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+        ld_t z0 = 0.0L, z1 = 0.0L;
+        for (int i = 0; i < glen; ++i) {
+            const ld_t xin = g[i], y = b0 * xin + z0;
+            z0 = b1 * xin - a1 * y + z1;
+            z1 = b2 * xin - a2 * y;
+            g[i] = y;
+        }
+    }
+    std::vector<ld_t> tail2(glen + 1, 0.0L);
+    for (int i = glen - 1; i >= 0; --i) tail2[i] = tail2[i + 1] + g[i] * g[i];
+    const ld_t tot = sqrtl(tail2[0]);
+    int NBmax = (7937 - wlen) / 256;
+    if (NBmax > 30) NBmax = 30;
+    int NB = 0, Rf = 0;
+    for (int cand = NBmax; cand >= 24 && !NB; --cand) {
+        const int S = 256 * cand, D = 32 - cand;
+        int rf = 0;
+        for (int r = 1; r <= kRMax && !rf; ++r) {
+            const int ir = kM + 256 * r - S + 1;
+            if (ir >= glen) break;
+            if (sqrtl(tail2[ir]) <= tail_tol * tot) rf = r;
+        }
+        if (rf && D + rf <= cand) {
+            NB = cand;
+            Rf = rf;
+        }
+    }
+    if (!NB) return T;
+    // slow modes: residues of the right tail g[wlen - 1 + n] = Re sum c_q lambda^n
+    int ns_needed = 0;
+    {
+        std::vector<int> cm, ck;
+        for (int q = 0; q < nm; ++q) {
+            cm.push_back(q);
+            ck.push_back(0);
+            if (!modes[q].real) {
+                cm.push_back(q);
+                ck.push_back(1);
+            }
+        }
+        const int ndh = (int)cm.size(), nfit = 64;
+        std::vector<ld_t> Bh((size_t)nfit * ndh);
+        for (int j = 0; j < ndh; ++j)
+            for (int i = 0; i < nfit; ++i) {
+                ld_t pr, pi;
+                mode_pow(modes[cm[j]], i, pr, pi);
+                Bh[(size_t)j * nfit + i] = ck[j] ? -pi : pr;
+            }
+        std::vector<ld_t> Ph;
+        if (pinv_qr(Bh, nfit, ndh, Ph) == 0.0L) return T;
+        for (int q = 0; q < nm; ++q) {
+            ld_t cr = 0.0L, ci = 0.0L;
+            for (int j = 0; j < ndh; ++j)
+                if (cm[j] == q)
+                    for (int i = 0; i < nfit; ++i) (ck[j] ? ci : cr) += Ph[(size_t)j * nfit + i] * g[wlen - 1 + i];
+            const ld_t rad2 = modes[q].re * modes[q].re + modes[q].im * modes[q].im;
+            const ld_t share = sqrtl(cr * cr + ci * ci) * powl(sqrtl(rad2), 257.0L) / sqrtl(1.0L - rad2);
+            if (share > tail_tol * tot / (ld_t)(4 * nm)) ns_needed = q + 1;
+        }
+    }
+    int NS = (std::max(ns_needed, 1) + 1) & ~1;
+    if (NS > NM) NS = NM;
+    if (NS > 6) return T;
+    // LDS behind the cube: fit samples [2 nh], this block's mu [Rf][NS][2], the previous block's
+    // [2 parity][Rf][NS][2], L [Rf][NM][2], P [20][NM][2], M [2 NS][2 nh]
+    int nh = 0;
+    for (int cand = 32; cand >= 16 && !nh; cand -= 8) {
+        const int bytes = 8 * (2 * cand + Rf * 3 * NS * 2 + Rf * NM * 2 + 20 * NM * 2 + 2 * NS * 2 * cand);
+        if (bytes <= lds_budget) nh = cand;
+    }
+    if (!nh) return T;
+    const int ns = 2 * nh;
+    std::vector<int> col_mode, col_im;
+    for (int q = 0; q < nm; ++q) {
+        col_mode.push_back(q);
+        col_im.push_back(0);
+        if (!modes[q].real) {
+            col_mode.push_back(q);
+            col_im.push_back(1);
+        }
+    }
+    const int nd = (int)col_mode.size();
+    std::vector<ld_t> B((size_t)ns * nd);
+    for (int j = 0; j < nd; ++j)
+        for (int i = 0; i < ns; ++i) {
+            const int l = i < nh ? i : 256 - ns + i;
+            ld_t pr, pi;
+            mode_pow(modes[col_mode[j]], l, pr, pi);
+            B[(size_t)j * ns + i] = col_im[j] ? -pi : pr;
+        }
+    std::vector<ld_t> Pinv;
+    const ld_t ratio = pinv_qr(B, ns, nd, Pinv);
+    T.fit_ratio = (double)ratio;
+    if (!(ratio > fit_floor)) return T;
+    T.M.assign((size_t)2 * NS * ns, 0.0);
+    for (int q = 0; q < nm && q < NS; ++q) {
+        int ja = -1, jb = -1;
+        for (int j = 0; j < nd; ++j)
+            if (col_mode[j] == q) (col_im[j] ? jb : ja) = j;
+        ld_t cr, ci;
+        mode_pow(modes[q], 256, cr, ci);                      // mu = gamma lambda^256
+        for (int i = 0; i < ns; ++i) {
+            const ld_t av = Pinv[(size_t)ja * ns + i];
+            const ld_t bv = jb >= 0 ? Pinv[(size_t)jb * ns + i] : 0.0L;
+            T.M[(size_t)q * ns + i] = (double)(cr * av - ci * bv);
+            T.M[(size_t)(NS + q) * ns + i] = (double)(ci * av + cr * bv);
+        }
+    }
+    const ld_t PI = acosl(-1.0L);
+    std::vector<ld_t> frq, fiq;
+    fir_spectrum(taps, wlen, frq, fiq, true);
+    T.H.assign(2 * kN, 0.0);
+    for (int k = 0; k < kN; ++k) {
+        const ld_t ang = -2.0L * PI * ((ld_t)k + 0.25L) / (ld_t)kN;
+        const ld_t zr = cosl(ang), zi = sinl(ang);
+        const ld_t z2r = zr * zr - zi * zi, z2i = 2.0L * zr * zi;
+        ld_t hr = frq[k] / kN, hi = fiq[k] / kN;
+        for (int q = 0; q < nsec; ++q) {
+            const ld_t b0 = sos[6 * q], b1 = sos[6 * q + 1], b2 = sos[6 * q + 2];
+            const ld_t a1 = sos[6 * q + 4], a2 = sos[6 * q + 5];
+            const ld_t nr = b0 + b1 * zr + b2 * z2r, ni = b1 * zi + b2 * z2i;
+            const ld_t dr = 1.0L + a1 * zr + a2 * z2r, di = a1 * zi + a2 * z2i;
+            const ld_t den = dr * dr + di * di;
+            const ld_t qr = (nr * dr + ni * di) / den, qi = (ni * dr - nr * di) / den;
+            const ld_t x = hr * qr - hi * qi, y = hr * qi + hi * qr;
+            hr = x;
+            hi = y;
+        }
+        T.H[2 * k] = (double)hr;
+        T.H[2 * k + 1] = (double)hi;
+    }
+    T.P.assign((size_t)20 * NM * 2, 0.0);
+    T.L.assign((size_t)kRMax * NM * 2, 0.0);
+    for (int q = 0; q < nm; ++q) {
+        for (int i = 0; i < 20; ++i) {
+            ld_t pr, pi;
+            mode_pow(modes[q], i < 8 ? 32 * i : i < 16 ? 4 * (i - 8) : i - 16, pr, pi);
+            T.P[((size_t)i * NM + q) * 2 + 0] = (double)pr;
+            T.P[((size_t)i * NM + q) * 2 + 1] = (double)pi;
+        }
+        for (int r = 0; r < kRMax; ++r) {
+            ld_t pr, pi;
+            mode_pow(modes[q], 256 * r, pr, pi);
+            T.L[((size_t)r * NM + q) * 2 + 0] = (double)pr;
+            T.L[((size_t)r * NM + q) * 2 + 1] = (double)pi;
+        }
+    }
+    T.NR = NB;
+    T.NM = NM;
+    T.nm = nm;
+    T.R = Rf;
+    T.Rf = Rf;
+    T.nh = nh;
+    T.NS = NS;
+    T.eligible = true;
+    return T;
+}
+
 }  // namespace spec
 }  // namespace osz

@@ -1,5 +1,6 @@
 // Builds the host tables of the spectral FIR -> cascade kernel (csrc/spec_tables.h)
 // with g++ and writes them out for tests/test_spec_host.py.
+//   spec_host_check <in.bin> <out.bin> [zp|zpn|specn]  (specn: the forward chain on one real block per transform)
 //   spec_host_check <in.bin> <out.bin> [zp|zpn]  (zp: the two-sided tables of chain_zp.hip;
 //                                                  zpn: those of chain_zpn.hip, one real block per transform)
 // in:  int32 wlen, int32 nsec, int32 forgets, double taps[wlen], double sos[nsec][6]
@@ -24,7 +25,9 @@ int main(int argc, char **argv) {
     if (fread(sos.data(), sizeof(double), sos.size(), f) != sos.size()) return 2;
     fclose(f);
     if (argc == 4) {
-        const osz::spec::TablesZp T = !strcmp(argv[3], "zpn")
+        const osz::spec::TablesZp T = !strcmp(argv[3], "specn")
+                                          ? osz::spec::build_specn(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0)
+                                      : !strcmp(argv[3], "zpn")
                                           ? osz::spec::build_zpn(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0, 15360 - 1024)
                                           : osz::spec::build_zp(taps.data(), hdr[0], sos.data(), hdr[1], hdr[2] != 0);
         f = fopen(argv[2], "wb");

@@ -573,3 +573,117 @@ def test_single_block_tables_and_block_algorithm(exe, name, ntaps, sos):
     # multiplied by about 1 / ratio (spec::build_zpn admits ratio > 3e-7)
     tol = max(3e-12, 1e-16 / T["ratio"])
     assert tol < 4e-10 and np.max(np.abs(got[L:] - ref[:len(got) - L])) < tol * np.max(np.abs(ref)), name
+
+
+# ------------------------------------- the forward chain on one real block per transform
+class ModelSpecN:
+    """FIR -> sosfilt (no backward pass) with the tables of spec::build_specn: the causal half of
+    ModelZpn -- the right tail wraps with its sign changed and is added back in the window,
+    continues into the next block from the previous block's amplitudes; no lag, nothing held."""
+
+    def __init__(self, T):
+        self.NB, self.NM, self.NS, self.Rf, self.nh = T["NR"], T["NM"], T["NS"], T["Rf"], T["nh"]
+        self.S, self.D = 256 * self.NB, 32 - self.NB
+        H = T["H"].reshape(N, 2)
+        self.Hq = (H[:, 0] + 1j * H[:, 1]) * N
+        M = T["M"].reshape(2 * self.NS, 2 * self.nh)
+        self.Mmu = M[:self.NS] + 1j * M[self.NS:]
+        P = T["P"].reshape(20, self.NM, 2)
+        P = P[..., 0] + 1j * P[..., 1]
+        t = np.arange(256)
+        self.P = P[t >> 5] * P[8 + ((t >> 2) & 7)] * P[16 + (t & 3)]
+        Lr = T["L"].reshape(-1, self.NM, 2)
+        self.Lr = Lr[..., 0] + 1j * Lr[..., 1]
+        self.lsel = np.concatenate([np.arange(self.nh), np.arange(256 - self.nh, 256)])
+        self.tw = np.exp(-1j * np.pi * np.arange(N) / MW)
+
+    def window(self, x):
+        buf = np.zeros(MW)
+        buf[:len(x)] = x
+        z = (buf[:N] - 1j * buf[N:]) * self.tw
+        w = np.fft.ifft(np.fft.fft(z) * self.Hq) * np.conj(self.tw)
+        return np.concatenate([w.real, -w.imag])
+
+    def burst(self, amp, e):
+        ok = (e >= 0) & (e < 256 * self.Rf)
+        ee = np.where(ok, e, 0)
+        nq = len(amp)
+        return np.where(ok, np.real(((self.Lr[ee >> 8, :nq] * self.P[ee & 255, :nq]) * amp).sum(-1)), 0.0)
+
+    def chunk(self, x, carry_in, nruns):
+        n, S, NB, D, Rf = len(x), self.S, self.NB, self.D, self.Rf
+        W = (n - 1) // S
+        assert W >= 1
+        lc = n - W * S
+        f = np.full(n, np.nan)
+        t = np.arange(256)
+        nruns = max(1, min(nruns, W))
+        carry_out = None
+        for run in range(nruns):
+            p0, p1 = run * W // nruns, (run + 1) * W // nruns
+            cr, mu_p = np.zeros((D, 256)), np.zeros(self.NS, complex)
+            blocks = list(range(p0 if run == 0 else p0 - 1, p1)) + ([W] if run == nruns - 1 else [])
+            for p in blocks:
+                o = p * S
+                la = S if p < W else lc
+                win = self.window(x[o:o + la])
+                mu = self.Mmu @ win[MW - 256 + self.lsel]
+                Y = win.reshape(32, 256).copy()
+                Y[:D] += cr
+                for r in range(Rf):
+                    Y[r] += self.burst(mu, 256 * r + t)
+                    Y[D + r] += self.burst(mu_p, 256 * r + t)
+                if p == 0:
+                    ci = np.zeros(MW)
+                    m = min(len(carry_in), MW)
+                    ci[:m] = carry_in[:m]
+                    Y += ci.reshape(32, 256)
+                if p < W:
+                    if p >= p0:
+                        f[o:o + S] = Y[:NB].ravel()
+                    cr, mu_p = Y[NB:].copy(), mu
+                else:
+                    flat = Y.ravel()
+                    f[o:n] = flat[:lc]
+                    k = np.arange(7680)
+                    src = lc + k
+                    carry_out = np.where(src < MW, flat[np.minimum(src, MW - 1)], self.burst(mu, src - MW))
+        return f, carry_out
+
+
+SPECN_CASES = CASES + [("eight sections, 1024 taps", 1024, sps.butter(8, [0.05, 0.3], "bandpass", output="sos"))]
+
+
+@pytest.mark.parametrize("name,ntaps,sos", SPECN_CASES, ids=[c[0] for c in SPECN_CASES])
+def test_forward_single_block_tables_and_block_algorithm(exe, name, ntaps, sos):
+    """FIR -> forward cascade with one real block of 8192 samples per transform: the tables of
+    spec::build_specn through the NumPy restatement of the kernel against scipy's
+    sosfilt(convolve(x, h)), every kind of chunk, the carry across chunks and as the flush."""
+    taps = sps.firwin(ntaps, 0.2)
+    T = tables_zp(exe, taps, sos, mode="specn")
+    assert T["eligible"], name
+    NB, Rf = T["NR"], T["Rf"]
+    assert 24 <= NB <= min((7937 - ntaps) // 256, 30) and 1 <= Rf <= 5 and 32 - NB + Rf <= NB
+    wq = 2 * np.pi * (np.arange(N) + 0.25) / N
+    _, h = sps.sosfreqz(sos, worN=wq)
+    Hq = np.polyval(taps[::-1], np.exp(-1j * wq)) * h / N
+    H = T["H"].reshape(N, 2)
+    assert np.max(np.abs(H[:, 0] + 1j * H[:, 1] - Hq)) < 1e-12 * np.max(np.abs(Hq))
+    m = ModelSpecN(T)
+    S = m.S
+    rng = np.random.default_rng(len(taps))
+    lens = [S * 5 + 1024, S * 4, S * 3 + S - 17, S + 5, S * 3 + S, 2 * S]
+    x = rng.standard_normal(sum(lens))
+    u = np.convolve(x, taps)
+    zi0 = sps.sosfilt_zi(sos) * u[0]
+    ref, _ = sps.sosfilt(sos, u, zi=zi0)
+    carry = np.zeros(7680)
+    cl = 4096 + 256 * Rf
+    carry[:cl] = sps.sosfilt(sos, np.zeros(cl), zi=zi0)[0]
+    o, scale = 0, np.max(np.abs(ref))
+    tol = max(1e-12, 1e-16 / T["ratio"])
+    for k, n in enumerate(lens):
+        f, carry = m.chunk(x[o:o + n], carry, nruns=[1, 2, 3, 1, 2, 1][k])
+        assert np.max(np.abs(f - ref[o:o + n])) < tol * scale, (name, k)
+        o += n
+    assert np.max(np.abs(carry[:ntaps - 1] - ref[o:o + ntaps - 1])) < tol * scale
