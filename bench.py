@@ -438,6 +438,27 @@ def run_chain(args, R, h, sos):
     _lib.check(lib.osz_profile_enable(0))
     elapsed = R.max_over_ranks(elapsed)
     R.barrier()
+    # The same K steps once more, further into the stream (NOT `value`): the first ~30 launches
+    # after the GPU was idle run up to 40 % slower while its clock / power controller settles
+    # (benchmarks/ramp_probe.py: the same on the same buffers after a 2 s pause), so K = 20
+    # steps behind W = 5 time that transient; a stream of hours runs at the rate below.
+    steady = None
+    if zp and not args.no_steady:
+        for _ in range(max(args.steps, 40 - args.steps - args.warmup)):
+            step(k)
+            k += 1
+        R.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(k)
+            k += 1
+        torch.cuda.synchronize()
+        el2 = R.max_over_ranks(time.perf_counter() - t1)
+        R.barrier()
+        steady = {"ms_per_step": el2 / args.steps * 1e3,
+                  "Msamples_s": R.ranks_seen() * C * CHUNK * args.steps / el2 / 1e6,
+                  "untimed_steps_before": k - args.steps,
+                  "note": "the same steps later in the stream, the GPU's power state settled; not `value`"}
     # order-independent checksum of the last output chunk (also the 8 B/lane
     # streaming read of known size that calibrates FETCH_SIZE in the PMC runs)
     bits, fsum = dev.checksum(fwd[(k - 3) % nf] if zp else y_out)
@@ -454,6 +475,8 @@ def run_chain(args, R, h, sos):
     extra = {"output_checksum": {"bits": f"{bits:#018x}", "sum": fsum}}
     if zp:
         extra["output_lag_samples"] = lag
+    if steady:
+        extra["steady_state"] = steady
     if args.full_stream:
         del fwd, y_out, fir_out
         fir.close()
@@ -751,6 +774,8 @@ def main():
                     help="welch: all-reduce through torch.distributed (RCCL) or through "
                          "osz_welch_reduce of the C ABI")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-steady", action="store_true",
+                    help="skip the second, later timing of the same steps (steady_state)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="chain: weak = 256 channels per rank; strong = the metric's 256 channels "
                          "split over the ranks (32 per GPU at 8 ranks)")

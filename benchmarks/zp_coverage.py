@@ -55,6 +55,11 @@ def main():
             row = {"filter": name, "setting": setting, "sections": int(sos.shape[0]), "channels": C, "chunksize": CHUNK}
             try:
                 lag = dev.chain_zp_lag(fir, iir)
+                if setting == "chain":       # what sosfilt behind the FIR runs on (osz_chain_forward_route)
+                    f2, i2 = dev.FirStream(taps, C), dev.SosStream(sos, C)
+                    row["forward_route"] = ("time scan", "pair of blocks", "one block")[dev.chain_forward_route(f2, i2)]
+                    f2.close()
+                    i2.close()
                 iir.set_state_scaled(ring[0], 0)
                 if lag >= 0:
                     dev.chain_zp_open(fir, iir, 0)

@@ -175,13 +175,21 @@ int osz_fir_flush(osz_fir_t h, double *y, int64_t ldy, int64_t skip,
  * kernel: f = sosfilt(fir(x)) for the next n samples of every channel, both
  * handles' carried states advanced exactly as osz_fir_push(skip = 0) followed
  * by osz_sos_forward would.  The FIR output never reaches HBM (16 instead of
- * 32 B per channel-sample).  Whole pairs of FIR blocks go through the fused
- * kernel, the ragged end of the chunk through the separate kernels.  Filters
- * the fused kernel does not take (partitioned FIRs; fewer than 4 block pairs)
- * return OSZ_ERR_UNSUPPORTED unless n is less than one SOS tile.
+ * 32 B per channel-sample).  Which kernel takes the chunk: osz_chain_forward_route
+ * below.  What no fused kernel takes (partitioned FIRs, chunks of fewer than four
+ * block pairs on route 0, the ragged head of a chunk there) runs through the
+ * separate kernels inside the call: same results, same carried states.
  */
 int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,
                       int64_t n, double *f, int64_t ldf, void *stream);
+/* Which kernel osz_chain_forward runs the whole blocks of this pair of handles on:
+ * 2 = FIR and cascade as one multiplication per bin, one 8192-sample block per 4096-point
+ * transform (chain_zpn_kernel<.., ZP = false>); 1 = the same with a pair of blocks per
+ * transform (chain_spec_kernel: cascades the first does not take); 0 = the FIR in the
+ * spectrum and the cascade as a scan in time (chain_kernel); -1 on error.  Builds the
+ * pair's tables on first use (cached on the handles); a handle paired otherwise before
+ * gets its own carried state back on `stream`.  Diagnostic: tests and coverage tables. */
+int osz_chain_forward_route(osz_fir_t fir, osz_sos_t sos, void *stream);
 
 /*
  * One steady-state step of the FIR -> sosfiltfilt chain: osz_chain_forward of the

@@ -686,6 +686,16 @@ def chain_forward(fir, sos, x2d, out=None):
     return f
 
 
+def chain_forward_route(fir, sos):
+    """Which kernel chain_forward runs this pair's whole blocks on (C ABI:
+    osz_chain_forward_route): 2 one block per transform with the cascade in the spectrum,
+    1 a pair of blocks per transform, 0 the cascade as a scan in time."""
+    r = int(fir.lib.osz_chain_forward_route(fir.h, sos.h, stream_ptr()))
+    if r < 0:
+        raise RuntimeError(fir.lib.osz_last_error().decode("utf-8", "replace"))
+    return r
+
+
 def chain_step(fir, sos, x2d, fa, fb=None, f_out=None, y_out=None, defer=False):
     """One steady-state step of FIR -> sosfiltfilt (C ABI: osz_chain_step): the
     fused forward half of chunk ``x2d`` -> f, and beside it, on the SOS

@@ -76,6 +76,7 @@ SIGNATURES = {
                                             c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                                             c_vp, c_i64, c_vp]),
     "osz_chain_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    "osz_chain_forward_route": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "osz_chain_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64,
                                       c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64,
                                       ctypes.c_int, c_vp]),

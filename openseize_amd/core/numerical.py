@@ -225,6 +225,13 @@ def sosfilt(pro, sos, axis, zi=None):
     ``osz_sos_forward``).  ``zi``: None (zeros) or an array of shape
     (nsections, ..., 2 along axis, ...)."""
     sos = np.atleast_2d(np.asarray(sos, dtype=np.float64))
+    fused = _fir_feeding(pro, axis)
+    if fused is not None:
+        # a resident FIR producer feeding this filter: one kernel per chunk for both
+        gen = _sosfilt_after_fir(pro, *fused, sos, zi)
+        if gen is not None:
+            yield from gen
+            return
     layout = dev.Layout(pro.shape, axis)
     stream = dev.SosStream(sos, layout.nch)
     try:
@@ -282,6 +289,78 @@ def _fir_feeding(pro, axis):
     if int(source.chunksize) != int(pro.chunksize):
         return None
     return source, taps
+
+
+def _sosfilt_after_fir(pro, source, taps, sos, zi):
+    """``sosfilt(oaconvolve(source, taps, 'same'))`` for a device-resident source, chunk for
+    chunk what the two generators yield one after the other (reference core/numerical.py:158-298
+    feeding :301-335), on ``osz_chain_forward``: FIR and forward cascade of an input chunk in
+    one launch, the FIR's output never in HBM (16 instead of 32 B per channel-sample).
+
+    'same' drops the first ``lcut = (taps-1)//2`` outputs, so the piece input chunk k produces
+    is output samples [k cs - lcut, (k+1) cs - lcut).  Piece k is written at the front of a
+    fresh buffer ``lcut`` columns wider than a chunk; its first ``lcut`` columns are copied
+    behind piece k-1 (C x lcut samples: nothing beside a chunk), whose buffer then holds
+    output chunk k-1 as one view -- memory of its own, as every array the separate generators
+    yield.  Input chunk 0 (the left cut) and the overhang of the convolution go through the
+    separate kernels.  Returns None (the caller runs the two generators apart) for host-fed
+    sources, short streams, short chunks and a last chunk shorter than the cut."""
+    import torch
+    axis = pro.axis
+    cs, total = int(pro.chunksize), int(pro.shape[axis])
+    wlen = len(taps)
+    lcut, rcut = _oa_cuts(wlen, "same")
+    nchunks = -(-total // cs)
+    last = total - (nchunks - 1) * cs
+    if nchunks < 3 or cs < 65536 or total < wlen or last < max(lcut, 1):
+        return None
+    chunks = dev.pull_resident(source, source)         # a source of this library hands CUDA tensors
+    first = next(chunks, None)
+    if first is None or first.shape[axis] != cs or not (dev.is_tensor(first) and first.is_cuda):
+        chunks.close()                                 # (a reader behind the source is released)
+        return None
+
+    def run():
+        layout = dev.Layout(pro.shape, axis)
+        C = layout.nch
+        fir, iir = dev.FirStream(taps, C), dev.SosStream(sos, C)
+        try:
+            if zi is not None:
+                iir.set_state(_zi_to_2d(zi, sos.shape[0], layout))
+            device = first.device
+
+            def fresh(m):
+                return torch.empty((C, m + lcut), dtype=torch.float64, device=device)
+
+            # ---- input chunk 0 on the separate kernels: the left cut
+            prev = fresh(cs)
+            iir.forward(fir.push(layout.to2d(first)[0], lcut), out=prev[:, lcut:cs])
+            k = 1
+            for arr in chunks:
+                if arr.shape[axis] == 0:
+                    continue
+                x2d = layout.to2d(arr)[0]
+                m = x2d.shape[1]
+                if k >= nchunks or m != (cs if k < nchunks - 1 else last):
+                    raise RuntimeError("sosfilt after oaconvolve: an inner chunk of the source "
+                                       f"is not chunksize = {cs} long")
+                cur = fresh(m)
+                dev.chain_forward(fir, iir, x2d, out=cur[:, :m])
+                if lcut:
+                    prev[:, cs:cs + lcut].copy_(cur[:, :lcut])
+                yield layout.from2d(prev[:, lcut:cs + lcut], False)
+                prev, k = cur, k + 1
+            if k != nchunks:
+                raise RuntimeError(f"sosfilt after oaconvolve: {k} of {nchunks} chunks")
+            # ---- the overhang of the convolution, behind the last piece
+            if lcut:
+                iir.forward(fir.flush(device, skip=0, drop=rcut), out=prev[:, last:last + lcut])
+            yield layout.from2d(prev[:, lcut:last + lcut], False)
+        finally:
+            fir.close()
+            iir.close()
+
+    return run()
 
 
 def _sosfiltfilt_after_fir(pro, source, taps, sos):

@@ -304,6 +304,22 @@ int osz_chain_forward(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx
     return chain_forward_impl(fir, sos, x, ldx, n, f, ldf, stream, [] { return OSZ_OK; });
 }
 
+int osz_chain_forward_route(osz_fir_t fir, osz_sos_t sos, void *stream) {
+    if (!fir || !sos || fir->nch != sos->nch) {
+        osz::fail(OSZ_ERR_INVALID, "osz_chain_forward_route: null handle or channel counts differ");
+        return -1;
+    }
+    int dev = -1;
+    if (osz::current_device(&dev)) return -1;
+    if (dev != fir->device || dev != sos->device) {
+        osz::fail(OSZ_ERR_STATE, "osz_chain_forward_route: handles belong to another device");
+        return -1;
+    }
+    int route = 0;
+    if (spec_route(fir, sos, as_stream(stream), &route)) return -1;
+    return route;
+}
+
 // Do two (nch, n) views, rows ld apart, share an element?  Views of one parent
 // buffer (equal pitch) are compared column-wise -- the chunks of a ring buffer
 // interleave in memory without touching; anything else by its address range.

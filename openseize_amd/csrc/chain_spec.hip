@@ -657,12 +657,9 @@ static int specn_forward(ChainSpec *s, const double *x, int64_t ldx, int64_t n, 
 }
 
 
-// FIR + forward cascade of one chunk by the spectral kernel, if it applies to this
-// pair of handles and this chunk (*taken says); `between` runs before the launch
-// (osz_chain_step starts the backward pass on its side stream there)
-int spec_try_forward(osz_fir_s *fir, osz_sos_s *sos, const double *x, int64_t ldx, int64_t n, double *f,
-                     int64_t ldf, hipStream_t st, const std::function<int()> &between, bool *taken) {
-    *taken = false;
+// the link of this pair of handles (tables built on first use); a handle paired with
+// another partner before gets its own state back first
+static int spec_link(osz_fir_s *fir, osz_sos_s *sos, hipStream_t st, ChainSpec **out) {
     ChainSpec *s = sos->spec;
     if (s && s->fir != fir) {
         // the cascade is paired with another FIR from here on
@@ -686,6 +683,30 @@ int spec_try_forward(osz_fir_s *fir, osz_sos_s *sos, const double *x, int64_t ld
             spec_unlink(s);
             return rc;
         }
+    }
+    *out = s;
+    return OSZ_OK;
+}
+
+// which kernel osz_chain_forward runs whole blocks of this pair on (osz_chain_forward_route)
+int spec_route(osz_fir_s *fir, osz_sos_s *sos, hipStream_t st, int *route) {
+    ChainSpec *s = nullptr;
+    int rc = spec_link(fir, sos, st, &s);
+    if (rc) return rc;
+    *route = !s->eligible ? 0 : s->nega ? 2 : 1;
+    return OSZ_OK;
+}
+
+// FIR + forward cascade of one chunk by the spectral kernel, if it applies to this
+// pair of handles and this chunk (*taken says); `between` runs before the launch
+// (osz_chain_step starts the backward pass on its side stream there)
+int spec_try_forward(osz_fir_s *fir, osz_sos_s *sos, const double *x, int64_t ldx, int64_t n, double *f,
+                     int64_t ldf, hipStream_t st, const std::function<int()> &between, bool *taken) {
+    *taken = false;
+    ChainSpec *s = nullptr;
+    {
+        int rc = spec_link(fir, sos, st, &s);
+        if (rc) return rc;
     }
     if (!s->eligible) return OSZ_OK;
     if (s->nega) return specn_forward(s, x, ldx, n, f, ldf, st, between, taken);

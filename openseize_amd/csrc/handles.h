@@ -98,6 +98,7 @@ int sosfiltfilt_chunk_on(osz_sos_s *h, const double *fa, int64_t ldfa, int64_t n
 // runs it, their own states (overlap tail, section states) are not kept up to date:
 // every entry point that reads them calls spec_settle first, every one that changes
 // them spec_touch.
+int spec_route(osz_fir_s *fir, osz_sos_s *sos, hipStream_t st, int *route);
 int spec_try_forward(osz_fir_s *fir, osz_sos_s *sos, const double *x, int64_t ldx, int64_t n, double *f,
                      int64_t ldf, hipStream_t st, const std::function<int()> &between, bool *taken);
 int spec_settle(ChainSpec *s, hipStream_t st);

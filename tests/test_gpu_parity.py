@@ -1182,6 +1182,81 @@ def test_fir_then_sosfiltfilt_through_the_api_fused(osz):
 
 
 @pytest.mark.gpu
+def test_fir_then_sosfilt_through_the_api_fused(osz):
+    """FIR.__call__ feeding IIR.__call__(phase-shifted: sosfilt) on device-resident data takes
+    osz_chain_forward per chunk (numerical._sosfilt_after_fir) -- array for array the same as
+    the two generators apart (OSZ_CHAIN_API=0), and the oracle's oaconvolve('same') -> sosfilt
+    (core/numerical.py:158-298 feeding :301-335); odd and even left cuts, ragged last chunk, a
+    stream ending exactly on a chunk, a start state zi, the scan-in-time route (2049 taps),
+    sample axis first; what the fused path does not take (a last chunk shorter than the cut,
+    host-fed data) still comes out right."""
+    import os
+    from functools import partial
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    from openseize_amd.core import numerical as nm
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+
+    def chain(x, taps, cs, axis, zi=None):
+        src = producer(x, cs, axis)
+        fir = producer(partial(nm.oaconvolve, src, taps, axis, "same"), cs, axis, shape=src.shape)
+        return [c for c in nm.sosfilt(fir, sos, axis, zi=zi)]
+
+    def counted(x, taps, cs, axis, zi=None):
+        calls, plain = [], dev.chain_forward
+        dev.chain_forward = lambda *a, **k: (calls.append(1), plain(*a, **k))[1]
+        try:
+            return chain(x, taps, cs, axis, zi), len(calls)
+        finally:
+            dev.chain_forward = plain
+
+    def apart(x, taps, cs, axis, zi=None):
+        os.environ["OSZ_CHAIN_API"] = "0"
+        try:
+            return chain(x, taps, cs, axis, zi)
+        finally:
+            del os.environ["OSZ_CHAIN_API"]
+
+    for taps_n, C, cs, total, fused in ((1024, 256, 6144 * 24, 6144 * 24 * 3 + 6144 * 9 + 321, True),
+                                        (301, 5, 100000, 100000 * 5, True), (2049, 3, 131072, 131072 * 3 + 1777, True),
+                                        (64, 4, 70001, 70001 * 4 + 45, True), (1024, 3, 70000, 70000 * 3 + 100, False)):
+        taps = sps.firwin(taps_n, 0.2)
+        x = dev.synth_normal(C, total, seed=47)
+        zi = None if taps_n != 301 else np.random.default_rng(3).standard_normal((sos.shape[0], C, 2))
+        got, ncalls = counted(x, taps, cs, -1, zi)
+        nchunks = -(-total // cs)
+        assert ncalls == (nchunks - 1 if fused else 0), (taps_n, ncalls)
+        ref = apart(x, taps, cs, -1, zi)
+        assert [g.shape for g in got] == [r.shape for r in ref], (taps_n, C)
+        for k, (a, b) in enumerate(zip(got, ref)):
+            err = float((a - b).abs().max()) / float(b.abs().max())
+            assert err < 1e-11, (taps_n, C, k, err)
+        assert len({g.untyped_storage().data_ptr() for g in got}) == len(got)    # arrays of their own
+        pick = [0, C // 2, C - 1]
+        xh = x[pick].cpu().numpy()
+        want, _ = orc.sosfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, cs,
+                              zi=None if zi is None else zi[:, pick])
+        gh = torch.cat(got, -1)[pick].cpu().numpy()
+        assert rel_err(gh, want) < RTOL, (taps_n, C)
+    # host-fed: the two generators apart, as before
+    taps = sps.firwin(513, 0.2)
+    xh = np.random.default_rng(48).standard_normal((4, 90000 * 3 + 1234))
+    got, ncalls = counted(xh, taps, 90000, -1)
+    assert ncalls == 0 and all(isinstance(g, np.ndarray) for g in got)
+    want, _ = orc.sosfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, 90000)
+    assert rel_err(np.concatenate(got, -1), want) < RTOL
+    # sample axis first: (samples, channels)
+    taps = sps.firwin(301, 0.2)
+    xt = dev.synth_normal(6, 100000 * 4 + 931, seed=49).T.contiguous()
+    got, ncalls = counted(xt, taps, 100000, 0)
+    assert ncalls == 4
+    got, ref = torch.cat(got, 0), torch.cat(apart(xt, taps, 100000, 0), 0)
+    assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-11 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
 def test_polyphase_large_decimation_stays_on_the_tiled_kernel(osz):
     """Decimation by 13, 25 (the reference's tutorial: downsample(M=25), docs/tutorials/
     resampling.ipynb:650) and 40 with the default Kaiser design (293 / 561 / 895 taps): the

@@ -397,3 +397,31 @@ def test_routes_and_parity_of_realistic_cascades(dev, which):
     assert len(steps) == (5 if zp else 0), (name, len(steps))
     want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(x.cpu().numpy(), taps, "same"), -1), sos, cs)
     assert np.max(np.abs(got - want)) < RTOL * np.max(np.abs(want)), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", range(6))
+def test_forward_chain_routes_and_parity(dev, which):
+    """The same six cascades behind a 1024-tap FIR through osz_chain_forward (FIR -> sosfilt, one
+    launch per chunk), held against the oracle: np.convolve's meaning of the overlap add
+    (core/numerical.py:158-298) into the DF2T cascade (scipy's sosfilt, :338-386), three chunks
+    with the carried states between them and a ragged last one.  Which kernel ran is asserted
+    (osz_chain_forward_route): the one-block kernel without its left tail for four of them, the
+    scan in time for nine sections and for the band 0.0002 of Nyquist wide."""
+    from oracle import oracle as orc
+    name, sos, spectral = _coverage_filters()[which]
+    sos = np.atleast_2d(np.asarray(sos, dtype=np.float64))
+    C, lens = 3, (200000, 200000, 77777)
+    taps = sps.firwin(1024, 0.2)
+    x = dev.synth_normal(C, sum(lens), seed=500 + which)
+    fir, iir = dev.FirStream(taps, C), dev.SosStream(sos, C)
+    assert dev.chain_forward_route(fir, iir) == (2 if spectral else 0), name
+    got, n0 = [], 0
+    for n in lens:
+        got.append(dev.chain_forward(fir, iir, x[:, n0:n0 + n].contiguous()).cpu().numpy())
+        n0 += n
+    fir.close(); iir.close()
+    got = np.concatenate(got, -1)
+    u = orc.convolve_direct(x.cpu().numpy(), taps, "full")[:, :sum(lens)]
+    want, _ = orc.sosfilt(u, sos, sum(lens))
+    assert np.max(np.abs(got - want)) < RTOL * np.max(np.abs(want)), name
