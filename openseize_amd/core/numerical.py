@@ -292,10 +292,10 @@ def _fir_feeding(pro, axis):
 
 
 def _sosfilt_after_fir(pro, source, taps, sos, zi):
-    """``sosfilt(oaconvolve(source, taps, 'same'))`` for a device-resident source, chunk for
-    chunk what the two generators yield one after the other (reference core/numerical.py:158-298
-    feeding :301-335), on ``osz_chain_forward``: FIR and forward cascade of an input chunk in
-    one launch, the FIR's output never in HBM (16 instead of 32 B per channel-sample).
+    """``sosfilt(oaconvolve(source, taps, 'same'))``, chunk for chunk what the two generators
+    yield one after the other (reference core/numerical.py:158-298 feeding :301-335), on
+    ``osz_chain_forward``: FIR and forward cascade of an input chunk in one launch, the FIR's
+    output never in HBM (16 instead of 32 B per channel-sample).
 
     'same' drops the first ``lcut = (taps-1)//2`` outputs, so the piece input chunk k produces
     is output samples [k cs - lcut, (k+1) cs - lcut).  Piece k is written at the front of a
@@ -303,8 +303,11 @@ def _sosfilt_after_fir(pro, source, taps, sos, zi):
     behind piece k-1 (C x lcut samples: nothing beside a chunk), whose buffer then holds
     output chunk k-1 as one view -- memory of its own, as every array the separate generators
     yield.  Input chunk 0 (the left cut) and the overhang of the convolution go through the
-    separate kernels.  Returns None (the caller runs the two generators apart) for host-fed
-    sources, short streams, short chunks and a last chunk shorter than the cut."""
+    separate kernels.  A host-fed source goes up and its results come down through
+    ``dev.HostPipe``: ONE trip over PCIe each way for the chain, where the two generators
+    apart make two and re-chunk on the host in between.  Returns None (the caller runs the
+    two generators apart) for CPU tensors, short streams, short chunks and a last chunk
+    shorter than the cut."""
     import torch
     axis = pro.axis
     cs, total = int(pro.chunksize), int(pro.shape[axis])
@@ -316,7 +319,7 @@ def _sosfilt_after_fir(pro, source, taps, sos, zi):
         return None
     chunks = dev.pull_resident(source, source)         # a source of this library hands CUDA tensors
     first = next(chunks, None)
-    if first is None or first.shape[axis] != cs or not (dev.is_tensor(first) and first.is_cuda):
+    if first is None or first.shape[axis] != cs or (dev.is_tensor(first) and not first.is_cuda):
         chunks.close()                                 # (a reader behind the source is released)
         return None
 
@@ -327,35 +330,49 @@ def _sosfilt_after_fir(pro, source, taps, sos, zi):
         try:
             if zi is not None:
                 iir.set_state(_zi_to_2d(zi, sos.shape[0], layout))
-            device = first.device
+            resident = dev.is_tensor(first)
+            device = first.device if resident else "cuda"
+            pipe = None if resident else dev.HostPipe(layout)
+            at = {"k": 0, "open": None}                # chunks taken; the buffer of the last piece
 
-            def fresh(m):
-                return torch.empty((C, m + lcut), dtype=torch.float64, device=device)
-
-            # ---- input chunk 0 on the separate kernels: the left cut
-            prev = fresh(cs)
-            iir.forward(fir.push(layout.to2d(first)[0], lcut), out=prev[:, lcut:cs])
-            k = 1
-            for arr in chunks:
-                if arr.shape[axis] == 0:
-                    continue
-                x2d = layout.to2d(arr)[0]
-                m = x2d.shape[1]
+            def op(x2d):
+                """Input chunk k in; output chunk k - 1 (complete now) out."""
+                k, m = at["k"], x2d.shape[1]
                 if k >= nchunks or m != (cs if k < nchunks - 1 else last):
                     raise RuntimeError("sosfilt after oaconvolve: an inner chunk of the source "
                                        f"is not chunksize = {cs} long")
-                cur = fresh(m)
+                at["k"] = k + 1
+                cur = torch.empty((C, m + lcut), dtype=torch.float64, device=device)
+                prev, at["open"] = at["open"], cur
+                if k == 0:                             # the left cut: separate kernels
+                    iir.forward(fir.push(x2d, lcut), out=cur[:, lcut:cs])
+                    return None
                 dev.chain_forward(fir, iir, x2d, out=cur[:, :m])
                 if lcut:
                     prev[:, cs:cs + lcut].copy_(cur[:, :lcut])
-                yield layout.from2d(prev[:, lcut:cs + lcut], False)
-                prev, k = cur, k + 1
-            if k != nchunks:
-                raise RuntimeError(f"sosfilt after oaconvolve: {k} of {nchunks} chunks")
+                return prev[:, lcut:cs + lcut]
+
+            seq = (c for c in _chain_first(first, chunks) if c.shape[axis] > 0)
+            if resident:
+                for arr in seq:
+                    y = op(layout.to2d(arr)[0])
+                    if y is not None:
+                        yield layout.from2d(y, False)
+            else:
+                yield from pipe.run(seq, op)
+            if at["k"] != nchunks:
+                raise RuntimeError(f"sosfilt after oaconvolve: {at['k']} of {nchunks} chunks")
             # ---- the overhang of the convolution, behind the last piece
+            cur = at["open"]
             if lcut:
-                iir.forward(fir.flush(device, skip=0, drop=rcut), out=prev[:, last:last + lcut])
-            yield layout.from2d(prev[:, lcut:last + lcut], False)
+                iir.forward(fir.flush(device, skip=0, drop=rcut), out=cur[:, last:last + lcut])
+            y = cur[:, lcut:last + lcut]
+            if resident or dev.emit_resident():
+                yield layout.from2d(y, False)
+            else:
+                out, done = pipe.download(y)
+                done.synchronize()
+                yield pipe.restore(out)
         finally:
             fir.close()
             iir.close()

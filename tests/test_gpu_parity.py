@@ -1188,8 +1188,8 @@ def test_fir_then_sosfilt_through_the_api_fused(osz):
     the two generators apart (OSZ_CHAIN_API=0), and the oracle's oaconvolve('same') -> sosfilt
     (core/numerical.py:158-298 feeding :301-335); odd and even left cuts, ragged last chunk, a
     stream ending exactly on a chunk, a start state zi, the scan-in-time route (2049 taps),
-    sample axis first; what the fused path does not take (a last chunk shorter than the cut,
-    host-fed data) still comes out right."""
+    sample axis first, host-fed data (ndarrays in and out); what the fused path does not take
+    (a last chunk shorter than the cut) still comes out right."""
     import os
     from functools import partial
     import scipy.signal as sps
@@ -1240,11 +1240,12 @@ def test_fir_then_sosfilt_through_the_api_fused(osz):
                               zi=None if zi is None else zi[:, pick])
         gh = torch.cat(got, -1)[pick].cpu().numpy()
         assert rel_err(gh, want) < RTOL, (taps_n, C)
-    # host-fed: the two generators apart, as before
+    # host-fed: ndarray chunks in, ndarray chunks out, one trip over PCIe each way
     taps = sps.firwin(513, 0.2)
-    xh = np.random.default_rng(48).standard_normal((4, 90000 * 3 + 1234))
+    xh = np.random.default_rng(48).standard_normal((4, 90000 * 5 + 1234))
     got, ncalls = counted(xh, taps, 90000, -1)
-    assert ncalls == 0 and all(isinstance(g, np.ndarray) for g in got)
+    assert ncalls == 5 and all(isinstance(g, np.ndarray) for g in got)
+    assert [g.shape[-1] for g in got] == [90000] * 5 + [1234]
     want, _ = orc.sosfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, 90000)
     assert rel_err(np.concatenate(got, -1), want) < RTOL
     # sample axis first: (samples, channels)
