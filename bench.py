@@ -9,7 +9,7 @@ chunk (256 x 2^20 channel-samples) through the whole chain in steady state, and 
 ONE kernel:
 
     osz_chain_zp_step(chunk k): FIR, forward and backward cascade as one multiplication per
-    bin of the FIR's own transform, plus the cascade's mode bursts (csrc/chain_zpn.hip: one
+    bin of the FIR's own transform, plus the cascade's mode bursts (csrc/chain_zpn_body.h: one
     real block of 27 rows x 256 samples per 4096-point transform at the odd frequencies);
     the stream runs `lag` samples late, the step writes the tail of output chunk k-1 and the
     head of chunk k; osz_chain_zp_seal(chunk k-2) (NaN reach of sosfiltfilt) is in the step.
@@ -18,7 +18,11 @@ ONE kernel:
 `roofline` prices the kernel by what the fused operation must move -- 8 B read + 8 B written
 per channel-sample -- over its measured duration: `frac` is a physical fraction of the HBM
 peak (<= 1); the 48 B per sample the unfused chain would move (FIR 16 +
-sosfiltfilt 32) appear only as `unfused_equivalent_*`.
+sosfiltfilt 32) appear only as `unfused_equivalent_*`.  `value` is W warm-up steps, then K
+timed steps, as the driver's contract says; `steady_state` (not `value`) is the same K steps
+timed once more 40 steps further into the stream: the first ~30 launches after the GPU was idle
+run slower while its clock / power controller settles (benchmarks/ramp_probe.py), which is what
+K = 20 behind W = 5 times.
 
 Inputs are synthesised on the device before the timed region (a ring of
 resident chunks keyed by (seed, channel, sample)); outputs land in a resident
@@ -66,14 +70,15 @@ CHUNK = 1 << 20
 NTAPS = 1024
 NFFT = 4096              # cfg-4: nperseg 4096 (fs 4096, resolution 1.0), 50 % overlap
 RAGGED = 100_000_000 - 95 * CHUNK     # last chunk of the literal 1e8-sample stream
-# algorithmic HBM bytes per channel-sample of one launch
-# (chain_fwd = FIR + forward sosfilt in one kernel: 16 + 16 of them; chain_step = that kernel
-# and the backward pass of an earlier chunk side by side on two streams, one osz_chain_step:
-# the whole 48 B of the chain.  What these launches really move is roofline.traffic.)
-# chain_zp: ONE kernel for the whole chain -- it must read a sample and write a sample, 16 B;
-# the 48 B the unfused chain would move are reported apart (unfused_equivalent_*).
+# algorithmic HBM bytes per channel-sample of one launch: what the operation the launch
+# performs must move, so that roofline.frac is a physical fraction of the peak.
+# chain_fwd = FIR + forward sosfilt in one kernel: a sample in, a sample out, 16 B (the FIR's
+# output never reaches HBM); chain_step = that kernel and the backward pass of an earlier chunk
+# side by side on two streams, one osz_chain_step: 16 + 16; chain_zp: ONE kernel for the whole
+# chain, 16 B.  The 48 B the unfused chain would move are reported apart
+# (unfused_equivalent_*).  What the launches really move is roofline.traffic.
 KERNEL_BYTES = {"fir_oa": 16, "sos_dual": 32, "sos_fwd": 16, "sos_bwd": 16, "sos_fwd_split": 16,
-                "sos_bwd_split": 16, "chain_fwd": 32, "chain_step": 48, "chain_zp": 16, "sos_warmup": 0,
+                "sos_bwd_split": 16, "chain_fwd": 16, "chain_step": 32, "chain_zp": 16, "sos_warmup": 0,
                 "fir_seam": 0, "spec_fused": 8, "poly_block": 9.6}
 CHAIN_BYTES = 48         # FIR 16 + sosfiltfilt 32 (the unfused accounting of the metric)
 METRIC = "Msamples/sec/node (FIR+IIR chain, 256ch f64); HBM GB/s vs roofline at 1/2/4/8 GPU"
@@ -335,8 +340,8 @@ def roofline_of(kernels, samples_per_step):
         out["limiter"] = "vector issue / LDS latency at 2 waves per SIMD, not HBM (profiles/r04_pmc_bench.json)"
     if dom == "chain_step":
         # two kernels side by side under one call: the duration is that of the pair
-        # (HIP events on the caller's stream around osz_chain_step), the bytes are the
-        # chain's 48 per sample of SURVEY 8d; fused, the pair really moves ~33
+        # (HIP events on the caller's stream around osz_chain_step), the bytes what the two
+        # fused halves must move: 16 + 16 per sample (counters: ~32.3)
         out["kernel"] = "chain_step (chain_fwd || sos_bwd_split, two streams, one osz_chain_step)"
         out["members"] = {nm: kernels[nm]["avg_ms"] for nm in ("chain_fwd", "sos_bwd_split", "sos_warmup")
                           if nm in kernels}

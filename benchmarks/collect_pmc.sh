@@ -30,7 +30,7 @@ SQ2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_W
 SQ3="SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"
 
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
-    B="python3 bench.py --steps 5 --warmup 3 --no-cpu"
+    B="python3 bench.py --steps 5 --warmup 3 --no-cpu --no-steady"
     run_pass bench_sq1 "$SQ1" $B
     run_pass bench_sq2 "$SQ2" $B
     run_pass bench_sq3 "$SQ3" $B
