@@ -280,6 +280,11 @@ def _fir_feeding(pro, axis):
     fir_axis, mode = bound.arguments["axis"], bound.arguments["mode"]
     if not isinstance(source, Producer) or mode != "same":
         return None
+    from openseize_amd.core.producer import MaskedProducer
+    if isinstance(source, MaskedProducer):
+        # its shape may name more samples than it yields (core/producer.py:399-408): the fused
+        # flows plan their chunks from the shape
+        return None
     ndim = len(pro.shape)
     if normalize_axis(fir_axis, ndim) != normalize_axis(axis, ndim):
         return None
