@@ -25,7 +25,7 @@
 namespace osz {
 namespace mix {
 
-struct C2 {
+struct alignas(16) C2 {
     double re, im;
 };
 
@@ -177,36 +177,162 @@ __device__ __forceinline__ void dft<10>(C2 *v) {
 
 // One in-place DIF pass of radix R over the M points: blocks of B = R S points,
 // butterfly (blk, inner) on the slots blk B + inner + q S, output q times W_B^(inner q).
-template <int R, int NT>
-__device__ __forceinline__ void pass(C2 *z, int t, int M, int S, int tstep, const double *tw,
-                                     int blkfast, int div, unsigned inv) {
-    const int nb = M / R;
-    const int B = R * S;
-#pragma unroll 1
-    for (int b = t; b < nb; b += NT) {
-        // b = hi * div + lo by multiplication with ceil(2^32 / div) (exact: b, div < 2^16)
+// A thread has at most ceil(10 / R) <= kMaxBf butterflies (M <= 10 NT, specmix_threads).  Their
+// twiddles W_B^inner -- 16-byte loads from the table in L2 -- are requested by the kernel BEFORE
+// the barrier in front of the pass (pass_twiddles: one routine for all radices, or the arrays of
+// every radix's branch stay live across the barrier the compiler merges them behind), so that the
+// table's latency runs beside the wait for the other waves instead of behind every butterfly's LDS
+// reads (a rolled loop was a chain of L2 round trips, one per butterfly).
+constexpr int kMaxBf = 5;     // butterflies of a thread per pass
+constexpr int kPreBf = 3;     // of them with their twiddle requested ahead (radix >= 4: all)
+
+struct Split {      // butterfly b = hi * div + lo by multiplication with ceil(2^32 / div) (exact: b, div < 2^16)
+    int blkfast, div;
+    unsigned inv;
+    __device__ __forceinline__ void operator()(int b, int &blk, int &inner) const {
         const int hi = div == 1 ? b : (int)__umulhi((unsigned)b, inv);
         const int lo = b - hi * div;
-        const int blk = blkfast ? lo : hi;
-        const int inner = blkfast ? hi : lo;
-        C2 *p = z + blk * B + inner;
-        C2 v[R];
+        blk = blkfast ? lo : hi;
+        inner = blkfast ? hi : lo;
+    }
+};
+
+template <int NT>
+__device__ __forceinline__ void pass_twiddles(C2 *w1, int t, int nb, int tstep, const double *tw, Split sp) {
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = p[q * S];
-        dft<R>(v);
-        if (S > 1) {
-            const int j = inner * tstep;
-            const C2 w1 = C2{tw[2 * j], tw[2 * j + 1]};
-            C2 wq = w1;
-            v[1] = cmul(v[1], wq);
+    for (int i = 0; i < kPreBf; ++i) {
+        const int b = t + i * NT;
+        int blk, inner;
+        sp(b < nb ? b : 0, blk, inner);
+        w1[i] = *reinterpret_cast<const C2 *>(tw + 2 * (inner * tstep));   // (S = 1: inner = 0, unused)
+    }
+}
+
+template <int R, int NT>
+__device__ __forceinline__ void pass(C2 *z, int t, int M, int S, const C2 *w1, Split sp, int tstep, const double *tw) {
+    constexpr int NI = (10 + R - 1) / R;
+    static_assert(NI <= kMaxBf, "butterflies per thread");
+    const int nb = M / R;
+    const int B = R * S;
 #pragma unroll
-            for (int q = 2; q < R; ++q) {
-                wq = cmul(wq, w1);
-                v[q] = cmul(v[q], wq);
+    for (int i = 0; i < NI; ++i) {
+        asm volatile("" ::: "memory");   // one butterfly's slots in registers at a time
+        if (t + i * NT < nb) {
+            int blk, inner;
+            sp(t + i * NT, blk, inner);
+            C2 *p = z + blk * B + inner;
+            C2 v[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[q] = p[q * S];
+            dft<R>(v);
+            if (S > 1) {
+                const C2 w = i < kPreBf ? w1[i] : *reinterpret_cast<const C2 *>(tw + 2 * (inner * tstep));
+                C2 wq = w;
+                v[1] = cmul(v[1], wq);
+#pragma unroll
+                for (int q = 2; q < R; ++q) {
+                    wq = cmul(wq, w);
+                    v[q] = cmul(v[q], wq);
+                }
             }
-        }
 #pragma unroll
-        for (int q = 0; q < R; ++q) p[q * S] = v[q];
+            for (int q = 0; q < R; ++q) p[q * S] = v[q];
+        }
+    }
+}
+
+// The head of a segment: samples -> trend -> window -> FIRST pass (radix R0, S0 = M / R0, one
+// block), all in registers: a thread loads the R0 points b + q S0 of its butterflies b = t + i NT
+// (consecutive lanes still read consecutive samples), the block sums of the trend go through the
+// one barrier, and what reaches LDS is the output of the first pass -- ONE store per point where
+// the raw samples, the detrended ones and the pass each made one (a 16-byte LDS store moves at
+// ~80 B per clock and CU, a third of a load: the stores, not the reads or the table, are what this
+// kernel's time is made of, profiles/r04_specmix_phases.txt).  Two halves around the kernel's
+// barrier, the points in ONE array for all radices (with the barrier inside a radix's branch the
+// compiler merges the branches behind it and keeps every radix's array alive).
+constexpr int kPreBf0 = 2;     // first-pass butterflies with their twiddle requested ahead (radix >= 5: all)
+
+// a row of nwin doubles as a raw buffer whose range check returns 0.0 beyond it: the zero padding
+// of a segment (nwin < nfft) and the lanes without a butterfly cost no compare and no select, and an
+// address is ONE register (a 64-bit address per load is what made this phase spill)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double *base, int nwin) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, nwin * 8, 0x00020000);
+}
+constexpr unsigned kOffRange = 0x7ffffff0u;   // a byte offset beyond every row
+
+// first half: the block sums of the trend over the thread's points (the samples themselves are not
+// kept: second half), and the twiddles of the pass requested
+template <int R0, bool LINEAR, int NT>
+__device__ __forceinline__ void head_sums(C2 *w1, double &sum, double &lin, const double *xs,
+                                          const Args &a, int t) {
+    constexpr int NI = (10 + R0 - 1) / R0;
+    static_assert(NI <= kMaxBf, "butterflies of a thread");
+    const int S0 = a.M / R0;
+    const double mid = 0.5 * (a.nwin - 1);
+    const __amdgpu_buffer_rsrc_t rx = row_rsrc(xs, a.nwin);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int b = t + i * NT;
+        const bool on = b < S0;
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            // samples 2 j and 2 j + 1 of point j = b + q S0
+            const int j = b + q * S0;
+            const unsigned at = on ? 16u * (unsigned)j : kOffRange;
+            const double x0 = buf_load(rx, at, 0), x1 = buf_load(rx, at + 8, 0);
+            sum += x0 + x1;
+            if (LINEAR) lin += (2 * j - mid) * x0 + (2 * j + 1 - mid) * x1;
+        }
+        // W_M^b of the pass, back by the time the barrier is behind us (tstep = N / M = 2)
+        if (i < kPreBf0) w1[i] = *reinterpret_cast<const C2 *>(a.tw + 4 * (on ? b : 0));
+    }
+}
+
+// second half, behind the barrier: the samples once more (from L2: they came by a microsecond ago;
+// kept in registers across the barrier they push the PSD sums of the mean mode out into scratch),
+// trend off, window on, the butterfly, one store per point
+template <int R0, bool LINEAR, int NT>
+__device__ __forceinline__ void head_finish(C2 *z, const C2 *w1, double mean, double slope, const double *xs,
+                                            const Args &a, int t) {
+    constexpr int NI = (10 + R0 - 1) / R0;
+    const int S0 = a.M / R0;
+    const double mid = 0.5 * (a.nwin - 1);
+    const __amdgpu_buffer_rsrc_t rx = row_rsrc(xs, a.nwin);
+    const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.window, a.nwin);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int b = t + i * NT;
+        asm volatile("" ::: "memory");   // one butterfly's points in registers at a time
+        if (b < S0) {
+            C2 u[R0];
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                const int j = b + q * S0;
+                const unsigned at = 16u * (unsigned)j;
+                const double x0 = buf_load(rx, at, 0), x1 = buf_load(rx, at + 8, 0);
+                const double g0 = buf_load(rw, at, 0), g1 = buf_load(rw, at + 8, 0);   // 0 in the padding
+                if (LINEAR) {
+                    u[q].re = (x0 - mean - slope * (2 * j - mid)) * g0;
+                    u[q].im = (x1 - mean - slope * (2 * j + 1 - mid)) * g1;
+                } else {
+                    u[q].re = (x0 - mean) * g0;
+                    u[q].im = (x1 - mean) * g1;
+                }
+            }
+            dft<R0>(u);
+            if (S0 > 1) {
+                const C2 w = i < kPreBf0 ? w1[i] : *reinterpret_cast<const C2 *>(a.tw + 4 * b);
+                C2 wq = w;
+                u[1] = cmul(u[1], wq);
+#pragma unroll
+                for (int q = 2; q < R0; ++q) {
+                    wq = cmul(wq, w);
+                    u[q] = cmul(u[q], wq);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < R0; ++q) z[b + q * S0] = u[q];
+        }
     }
 }
 
@@ -223,7 +349,6 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
     const double *xr = a.x + (int64_t)c * a.ldx;
     const int64_t s0 = ((int64_t)run * a.nseg) / a.nruns;
     const int64_t s1 = ((int64_t)(run + 1) * a.nseg) / a.nruns;
-    const double mid = 0.5 * (a.nwin - 1);
     const double s2 = a.scale * a.scale;
     double acc[kAcc];
 #pragma unroll
@@ -231,105 +356,66 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
 
     for (int64_t s = s0; s < s1; ++s) {
         const double *xs = xr + s * (int64_t)a.stride;
-        // ---- samples into LDS (raw), block sums for the trend.  The trip count
-        // is at most kAcc (the launch picks NT so): unrolled in batches whose
-        // loads are in flight together -- a rolled loop is a chain of HBM latencies.
-        double sum = 0.0, lin = 0.0;
-        __syncthreads();   // the bin reads of the previous segment are done
-        // opaque thread index, again before every phase: hoisted out of the segment
-        // loop, the addresses / masks / ramp values of all kAcc trips would spill
+        // ---- samples, trend, window and the first pass: one LDS store per point (head_sums / head_finish)
+        {
+            const int r0 = a.radix[0];
+            C2 w0[kPreBf0];
+            double sum = 0.0, lin = 0.0;
+            // opaque thread index, again before every phase: hoisted out of the segment loop, the
+            // addresses / masks / ramp values of all a thread's points would spill
+            int tt = t;
+            asm volatile("" : "+v"(tt));
+            if (r0 == 10) head_sums<10, LINEAR, NT>(w0, sum, lin, xs, a, tt);
+            else if (r0 == 4) head_sums<4, LINEAR, NT>(w0, sum, lin, xs, a, tt);
+            else if (r0 == 5) head_sums<5, LINEAR, NT>(w0, sum, lin, xs, a, tt);
+            else if (r0 == 2) head_sums<2, LINEAR, NT>(w0, sum, lin, xs, a, tt);
+            else if (r0 == 3) head_sums<3, LINEAR, NT>(w0, sum, lin, xs, a, tt);
+            else head_sums<7, LINEAR, NT>(w0, sum, lin, xs, a, tt);
+            sum = wave_sum63(sum);
+            if (LINEAR) lin = wave_sum63(lin);
+            if ((t & 63) == 63) {
+                red[t >> 6][0] = sum;
+                red[t >> 6][1] = lin;
+            }
+            __syncthreads();   // (also: the bin reads of the previous segment are done)
+            double tot = 0.0, tlin = 0.0;
+#pragma unroll
+            for (int q = 0; q < NWV; ++q) {
+                tot += red[q][0];
+                if (LINEAR) tlin += red[q][1];
+            }
+            const double mean = tot / a.nwin;
+            double slope = 0.0;
+            if (LINEAR) {
+                const double nn = (double)a.nwin;
+                const double sxx = nn * (nn * nn - 1.0) / 12.0;
+                slope = sxx > 0.0 ? tlin / sxx : 0.0;
+            }
+            asm volatile("" : "+v"(tt));
+            if (r0 == 10) head_finish<10, LINEAR, NT>(z, w0, mean, slope, xs, a, tt);
+            else if (r0 == 4) head_finish<4, LINEAR, NT>(z, w0, mean, slope, xs, a, tt);
+            else if (r0 == 5) head_finish<5, LINEAR, NT>(z, w0, mean, slope, xs, a, tt);
+            else if (r0 == 2) head_finish<2, LINEAR, NT>(z, w0, mean, slope, xs, a, tt);
+            else if (r0 == 3) head_finish<3, LINEAR, NT>(z, w0, mean, slope, xs, a, tt);
+            else head_finish<7, LINEAR, NT>(z, w0, mean, slope, xs, a, tt);
+        }
         int tt = t;
         asm volatile("" : "+v"(tt));
-#pragma unroll
-        for (int h = 0; h < kAcc; h += kBatch) {
-            if (NT * h >= M) break;   // uniform
-            double v0[kBatch], v1[kBatch];
-            asm volatile("" : "+v"(tt));
-#pragma unroll
-            for (int m = 0; m < kBatch; ++m) {
-                const unsigned j = tt + NT * (h + m);
-                const unsigned i0 = 2 * j, i1 = 2 * j + 1;
-                // clamped addresses, zeros by select: no branch around the loads
-                const double a0 = xs[i0 < (unsigned)a.nwin ? i0 : 0u], a1 = xs[i1 < (unsigned)a.nwin ? i1 : 0u];
-                v0[m] = i0 < (unsigned)a.nwin ? a0 : 0.0;
-                v1[m] = i1 < (unsigned)a.nwin ? a1 : 0.0;
-            }
-#pragma unroll
-            for (int m = 0; m < kBatch; ++m) {
-                const int j = tt + NT * (h + m);
-                const int i0 = 2 * j, i1 = 2 * j + 1;
-                if (j < M) {
-                    sum += v0[m] + v1[m];
-                    if (LINEAR) lin += (i0 - mid) * v0[m] + (i1 - mid) * v1[m];
-                    z[j] = C2{v0[m], v1[m]};
-                }
-            }
-        }
-        sum = wave_sum63(sum);
-        if (LINEAR) lin = wave_sum63(lin);
-        if ((t & 63) == 63) {
-            red[t >> 6][0] = sum;
-            red[t >> 6][1] = lin;
-        }
-        __syncthreads();
-        double tot = 0.0, tlin = 0.0;
-#pragma unroll
-        for (int q = 0; q < NWV; ++q) {
-            tot += red[q][0];
-            if (LINEAR) tlin += red[q][1];
-        }
-        const double mean = tot / a.nwin;
-        double slope = 0.0;
-        if (LINEAR) {
-            const double nn = (double)a.nwin;
-            const double sxx = nn * (nn * nn - 1.0) / 12.0;
-            slope = sxx > 0.0 ? tlin / sxx : 0.0;
-        }
-        // ---- detrend and window in place (a thread rewrites the slots it filled)
-#pragma unroll
-        for (int h = 0; h < kAcc; h += kBatch) {
-            if (NT * h >= M) break;   // uniform
-            double w0[kBatch], w1[kBatch];
-            asm volatile("" : "+v"(tt));
-#pragma unroll
-            for (int m = 0; m < kBatch; ++m) {
-                const unsigned j = tt + NT * (h + m);
-                const unsigned i0 = 2 * j, i1 = 2 * j + 1;
-                const double a0 = a.window[i0 < (unsigned)a.nwin ? i0 : 0u];
-                const double a1 = a.window[i1 < (unsigned)a.nwin ? i1 : 0u];
-                w0[m] = i0 < (unsigned)a.nwin ? a0 : 0.0;
-                w1[m] = i1 < (unsigned)a.nwin ? a1 : 0.0;
-            }
-#pragma unroll
-            for (int m = 0; m < kBatch; ++m) {
-                const int j = tt + NT * (h + m);
-                const int i0 = 2 * j, i1 = 2 * j + 1;
-                if (j < M) {
-                    C2 v = z[j];
-                    if (LINEAR) {
-                        v.re = (v.re - mean - slope * (i0 - mid)) * w0[m];
-                        v.im = (v.im - mean - slope * (i1 - mid)) * w1[m];
-                    } else {
-                        v.re = (v.re - mean) * w0[m];
-                        v.im = (v.im - mean) * w1[m];
-                    }
-                    z[j] = v;
-                }
-            }
-        }
-        // ---- M-point transform, in place
-        int B = M;
-        for (int p = 0; p < a.npass; ++p) {
-            __syncthreads();
+        // ---- the other passes of the M-point transform, in place
+        int B = M / a.radix[0];
+        for (int p = 1; p < a.npass; ++p) {
             const int r = a.radix[p];
             const int S = B / r;
-            const int tstep = N / B;
-            if (r == 10) pass<10, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
-            else if (r == 4) pass<4, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
-            else if (r == 5) pass<5, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
-            else if (r == 2) pass<2, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
-            else if (r == 3) pass<3, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
-            else pass<7, NT>(z, t, M, S, tstep, a.tw, a.blkfast[p], a.div[p], a.inv[p]);
+            const Split sp{a.blkfast[p], a.div[p], a.inv[p]};
+            C2 w1[kPreBf];
+            pass_twiddles<NT>(w1, t, M / r, N / B, a.tw, sp);
+            __syncthreads();
+            if (r == 10) pass<10, NT>(z, t, M, S, w1, sp, N / B, a.tw);
+            else if (r == 4) pass<4, NT>(z, t, M, S, w1, sp, N / B, a.tw);
+            else if (r == 5) pass<5, NT>(z, t, M, S, w1, sp, N / B, a.tw);
+            else if (r == 2) pass<2, NT>(z, t, M, S, w1, sp, N / B, a.tw);
+            else if (r == 3) pass<3, NT>(z, t, M, S, w1, sp, N / B, a.tw);
+            else pass<7, NT>(z, t, M, S, w1, sp, N / B, a.tw);
             B = S;
         }
         __syncthreads();
