@@ -13,6 +13,9 @@ per workgroup, mean duration of the profiled launches, and derived ratios
   valu      = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
   wait_any  = SQ_WAIT_ANY / SQ_WAVE_CYCLES          waves parked (s_waitcnt, barrier)
   lds_conf  = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+  lds_array = SQ_LDS_IDX_ACTIVE / 256 CUs / (SQ_BUSY_CYCLES / 32 shader engines): the share of the
+              launch a CU's LDS array is busy (specmix before its 16-byte accesses: 0.78; this, not
+              SQ_ACTIVE_INST_LDS / SQ_WAVE_CYCLES, says whether a kernel is LDS-bound)
   hbm_bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024    (gfx950 FETCH_SIZE half count)
 """
 import csv
@@ -74,6 +77,8 @@ def main():
                         rec[nm] = rec[c] / wc
             if rec.get("SQ_LDS_IDX_ACTIVE"):
                 rec["lds_conf"] = rec.get("SQ_LDS_BANK_CONFLICT", 0.0) / rec["SQ_LDS_IDX_ACTIVE"]
+                if rec.get("SQ_BUSY_CYCLES"):
+                    rec["lds_array"] = rec["SQ_LDS_IDX_ACTIVE"] / 256.0 / (rec["SQ_BUSY_CYCLES"] / 32.0)
             if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
                 rec["hbm_bytes"] = (2 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024
             table[k] = {key: val for key, val in rec.items() if not key.startswith("launches_")}
@@ -87,7 +92,7 @@ def main():
             print(f"{k[:60]:60s} {v['profiled_ms']:8.3f} ms vgpr {v['vgpr']:3d} lds {v['lds_bytes']:6d} "
                   f"busy {v.get('busy', 0):.2f} valu {v.get('valu', 0):.2f} wait {v.get('wait_any', 0):.2f} "
                   f"wait_inst {v.get('wait_inst', 0):.2f} lds {v.get('lds_active', 0):.2f} vmem {v.get('vmem_active', 0):.2f} "
-                  f"conf {v.get('lds_conf', 0):.3f} hbm {v.get('hbm_bytes', 0) / 1e9:.2f} GB")
+                  f"conf {v.get('lds_conf', 0):.3f} lds_array {v.get('lds_array', 0):.2f} hbm {v.get('hbm_bytes', 0) / 1e9:.2f} GB")
 
 
 if __name__ == "__main__":

@@ -4,11 +4,13 @@
 // resolution 0.5 -> nfft = 2 fs): 500, 1000, 2000, 5000, 10000 ... are products
 // of 2, 3 and 5 far more often than powers of two.  One workgroup walks a run of
 // segments of one channel; a segment of nfft real samples is packed into
-// M = nfft / 2 complex points z[j] = y[2j] + i y[2j+1] in LDS (16 B a point,
-// 80 KB at nfft = 10000), transformed IN PLACE by decimation-in-frequency passes
+// M = nfft / 2 complex points z[j] = y[2j] + i y[2j+1] (16 B a point, 80 KB of LDS
+// at nfft = 10000), transformed by decimation-in-frequency passes
 // of radix 10, 4, 2, 3, 5, 7 (in that order: the even radices run while the butterfly
 // stride is long, the last passes -- stride 1 ... 25 -- are the odd ones, whose
-// 48- and 80-byte lane strides spread over all banks), one barrier per pass, and
+// 48- and 80-byte lane strides spread over all banks) -- the FIRST pass in registers,
+// on the detrended and windowed samples as they come from memory (head_sums /
+// head_finish), the others in place in LDS, one barrier per pass -- and
 // untangled into the nfft / 2 + 1 bins of the real transform on the way out:
 //   X[k] = E[k] + W_nfft^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i (Z[k] - conj Z[M-k]) / 2.
 // In-place DIF leaves Z[k] at the digit-reversed slot pos[k] (host table).
