@@ -33,7 +33,6 @@ struct alignas(16) C2 {
 
 constexpr int kMaxPass = 14;   // 2^13 * ... : M <= 10240 needs at most 7 radix-4/2 passes
 constexpr int kAcc = 12;       // PSD sums per thread: bins t + NT m, m < kAcc
-constexpr int kBatch = 4;      // sample trips whose loads are in flight together (divides kAcc)
 constexpr int kMaxM = 10240;   // 160 KB of LDS
 
 struct Args {
