@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 12
+        kind = it % 13
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -188,6 +188,25 @@ def main():
                 finally:
                     del os.environ["OSZ_CHAIN_API"]
                 e, what = rel(got_, ref_) * 100, f"api chain taps={taps} C={C} cs={cs} total={total}"
+            elif kind == 12:   # FIR producer -> sosfilt through the API: one launch per chunk vs SciPy
+                from functools import partial
+                taps = int(rng.choice([2, 64, 301, 512, 1024, 1025, 2049]))
+                C = int(rng.integers(1, 6))
+                cs = int(rng.integers(65536, 140000))
+                nch_ = int(rng.integers(3, 7))
+                total = cs * (nch_ - 1) + int(rng.integers(1, cs + 1))
+                h = rng.standard_normal(taps) / np.sqrt(taps)
+                sos = designs[int(rng.integers(0, len(designs)))]
+                xh = rng.standard_normal((C, total))
+                src = producer(torch.from_numpy(xh).cuda() if it % 2 else xh, cs, -1)
+                fir_ = producer(partial(nm.oaconvolve, src, h, -1, "same"), cs, -1, shape=src.shape)
+                pieces = list(nm.sosfilt(fir_, sos, -1))
+                got_ = np.concatenate([p_.cpu().numpy() if torch.is_tensor(p_) else p_ for p_ in pieces], -1)
+                lens_ = [p_.shape[-1] for p_ in pieces]
+                u_ = sps.oaconvolve(xh, h[None], axes=-1)[:, (taps - 1) // 2:(taps - 1) // 2 + total]
+                e, what = rel(got_, sps.sosfilt(sos, u_, axis=-1)), f"api causal chain taps={taps} C={C} cs={cs} total={total}"
+                if lens_ != [cs] * (nch_ - 1) + [total - cs * (nch_ - 1)]:
+                    e = float("inf")
             elif kind == 4:    # psd
                 fs = float(rng.choice([250, 500, 1000, 4096, 173.61, 700, 1111, 3001]))
                 res = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
