@@ -27,6 +27,7 @@
 #include "fft4096.h"
 #include "fft8.h"
 #include "specmix.h"
+#include "nega_window.h"
 
 namespace osz {
 
@@ -174,9 +175,12 @@ constexpr int kNF = 2049;   // nfft / 2 + 1
 // segment b's first half IS segment a's second half in the same registers and
 // b's second half is the next pair's first half, so a thread loads 16 new
 // samples per pair instead of 32: each sample goes through the vector-memory
-// path once.  (Requesting those 16 one pair ahead was measured 14 % SLOWER,
-// as the same idea was in the FIR kernel: the kernel is not latency-starved
-// at two workgroups per CU, and the longer-lived registers cost more.)  The
+// path once.  (Requesting those 16 one pair ahead INTO REGISTERS was measured
+// 14 % slower: the kernel is not latency-starved at two workgroups per CU, and
+// the longer-lived registers cost more.  In the mean mode they now come by
+// LDS-DMA into the wave's own pieces of the cube, which holds no register:
+// nothing with the constant trend, 0.91 -> 0.83 ms with the linear one, whose
+// registers were the tightest.)  The
 // two spectra are separated through the view-C slots a thread already owns
 // (Z[k] parked at slot_c(t, k >> 8), its mirror Z[N-k] read from thread
 // 256 - t's slots).
@@ -212,6 +216,11 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
     for (int j = 0; j < 16; ++j) acc[j] = 0.0;
     double keep[HALF ? 8 : 1];
     bool have_keep = false;
+    // mean mode at 50 % overlap: the next pair's sixteen new rows are requested by LDS-DMA into
+    // this wave's own pieces of the cube (nega_window.h: zp_request_rows) as soon as pass 3 has
+    // read them -- view C and view A of fft::cube are the same 1 KB piece per plane and wave --
+    // and picked up at the top of the next pair: no registers held, no load latency there
+    bool pending = false;
 
     auto ld = [&](int64_t v) { return v < a.ncarry ? cr[v] : xr[v - a.ncarry]; };
 
@@ -221,7 +230,19 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
         const bool has_b = sb < a.nseg;
         const int64_t va = sa * (int64_t)a.stride, vb = va + a.stride;
         // ---- load both segments (virtual stream = carry ++ chunk)
-        if (HALF) {
+        if (HALF && pending) {
+            asm volatile("s_waitcnt vmcnt(0) ; osz:dma rows" ::: "memory");
+            const char *mine = reinterpret_cast<const char *>(L) + 1024 * (t >> 6) + 8 * (t & 63);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                re[j] = keep[HALF ? j : 0];
+                re[8 + j] = *reinterpret_cast<const double *>(mine + 4096 * (j >> 1) + 512 * (j & 1));
+                im[j] = re[8 + j];
+                im[8 + j] = *reinterpret_cast<const double *>(mine + 4096 * (4 + (j >> 1)) + 512 * (j & 1));
+                keep[HALF ? j : 0] = im[8 + j];
+            }
+            have_keep = true;
+        } else if (HALF) {
             const bool chunk_only = va + (have_keep ? 2048 : 0) >= a.ncarry;
             const double *q = xr + (va - a.ncarry) + t;
             if (have_keep) {
@@ -312,7 +333,29 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
         __syncthreads();
         fft::cube::f2(tt, re, im, tw2, L);
         __syncthreads();
-        fft::cube::f3(tt, re, im, L);
+        if (MODE == OSZ_SPEC_PSD_MEAN && HALF) {
+            // pass 3 with the request between its loads and its butterflies
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const C2 v = L[fft::cube::slot_c(tt, j)];
+                re[j] = v.re;
+                im[j] = v.im;
+            }
+            pending = false;
+            if (p + 1 < p1) {
+                const int64_t sa2 = 2 * (p + 1), va2 = sa2 * (int64_t)a.stride;
+                const double *src = xr + (va2 - a.ncarry) + 2048;
+                // a whole pair, all of it in the chunk, rows on 16-byte addresses
+                if (sa2 + 1 < a.nseg && va2 + 2048 >= a.ncarry && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0) ; osz:dma" ::: "memory");
+                    zp_request_rows<8>(src, 16, t, L);
+                    pending = true;
+                }
+            }
+            fft::fwd16(re, im);
+        } else {
+            fft::cube::f3(tt, re, im, L);
+        }
         if (MODE == OSZ_SPEC_PSD_MEAN) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = fma(re[r], re[r], fma(im[r], im[r], acc[r]));
