@@ -375,6 +375,8 @@ def run_chain(args, R, h, sos):
     fir = dev.FirStream(h, C)
     iir = dev.SosStream(sos, C)
     zp = not (args.unfused or args.fused or args.two_kernel)
+    if args.zp_tol:
+        dev.chain_zp_tolerance(fir, iir, args.zp_tol)       # A/B only: the default line runs the library's default cut
     lag = dev.chain_zp_lag(fir, iir) if zp else -1
     if zp and lag < 0:
         raise RuntimeError("the zero-phase chain kernel refused the benchmark's filters")
@@ -779,6 +781,9 @@ def main():
                     help="welch: all-reduce through torch.distributed (RCCL) or through "
                          "osz_welch_reduce of the C ABI")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--zp-tol", type=float, default=0.0,
+                    help="A/B: where the chain kernel cuts its bursts (0: the library's default, 1e-15; "
+                         "rounds 3-4 ran 1e-12 on zero-mean data)")
     ap.add_argument("--no-steady", action="store_true",
                     help="skip the second, later timing of the same steps (steady_state)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",

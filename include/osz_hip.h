@@ -238,10 +238,13 @@ int osz_chain_wait(osz_sos_t sos, void *stream);
  *                           ringing longer than the transform's guard rows, FIR longer
  *                           than 1793 taps or partitioned)
  *   osz_chain_zp_tolerance  where the bursts are cut, relative to the norm of the composite
- *                           impulse response (0: the default, 1e-12; before osz_chain_zp_lag /
- *                           _open).  What is cut off scales with the INPUT: a stream whose
- *                           offset is 10^4 times its in-band signal wants 1e-15 (one more burst
- *                           row each way, +2 % time) to stay at 1e-10 of its output.
+ *                           impulse response (0: the default, 1e-15; before osz_chain_zp_lag /
+ *                           _open; also the cut of osz_chain_forward's spectral kernels for
+ *                           this cascade).  What is cut off scales with the INPUT's magnitude,
+ *                           about 0.3 tol max|x|: the default keeps it at float64's own
+ *                           rounding on any input; a caller whose streams are zero-mean may
+ *                           relax it (1e-12: one burst row less each way, 2 % less time, 6e-13
+ *                           of the output scale on such data).
  *   osz_chain_zp_min_chunk  shortest chunk osz_chain_zp_step takes (two blocks)
  *   osz_chain_zp_open       starts a stream at sample 0: the FIR's overlap tail must be
  *                           zero; the forward cascade starts from the state on the SOS

@@ -286,7 +286,11 @@ def _fir_feeding(pro, axis):
         # flows plan their chunks from the shape
         return None
     ndim = len(pro.shape)
-    if normalize_axis(fir_axis, ndim) != normalize_axis(axis, ndim):
+    # the fused flows filter along the axis the chunks are cut along: the FIR's axis, the
+    # cascade's axis and both producers' chunking axes must be one and the same
+    ax = normalize_axis(axis, ndim)
+    if (normalize_axis(fir_axis, ndim) != ax or normalize_axis(pro.axis, ndim) != ax
+            or normalize_axis(source.axis, ndim) != ax):
         return None
     taps = np.asarray(taps, dtype=np.float64)
     if taps.ndim != 1 or not 2 <= len(taps) <= 2049 or tuple(source.shape) != tuple(pro.shape):
@@ -333,6 +337,7 @@ def _sosfilt_after_fir(pro, source, taps, sos, zi):
         C = layout.nch
         fir, iir = dev.FirStream(taps, C), dev.SosStream(sos, C)
         try:
+            dev.chain_zp_tolerance(fir, iir, dev.zp_tolerance())   # (the forward link's cut too)
             if zi is not None:
                 iir.set_state(_zi_to_2d(zi, sos.shape[0], layout))
             resident = dev.is_tensor(first)
@@ -431,7 +436,7 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
             device = first.device if resident else "cuda"
             pipe = None if resident else dev.HostPipe(layout)
             flying = deque()
-            dev.chain_zp_tolerance(fir, iir, dev.zp_tolerance_for(first, axis))
+            dev.chain_zp_tolerance(fir, iir, dev.zp_tolerance())
             lag = dev.chain_zp_lag(fir, iir)
             if (lag >= 0 and nchunks >= 6 and os.environ.get("OSZ_CHAIN_ZP", "1") != "0"
                     and cs >= max(4 * (lcut + lag), warm + lcut + lag, 2 * dev.chain_zp_min_chunk(fir, iir))):
@@ -715,7 +720,7 @@ def sosfiltfilt(pro, sos, axis):
                 and stream.warm_len <= cs):
             ident = dev.FirStream(np.array([1.0, 0.0]), layout.nch)
             try:
-                dev.chain_zp_tolerance(ident, stream, dev.zp_tolerance_for(first, layout.axis))
+                dev.chain_zp_tolerance(ident, stream, dev.zp_tolerance())
                 lag = dev.chain_zp_lag(ident, stream)
                 if lag >= 0 and cs >= max(4 * lag, stream.warm_len + lag, 2 * dev.chain_zp_min_chunk(ident, stream)):
                     yield from _zero_phase_stream(ident, stream, layout, pipe, flying, first, chunks,

@@ -445,13 +445,17 @@ static int spec_build(ChainSpec *s) {
         return OSZ_OK;
     };
     int rcu;
+    // where the right tail's bursts are cut: the library's default unless the caller set one
+    // (osz_chain_zp_tolerance names both links of a cascade)
+    const spec::ld_t tol = sos->zp_tol > 0.0 ? (spec::ld_t)sos->zp_tol : spec::kTailTol;
     // one real block per transform where its tables exist (OSZ_SPEC_NEGA=0: the pair kernel below)
     static const bool nega_on = [] {
         const char *e = getenv("OSZ_SPEC_NEGA");
         return !(e && e[0] == '0');
     }();
     if (nega_on) {
-        const spec::TablesZp Tn = spec::build_specn(fir->htaps.data(), wlen, sos->coef, nsec, sos->warm_len <= (1 << 20));
+        const spec::TablesZp Tn = spec::build_specn(fir->htaps.data(), wlen, sos->coef, nsec, sos->warm_len <= (1 << 20),
+                                                    15360 - 1024, tol);
         if (Tn.eligible) {
             const size_t nl = (size_t)Tn.R * Tn.NM * 2;
             std::vector<double> cat(Tn.L.begin(), Tn.L.begin() + nl);
@@ -478,7 +482,7 @@ static int spec_build(ChainSpec *s) {
             return OSZ_OK;
         }
     }
-    const spec::Tables T = spec::build(fir->htaps.data(), wlen, sos->coef, nsec, sos->warm_len <= (1 << 20));
+    const spec::Tables T = spec::build(fir->htaps.data(), wlen, sos->coef, nsec, sos->warm_len <= (1 << 20), tol);
     if (!T.eligible) return OSZ_OK;
     if ((rcu = up(&s->dH, spec_permuted_spectrum(T.H))) || (rcu = up(&s->dM, T.M)) || (rcu = up(&s->dP, T.P)) || (rcu = up(&s->dL, T.L)))
         return rcu;

@@ -649,6 +649,7 @@ struct ChainZp {
     double *dscratch = nullptr;
     double *dfin = nullptr;        // osz_chain_zp_finish: the kernel's outputs for the head of what follows
     size_t fin_cap = 0;            // doubles
+    hipEvent_t fin_done = nullptr; // behind the last copy out of dfin: a later finish may come on another stream
     double *dzero = nullptr;       // (nsec, nch, 2) zeros: start state of the opening's backward pass
 };
 
@@ -675,6 +676,7 @@ static void zp_free(ChainZp *s) {
     (void)hipFree(s->dnanpos);
     (void)hipFree(s->dscratch);
     (void)hipFree(s->dfin);
+    if (s->fin_done) (void)hipEventDestroy(s->fin_done);
     (void)hipFree(s->dzero);
     delete s;
 }
@@ -710,12 +712,12 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
         fir->zp = sos->zp = s;
         if (fir->parts.size() == 1 && fir->nch == sos->nch) {
             spec::TablesZp T;
+            const double tol = sos->zp_tol > 0.0 ? sos->zp_tol : (double)spec::kTailTol;
             if (zp_nega()) {
                 // The tables of the last few (taps, cascade, tolerance) are kept: the same filters
                 // run over recording after recording, and 5 ms of long-double arithmetic per
                 // stream are 4 % of a 1e8-sample stream of 256 channels.
                 const bool forgets = sos->warm_len <= (1 << 20);
-                const double tol = sos->zp_tol > 0.0 ? sos->zp_tol : (double)spec::kTailTol;
                 std::vector<double> key(fir->htaps);
                 key.insert(key.end(), sos->coef, sos->coef + 6 * (size_t)sos->nsec);
                 key.push_back(tol);
@@ -742,7 +744,8 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
                 s->nega = T.eligible;
             }
             if (!T.eligible)
-                T = spec::build_zp(fir->htaps.data(), fir->ntaps, sos->coef, sos->nsec, sos->warm_len <= (1 << 20));
+                T = spec::build_zp(fir->htaps.data(), fir->ntaps, sos->coef, sos->nsec, sos->warm_len <= (1 << 20),
+                                   15360, (spec::ld_t)tol);
             if (T.eligible) {
                 auto up = [](double **d, const std::vector<double> &v) -> int {
                     OSZ_HIP(hipMalloc(d, v.size() * sizeof(double)));
@@ -897,6 +900,14 @@ int osz_chain_zp_tolerance(osz_fir_t fir, osz_sos_t sos, double tol) {
     OSZ_REQUIRE(tol == 0.0 || (tol >= 1e-18 && tol <= 1e-6), "osz_chain_zp_tolerance: tol=%g", tol);
     if (sos->zp && sos->zp->open) return fail(OSZ_ERR_STATE, "osz_chain_zp_tolerance: a zero-phase stream is open");
     if (sos->zp_tol != tol) {
+        // the forward link (osz_chain_forward) cuts its right tail at the same tolerance: the
+        // handles' own states are brought up to date before its tables go
+        if (sos->spec) {
+            int rc = spec_settle(sos->spec, nullptr);
+            if (rc) return rc;
+            OSZ_HIP(hipStreamSynchronize(nullptr));
+            spec_unlink(sos->spec);
+        }
         sos->zp_tol = tol;
         if (sos->zp) zp_unlink(sos->zp);        // the tables are rebuilt at the next use
     }
@@ -1000,7 +1011,9 @@ int osz_chain_zp_finish(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t l
         const size_t want = (size_t)nch * (size_t)m;
         if (want > s->fin_cap) {
             if (s->dfin) {
-                OSZ_HIP(hipStreamSynchronize(st));        // an earlier finish may still read it
+                // an earlier finish may still read it -- on this stream or on the one it came on
+                if (s->fin_done) OSZ_HIP(hipEventSynchronize(s->fin_done));
+                OSZ_HIP(hipStreamSynchronize(st));
                 OSZ_HIP(hipFree(s->dfin));
                 s->dfin = nullptr;
                 s->fin_cap = 0;
@@ -1009,10 +1022,15 @@ int osz_chain_zp_finish(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t l
                 return fail(OSZ_ERR_NOMEM, "osz_chain_zp_finish: scratch of %zu doubles", want);
             s->fin_cap = want;
         }
+        // (the scratch is ordered by events, not by the caller's choice of stream: the kernel
+        // below must not overwrite what the previous finish's copy is still reading)
+        if (s->fin_done) OSZ_HIP(hipStreamWaitEvent(st, s->fin_done, 0));
         int rc = zp_launch(s, x, ldx, m, nullptr, 0, 0, s->dfin, m, st);
         if (rc) return rc;
         OSZ_HIP(hipMemcpy2DAsync(y, sizeof(double) * ldy, s->dfin, sizeof(double) * m, sizeof(double) * ny, nch,
                                  hipMemcpyDeviceToDevice, st));
+        if (!s->fin_done) OSZ_HIP(hipEventCreateWithFlags(&s->fin_done, hipEventDisableTiming));
+        OSZ_HIP(hipEventRecord(s->fin_done, st));
     }
     s->open = false;
     return OSZ_OK;

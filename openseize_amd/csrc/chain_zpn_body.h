@@ -479,7 +479,9 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
 }
 
 // (one translation unit per mode count: chain_zpn_{2,4,6,8}.hip define OSZ_ZPN_NM and include
-// this file; the dispatcher lives with NM = 2)
+// this file; the dispatcher lives with NM = 2.  OSZ_ZPN_NO_DISPATCH: the kernel template alone, for
+// the diagnostic builds of benchmarks/ that instantiate one instance)
+#ifndef OSZ_ZPN_NO_DISPATCH
 template <int NM, int NS>
 static zp_kern_t zpn_kernel_nb(int nb, int r) {
     static const zp_kern_t k[7] = {chain_zpn_kernel<24, NM, NS>, chain_zpn_kernel<25, NM, NS>,
@@ -540,5 +542,6 @@ zp_kern_t zpn_kernel_for(int nb, int nm, int ns, int r) {
            : nm == 8 ? zpn_kernel_nm8(nb, ns, r) : nullptr;
 }
 #endif
+#endif  // OSZ_ZPN_NO_DISPATCH
 
 }  // namespace osz

@@ -10,7 +10,8 @@
 // fork(): the workers exist in the process that created them only.  The pool is never destroyed
 // (no join at exit: a forked child that runs static destructors would wait for threads it does
 // not have), and a child made by fork() copies single-threaded: pthread_atfork marks the pool it
-// inherited as without workers and gives it fresh locks (the parent may have forked mid-job).
+// inherited as without workers, and a pool without workers never touches its locks (which the
+// parent may have held when it forked).
 #include <pthread.h>
 
 #include <atomic>

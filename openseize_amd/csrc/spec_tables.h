@@ -15,9 +15,9 @@
 //         on the basis Re(lambda^l), -Im(lambda^l) by Householder QR
 //   P     [32][NM][2] lambda^(16 i), i < 16, then lambda^i, i < 16
 //   L     [5][NM][2]  lambda^(256 r)
-//   R     rows of 256 samples over which a burst exceeds kTailTol (1e-12) of the output scale,
-//         from the tail energy of the composite impulse response (as the two-sided tables
-//         below: the cut buys time, the path's contract is 1e-6)
+//   R     rows of 256 samples over which a burst exceeds the tail tolerance (kTailTol, 1e-15 of
+//         the composite impulse response's norm unless the caller relaxes it), from the tail
+//         energy of that response (as the two-sided tables below)
 #pragma once
 
 #include <algorithm>
@@ -33,9 +33,16 @@ typedef long double ld_t;
 constexpr int kFit = 64;      // samples of row 15 the fit reads (one wave)
 constexpr int kRMax = 5;      // burst rows supported (the pair kernels)
 constexpr int kRMaxN = 8;     // ... by the one-block kernel (chain_zpn_body.h: its instances hold 5 or 8 rows)
-// where a burst is cut off, relative to the norm of the composite impulse response (see the
-// two-sided tables below for what it costs and buys)
-constexpr ld_t kTailTol = 1e-12L;
+// Where a burst is cut off, relative to the norm of the composite impulse response.  What is cut
+// is an error proportional to the INPUT's magnitude (a block's ringing is driven by everything in
+// it, offsets included, and only cancels between neighbouring blocks as far as both were kept):
+// about 0.3 tol max|x| in the output.  1e-15 puts that at the level of the rounding the
+// reference's own float64 recurrences leave on such an input (eps max|x| and up), so no stream --
+// whatever offset, step or rail it carries, wherever in the stream -- sees more from the cut than
+// from float64 itself.  (Rounds 3-4 cut at 1e-12 and guarded large offsets by a look at the
+// first samples of the first chunk; an offset appearing later got the loose cut.  A caller that
+// knows its data may still relax it: osz_chain_zp_tolerance.)
+constexpr ld_t kTailTol = 1e-15L;
 constexpr int kN = 4096;
 
 struct Tables {
@@ -155,7 +162,8 @@ inline void mode_pow(const Mode &m, int e, ld_t &pr, ld_t &pi) {
 
 // sos: nsec rows of (b0 b1 b2 a0 a1 a2), a0 == 1; forgets: the cascade's memory is
 // bounded (osz_sos_s::warm_len is a finite number of samples)
-inline Tables build(const double *taps, int wlen, const double *sos, int nsec, bool forgets) {
+inline Tables build(const double *taps, int wlen, const double *sos, int nsec, bool forgets,
+                    ld_t tail_tol = kTailTol) {
     Tables T;
     if (wlen < 2 || !forgets) return T;
     int NR = (3841 - wlen) / 256;
@@ -241,7 +249,7 @@ inline Tables build(const double *taps, int wlen, const double *sos, int nsec, b
     std::vector<ld_t> tail2(glen + 1, 0.0L);
     for (int i = glen - 1; i >= 0; --i) tail2[i] = tail2[i + 1] + g[i] * g[i];
     int R = 1;
-    while (R <= 16 && kN + 256 * R - S < glen && sqrtl(tail2[kN + 256 * R - S]) > kTailTol * sqrtl(tail2[0]))
+    while (R <= 16 && kN + 256 * R - S < glen && sqrtl(tail2[kN + 256 * R - S]) > tail_tol * sqrtl(tail2[0]))
         ++R;
     // the +mu burst of a block must end inside the next block (D + R <= NR) and the closing
     // pair's accumulator holds 8192 samples (NR + R <= 16)
@@ -313,8 +321,8 @@ inline Tables build(const double *taps, int wlen, const double *sos, int nsec, b
 //         (Rf <= R).  What is cut off is the error the kernel adds to the transform's own
 //         rounding (1e-14 of the output scale): for the headline filters the tails are
 //         7.6e-13 / 7.3e-13 at R, Rf = 2, 1 and 3.8e-16 / 3.6e-16 at 3, 2 -- measured against
-//         SciPy 5e-13 and 7e-15, the step 1.53 and 1.66 ms.  The contract of the path is 1e-6
-//         (BASELINE.json), the tests hold 1e-9: the tolerance buys the 8 %.
+//         SciPy 5e-13 and 7e-15.  The default (kTailTol above) is the tighter pair: the cut
+//         scales with the input's magnitude, not with the output's.
 // NR is the largest block height whose guard rows hold the bursts (R <= D, D + Rf <= NR).
 
 struct TablesZp {
@@ -330,7 +338,7 @@ struct TablesZp {
 // each (measured: at 81 152 the second one no longer fits and the kernel takes 2.4 instead of
 // 1.8 ms), i.e. 15 360 behind the 64 KB cube.
 inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int nsec, bool forgets,
-                         int lds_budget = 15360) {
+                         int lds_budget = 15360, ld_t tail_tol = kTailTol) {
     TablesZp T;
     if (wlen < 2 || !forgets) return T;
     std::vector<Mode> modes;
@@ -387,8 +395,8 @@ inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int ns
         for (int r = 1; r <= kRMax && !(rb && rf); ++r) {
             const int ir = Lg + kN + 256 * r - S + 1, il = Lg - 256 * r;
             if (ir >= 2 * Lg || il < 0) break;
-            if (!rf && sqrtl(right2[ir]) <= kTailTol * tot) rf = r;
-            if (!rb && sqrtl(left2[il]) <= kTailTol * tot) rb = r;
+            if (!rf && sqrtl(right2[ir]) <= tail_tol * tot) rf = r;
+            if (!rb && sqrtl(left2[il]) <= tail_tol * tot) rb = r;
         }
         if (rb && rf && rf <= rb && rb <= D && D + rf <= cand) {
             NR = cand;
