@@ -365,7 +365,18 @@ def run_chain(args, R, h, sos):
         time.sleep(1e-3 * args.steps)
         elapsed = R.max_over_ranks(time.perf_counter() - t0)
         R.barrier()
-        return elapsed, {}, None, {"channel_blocks": blocks.tolist()}
+        extra = {"channel_blocks": blocks.tolist()}
+        if R.world > 1 and args.scaling == "weak":
+            # the strong leg's partition and gather (strong_leg below), without kernels
+            from openseize_amd import sharding
+            from openseize_amd.core import numerical as nm
+            lo, hi = sharding.channel_block(C_PER_GPU, R.rank, R.world)
+            per_rank = torch.zeros(R.world, dtype=torch.float64)
+            per_rank[R.rank] = 1.0 + R.rank
+            R.dist.all_reduce(per_rank)
+            extra["strong"] = {"channels_per_gpu": hi - lo, "chunks_per_launch": nm._zp_group(hi - lo),
+                               "ms_per_step_by_rank": per_rank.tolist(), "dry": True}
+        return elapsed, {}, None, extra
     from openseize_amd import _device as dev
     from openseize_amd import _lib
     lib = _lib.load()
@@ -380,10 +391,16 @@ def run_chain(args, R, h, sos):
     lag = dev.chain_zp_lag(fir, iir) if zp else -1
     if zp and lag < 0:
         raise RuntimeError("the zero-phase chain kernel refused the benchmark's filters")
-    ring = [dev.synth_normal(C, CHUNK, seed=0, ch0=ch0, n0=k * CHUNK) for k in range(3)]
+    # chunks per launch: 1 at 256 channels; a rank with fewer channels (--scaling strong: 256 / N)
+    # steps its resident stream 256 / C chunks at a time, as numerical.sosfiltfilt does
+    # (numerical._zp_group) -- a launch is always 2^28 channel-samples
+    from openseize_amd.core import numerical as nm
+    g = nm._zp_group(C) if zp else 1
+    NS = g * CHUNK
+    ring = [dev.synth_normal(C, NS, seed=0, ch0=ch0, n0=k * NS) for k in range(3)]
     # resident buffers with defined contents (zero-filled, so every page of the ring
     # has been written once before the first step reads or overwrites it)
-    fir_out = torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda")
+    fir_out = torch.zeros((C, NS), dtype=torch.float64, device="cuda")
     nf = 3 if (args.unfused or args.fused) else 4
     fwd = [torch.zeros_like(fir_out) for _ in range(nf)]
     y_out = torch.zeros_like(fir_out)
@@ -395,10 +412,12 @@ def run_chain(args, R, h, sos):
             # runs `lag` samples late) are the tail of output chunk k-1 and the head of chunk
             # k; output chunk k-2 is sealed (NaN reach of sosfiltfilt) and the caller's
             yb = fwd[k % nf]
-            dev.chain_zp_step(fir, iir, ring[k % len(ring)], out=yb[:, :CHUNK - lag],
-                              tail=fwd[(k - 1) % nf][:, CHUNK - lag:])
+            dev.chain_zp_step(fir, iir, ring[k % len(ring)], out=yb[:, :NS - lag],
+                              tail=fwd[(k - 1) % nf][:, NS - lag:])
             if k >= 2:
-                dev.chain_zp_seal(fir, iir, fwd[(k - 2) % nf], (k - 2) * CHUNK, 0, CHUNK)
+                for j in range(g):       # (one seal per output CHUNK, as the generator issues them)
+                    dev.chain_zp_seal(fir, iir, fwd[(k - 2) % nf][:, j * CHUNK:(j + 1) * CHUNK],
+                                      ((k - 2) * g + j) * CHUNK, 0, CHUNK)
             return
         if args.unfused:
             # chunk k: FIR, then ONE launch = forward(chunk k) + backward(chunk
@@ -429,14 +448,15 @@ def run_chain(args, R, h, sos):
     if zp:
         dev.chain_zp_open(fir, iir, 0)
     k = 0
-    for _ in range(max(args.warmup, 2)):
+    launches, warm_launches = -(-args.steps // g), max(-(-args.warmup // g), 2)
+    for _ in range(warm_launches):
         step(k)
         k += 1
     R.barrier()
     _lib.check(lib.osz_profile_reset())
     _lib.check(lib.osz_profile_enable(1))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(launches):
         step(k)
         k += 1
     dev.chain_wait(iir)                 # the last deferred backward pass (no-op otherwise)
@@ -451,25 +471,25 @@ def run_chain(args, R, h, sos):
     # steps behind W = 5 time that transient; a stream of hours runs at the rate below.
     steady = None
     if zp and not args.no_steady:
-        for _ in range(max(args.steps, 40 - args.steps - args.warmup)):
+        for _ in range(max(launches, 40 - launches - warm_launches)):
             step(k)
             k += 1
         R.barrier()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(launches):
             step(k)
             k += 1
         torch.cuda.synchronize()
         el2 = R.max_over_ranks(time.perf_counter() - t1)
         R.barrier()
-        steady = {"ms_per_step": el2 / args.steps * 1e3,
-                  "Msamples_s": R.ranks_seen() * C * CHUNK * args.steps / el2 / 1e6,
-                  "untimed_steps_before": k - args.steps,
+        steady = {"ms_per_step": el2 / (launches * g) * 1e3,
+                  "Msamples_s": R.ranks_seen() * C * NS * launches / el2 / 1e6,
+                  "untimed_steps_before": (k - launches) * g,
                   "note": "the same steps later in the stream, the GPU's power state settled; not `value`"}
     # order-independent checksum of the last output chunk (also the 8 B/lane
     # streaming read of known size that calibrates FETCH_SIZE in the PMC runs)
     bits, fsum = dev.checksum(fwd[(k - 3) % nf] if zp else y_out)
-    kernels = kernel_table(lib, C * CHUNK)
+    kernels = kernel_table(lib, C * NS)
     if not args.unfused and not zp:
         # beside the fused kernel and the backward pass, a step has the head of the chunk
         # (the 4096 of 2^20 samples that are not whole block pairs) on the plain kernels,
@@ -482,6 +502,8 @@ def run_chain(args, R, h, sos):
     extra = {"output_checksum": {"bits": f"{bits:#018x}", "sum": fsum}}
     if zp:
         extra["output_lag_samples"] = lag
+        extra["steps_done"] = launches * g            # (steps rounded up to whole launches)
+        extra["chunks_per_launch"] = g
     if steady:
         extra["steady_state"] = steady
     if args.full_stream:
@@ -489,7 +511,69 @@ def run_chain(args, R, h, sos):
         fir.close()
         iir.close()
         extra["full_stream"] = full_stream_leg(R, ring, h, sos)
-    return elapsed, kernels, roofline_of(kernels, C * CHUNK), extra
+    if zp and R.world > 1 and args.scaling == "weak":
+        del fwd, y_out, fir_out, ring
+        fir.close()
+        iir.close()
+        extra["strong"] = strong_leg(args, R, h, sos, R.world * C * CHUNK * launches / elapsed / 1e6)
+    return elapsed, kernels, roofline_of(kernels, C * NS), extra
+
+
+def strong_leg(args, R, h, sos, weak_value):
+    """Beside the weak line of an N > 1 run: the metric's OWN job -- 256 channels, split
+    channel_block-wise over the ranks (32 per GPU at 8) -- timed the same way (barrier,
+    K steps, max over ranks).  A rank steps its C = 256 / N channels 256 / C chunks per launch (what
+    numerical.sosfiltfilt does with a resident stream of few channels).  `efficiency` = this job's rate
+    over the weak line's: 1 when N GPUs run the 256 channels N times as fast as one GPU runs them."""
+    torch = R.torch
+    from openseize_amd import _device as dev
+    from openseize_amd import sharding
+    from openseize_amd.core import numerical as nm
+    lo, hi = sharding.channel_block(C_PER_GPU, R.rank, R.world)
+    C = hi - lo
+    fir, iir = dev.FirStream(h, C), dev.SosStream(sos, C)
+    lag = dev.chain_zp_lag(fir, iir)
+    g = nm._zp_group(C)
+    NS = g * CHUNK
+    ring = [dev.synth_normal(C, NS, seed=0, ch0=lo, n0=k * NS) for k in range(3)]
+    ys = [torch.zeros((C, NS), dtype=torch.float64, device="cuda") for _ in range(3)]
+
+    def step(k):
+        dev.chain_zp_step(fir, iir, ring[k % 3], out=ys[k % 3][:, :NS - lag], tail=ys[(k - 1) % 3][:, NS - lag:])
+        if k >= 1:
+            for j in range(g):
+                dev.chain_zp_seal(fir, iir, ys[(k - 1) % 3][:, j * CHUNK:(j + 1) * CHUNK], ((k - 1) * g + j) * CHUNK, 0, CHUNK)
+
+    iir.set_state_scaled(ring[0], 0)
+    dev.chain_zp_open(fir, iir, 0)
+    launches, warm = -(-args.steps // g), max(-(-args.warmup // g), 2)
+    k = 0
+    for _ in range(warm):
+        step(k)
+        k += 1
+    R.barrier()
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        step(k)
+        k += 1
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
+    elapsed = R.max_over_ranks(mine)
+    R.barrier()
+    per_rank = torch.zeros(R.world, dtype=torch.float64)
+    per_rank[R.rank] = mine / (launches * g) * 1e3
+    if R.dist is not None:
+        dev_t = per_rank.cuda()
+        R.dist.all_reduce(dev_t)
+        per_rank = dev_t.cpu()
+    fir.close()
+    iir.close()
+    value = C_PER_GPU * CHUNK * launches * g / elapsed / 1e6
+    return {"job": "256 channels split channel_block-wise over the ranks", "channels_per_gpu": C,
+            "chunks_per_launch": g, "steps": launches * g, "ms_per_step": elapsed / (launches * g) * 1e3,
+            "ms_per_step_by_rank": [float(v) for v in per_rank], "value": value, "unit": "Msamples/s",
+            "efficiency": value / weak_value,
+            "note": "efficiency = this rate / the weak line's `value` (N x one GPU's 256-channel rate)"}
 
 
 def chain_channels(args, R):
@@ -498,6 +582,9 @@ def chain_channels(args, R):
     GPU at 8 ranks)."""
     if args.scaling == "strong":
         from openseize_amd import sharding
+        if args.shard_of > 1 and R.world == 1:      # one GPU standing in for rank 0 of an N-way split
+            lo, hi = sharding.channel_block(C_PER_GPU, 0, args.shard_of)
+            return hi - lo, lo
         lo, hi = sharding.channel_block(C_PER_GPU, R.rank, R.world)
         return hi - lo, lo
     return C_PER_GPU, R.rank * C_PER_GPU
@@ -789,6 +876,10 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="chain: weak = 256 channels per rank; strong = the metric's 256 channels "
                          "split over the ranks (32 per GPU at 8 ranks)")
+    ap.add_argument("--shard-of", type=int, default=1,
+                    help="with --scaling strong on ONE GPU: run rank 0's shard of an N-way split of the 256 "
+                         "channels (N = 8: 32 channels, 8 chunks per launch) -- the one-GPU stand-in for a "
+                         "point of the strong curve; `value` is then that shard's rate x N")
     ap.add_argument("--two-kernel", action="store_true",
                     help="chain: osz_chain_step, the fused FIR + forward SOS kernel with the backward "
                          "pass of chunk k-2 beside it on a second stream (the round-2 step; the "
@@ -853,19 +944,24 @@ def main():
         parallelism = f"channel-shard x{R.world}"
     ch_per_gpu = {"stft": STFT_CH, "fir": FIR_CH}.get(args.workload, C_PER_GPU)
     strong = args.workload == "chain" and args.scaling == "strong"
+    steps_done = (extra or {}).get("steps_done", args.steps)
     if strong:
         # the job is the metric's 256 channels whatever the rank count
         samples_per_step = C_PER_GPU * CHUNK
-        value = samples_per_step * args.steps / elapsed / 1e6
+        value = samples_per_step * steps_done / elapsed / 1e6
         ch_per_gpu = C_PER_GPU / R.world
         parallelism = f"256 channels split over {R.world} ranks (channel_block)"
+        if args.shard_of > 1 and R.world == 1:
+            ch_per_gpu = C_PER_GPU / args.shard_of
+            parallelism = (f"rank 0's shard of a {args.shard_of}-way channel_block split, on one GPU; value = "
+                           f"that shard's rate x {args.shard_of} (a stand-in, not a {args.shard_of}-GPU run)")
     else:
         samples_per_step = ch_per_gpu * CHUNK
-        value = samples_per_step * args.steps * R.world / elapsed / 1e6
+        value = samples_per_step * steps_done * R.world / elapsed / 1e6
     out = {
         "metric": metric, "value": value, "unit": "Msamples/s", "n_gpus": R.world,
-        "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "steps": steps_done, "warmup": args.warmup,
+        "ms_per_step": elapsed / steps_done * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": label,

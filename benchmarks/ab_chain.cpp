@@ -27,6 +27,8 @@ struct Lib {
     int (*zp_step)(h_t, h_t, const double *, int64_t, int64_t, double *, int64_t, int64_t, double *, int64_t, void *);
     int (*sos_set_state)(h_t, const double *);
     const char *(*last_error)();
+    int (*dbg_clk)(unsigned long long *) = nullptr;   // diagnostic builds: shader / 100 MHz clock ticks of one workgroup's life
+    double ghz = 0.0;
     h_t fir = nullptr, sos = nullptr;
     int64_t lag = 0;
     std::vector<float> ms;
@@ -78,6 +80,7 @@ int main(int argc, char **argv) {
         sym(L.dl, "osz_chain_zp_open", L.zp_open);
         sym(L.dl, "osz_chain_zp_step", L.zp_step);
         sym(L.dl, "osz_last_error", L.last_error);
+        L.dbg_clk = reinterpret_cast<int (*)(unsigned long long *)>(dlsym(L.dl, "osz_dbg_clk"));
         libs.push_back(L);
     }
     double *x[3], *y[2];
@@ -130,6 +133,10 @@ int main(int argc, char **argv) {
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
             L.ms.push_back(ms / 30);
+            if (L.dbg_clk) {
+                unsigned long long c[4] = {0, 0, 0, 0};
+                if (L.dbg_clk(c) == 0 && c[1]) L.ghz = (double)c[0] / (double)c[1] * 0.1;
+            }
             if (r == rounds - 1) {
                 std::vector<double> out((size_t)n);
                 hipMemcpy(out.data(), y[(k - 1) & 1] + 5 * n, n * 8, hipMemcpyDeviceToHost);   // channel 5 of the last chunk
@@ -143,7 +150,9 @@ int main(int argc, char **argv) {
         std::sort(m.begin(), m.end());
         printf("%-40s lag %4lld  median %.4f  best %.4f ms  (", L.path, (long long)L.lag, m[m.size() / 2], m[0]);
         for (float v : L.ms) printf(" %.4f", v);
-        printf(" )  sum %.12e\n", L.sum);
+        printf(" )  sum %.12e", L.sum);
+        if (L.ghz > 0.0) printf("  shader clock %.3f GHz", L.ghz);
+        printf("\n");
     }
     return 0;
 }

@@ -6,7 +6,9 @@ tutorials run 4 channels.  One JSON line per (workload, channels):
 
     PYTHONPATH=. python benchmarks/sweep_chain.py > profiles/rNN_channel_sweep.jsonl
 
-  chain  FIR(1024) -> sosfiltfilt(6 sections), one osz_chain_zp_step (+ seal) per 2^20-sample chunk
+  chain  FIR(1024) -> sosfiltfilt(6 sections) on osz_chain_zp_step (+ a seal per chunk): 256 / C chunks of
+         2^20 samples per launch, as numerical.sosfiltfilt steps a resident stream of C channels (round 5:
+         `chunks_per_launch`); `chain_1` is the same with every chunk its own launch (rounds 3-4)
   fir    FIR(1024) overlap-add alone (osz_fir_push)
   welch  Welch PSD nperseg 4096, 50 % overlap, segment average (osz_spec_push)
   sosfiltfilt  the 6-section cascade alone, zero phase: one osz_chain_zp_step per chunk with the
@@ -36,28 +38,37 @@ def timed(step, steps, warm):
     return (time.perf_counter() - t0) / steps
 
 
-def chain(C, steps=24, warm=6):
+def chain(C, steps=24, warm=6, group=None):
     import scipy.signal as sps
     import torch
     from openseize_amd import _device as dev
+    from openseize_amd.core import numerical as nm
     h = sps.firwin(1024, 0.2)
     sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
-    ring = [dev.synth_normal(C, CHUNK, seed=0, n0=k * CHUNK) for k in range(3)]
+    g = nm._zp_group(C) if group is None else group       # chunks per launch (the generators' own rule)
+    n = g * CHUNK
+    ring = [dev.synth_normal(C, n, seed=0, n0=k * n) for k in range(3)]
     fir, iir = dev.FirStream(h, C), dev.SosStream(sos, C)
     lag = dev.chain_zp_lag(fir, iir)
-    ys = [torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda") for _ in range(4)]
+    ys = [torch.zeros((C, n), dtype=torch.float64, device="cuda") for _ in range(3)]
     iir.set_state_scaled(ring[0], 0)
     dev.chain_zp_open(fir, iir, 0)
 
     def step(k):
-        dev.chain_zp_step(fir, iir, ring[k % 3], out=ys[k % 4][:, :CHUNK - lag], tail=ys[(k - 1) % 4][:, CHUNK - lag:])
-        if k >= 2:
-            dev.chain_zp_seal(fir, iir, ys[(k - 2) % 4], (k - 2) * CHUNK, 0, CHUNK)
+        dev.chain_zp_step(fir, iir, ring[k % 3], out=ys[k % 3][:, :n - lag], tail=ys[(k - 1) % 3][:, n - lag:])
+        if k >= 1:                                   # the chunks that have just become complete, one seal each
+            for j in range(g):
+                dev.chain_zp_seal(fir, iir, ys[(k - 1) % 3][:, j * CHUNK:(j + 1) * CHUNK], ((k - 1) * g + j) * CHUNK, 0, CHUNK)
 
-    dt = timed(step, steps, warm)
+    dt = timed(step, steps, warm) / g
     fir.close()
     iir.close()
-    return dt, 48
+    return dt, 48, {"chunks_per_launch": g}
+
+
+def chain_1(C, steps=24, warm=6):
+    dt, bps, extra = chain(C, steps, warm, group=1)
+    return dt, bps, extra
 
 
 def sosfiltfilt(C, steps=24, warm=6):
@@ -116,7 +127,7 @@ def welch(C, steps=24, warm=6):
 
 if __name__ == "__main__":
     rows = []
-    for name, fn in (("chain", chain), ("fir", fir_only), ("welch", welch), ("sosfiltfilt", sosfiltfilt)):
+    for name, fn in (("chain", chain), ("chain_1", chain_1), ("fir", fir_only), ("welch", welch), ("sosfiltfilt", sosfiltfilt)):
         for C in (4, 8, 16, 32, 64, 128, 256):
             try:
                 dt, bps, *extra = fn(C)

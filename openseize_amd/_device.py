@@ -332,7 +332,10 @@ class Layout:
         out = torch.movedim(out, -1, self.axis)
         if host and not _EMIT.get():
             return out.cpu().numpy()
-        return out.contiguous()
+        # (a resident result whose sample axis is the last one is handed on as the view it is:
+        # the chunks of a grouped zero-phase step are column ranges of the step's buffer, and a
+        # copy of each would move as many bytes again as the kernel did)
+        return out if self.axis == self.ndim - 1 else out.contiguous()
 
 
 # ---------------------------------------------------------------------------

@@ -559,6 +559,26 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
     return gen
 
 
+def _zp_group(nch):
+    """Chunks per step of the zero-phase kernel for ``nch`` channels: as many as make a step of
+    256 channel-chunks (``OSZ_ZP_GROUP`` overrides; 1: every chunk its own launch)."""
+    env = os.environ.get("OSZ_ZP_GROUP")
+    if env:
+        return max(1, int(env))
+    return max(1, 256 // max(int(nch), 1))
+
+
+def _row_joined(a, b):
+    """The (C, na + nb) view of two 2-D device views of ONE storage whose rows continue each
+    other (b's row r starts where a's row r ends), or None."""
+    if (a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0] or a.stride() != b.stride() or a.stride(1) != 1
+            or a.dtype != b.dtype or a.device != b.device
+            or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
+            or b.storage_offset() != a.storage_offset() + a.shape[1]):
+        return None
+    return a.as_strided((a.shape[0], a.shape[1] + b.shape[1]), a.stride(), a.storage_offset())
+
+
 def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, total, lcut, rcut, lag, device,
                        what="sosfiltfilt after oaconvolve"):
     """The body of ``_sosfiltfilt_after_fir`` on the zero-phase kernel (C ABI: osz_chain_zp_*,
@@ -617,6 +637,33 @@ def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, 
     junk = torch.empty((C, shift), dtype=torch.float64, device=device)     # outputs before sample 0
     ys = {0: fresh(0)}
     dev.chain_zp_step(fir, iir, x0, out=ys[0][:, :cs - shift], tail=junk)
+    # Few channels: a launch over ONE chunk has too few blocks per workgroup to hide what it
+    # pays once (tables, the pre-roll block of every run, the launch itself: 32 channels x 2^20
+    # run at 0.7 of the 256-channel rate).  Chunks of a resident source that lie one
+    # behind the other in memory -- the views an ArrayProducer cuts from one tensor -- therefore
+    # go through the kernel several at a time: `gmax` of them make one step of as many
+    # channel-samples as a 256-channel chunk; the results are handed on chunk by chunk as
+    # before (views of the step's output buffer).
+    gmax = _zp_group(C) if pipe is None else 1
+    group, emitted = [], 0                                    # [(k, 2-D view)]; chunks handed on so far
+
+    def run_group():
+        nonlocal emitted
+        a, g = group[0][0], len(group)
+        X = group[0][1]
+        for _, nxt in group[1:]:
+            X = _row_joined(X, nxt)
+        Y = ys[a] = fresh(a) if g == 1 else torch.empty((C, g * cs), dtype=torch.float64, device=device)
+        for i in range(g if g > 1 else 0):
+            ys[a + i] = Y[:, i * cs:(i + 1) * cs]
+        dev.chain_zp_step(fir, iir, X, out=Y[:, :g * cs - shift], tail=ys[a - 1][:, cs - shift:])
+        group.clear()
+        while emitted <= a + g - 3:                           # complete: the forward stream of chunk j + 1 is known
+            j = emitted
+            dev.chain_zp_seal(fir, iir, ys[j], lcut + j * cs, lcut, cs)
+            yield from emit(ys.pop(j))
+            emitted += 1
+
     k, x2d = 1, None
     for arr in chunks:
         if arr.shape[layout.axis] == 0:
@@ -626,13 +673,12 @@ def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, 
             raise RuntimeError(f"{what}: an inner chunk of the source is not chunksize = {cs} long")
         if k == nchunks - 2:
             break
-        ys[k] = fresh(k)
-        dev.chain_zp_step(fir, iir, x2d, out=ys[k][:, :cs - shift], tail=ys[k - 1][:, cs - shift:])
-        if k >= 2:
-            j = k - 2
-            dev.chain_zp_seal(fir, iir, ys[j], lcut + j * cs, lcut, cs)
-            yield from emit(ys.pop(j))
+        if group and (len(group) >= gmax or _row_joined(group[-1][1], x2d) is None):
+            yield from run_group()
+        group.append((k, x2d))
         k += 1
+    if group:
+        yield from run_group()
     if k != nchunks - 2 or x2d is None:
         raise RuntimeError(f"{what}: the source ended after {k} of {nchunks} chunks")
     # ---- the end: chunks n-2 and n-1 on the separate kernels.  The rest of output chunk

@@ -877,7 +877,7 @@ def test_long_stream_cfg3_direct(osz):
     pick = [0, 101, 255]
     got = []
     steps, plain = [], dev.chain_zp_step
-    dev.chain_zp_step = lambda *a, **k: (steps.append(1), plain(*a, **k))[1]
+    dev.chain_zp_step = lambda *a, **k: (steps.extend([1] * (a[2].shape[1] // cs)), plain(*a, **k))[1]
     try:
         for out in osz.sosfiltfilt(fir, sos, -1):
             assert out.is_cuda
@@ -1131,7 +1131,7 @@ def test_fir_then_sosfiltfilt_through_the_api_fused(osz):
         x = dev.synth_normal(C, total, seed=44)
         steps, plain_step, plain_zp = [], dev.chain_step, dev.chain_zp_step
         dev.chain_step = lambda *a, **k: (steps.append("step"), plain_step(*a, **k))[1]
-        dev.chain_zp_step = lambda *a, **k: (steps.append("zp"), plain_zp(*a, **k))[1]
+        dev.chain_zp_step = lambda *a, **k: (steps.extend(["zp"] * (a[2].shape[1] // cs)), plain_zp(*a, **k))[1]
         try:
             got = chain(x, taps, cs, -1)
         finally:

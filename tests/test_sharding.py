@@ -106,6 +106,10 @@ def test_bench_launcher_world2_dry():
     out = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry")
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 2
     assert out["scaling"] == "weak" and out["dry"] is True
+    # beside the weak line: the metric's own 256 channels split over the ranks (128 each, two
+    # chunks per launch), every rank's time gathered
+    assert out["strong"]["channels_per_gpu"] == 128 and out["strong"]["chunks_per_launch"] == 2
+    assert out["strong"]["ms_per_step_by_rank"] == [1.0, 2.0]
     out = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry",
                      "--workload", "welch")
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
