@@ -920,6 +920,29 @@ def filtfilt(pro, coeffs, axis):
 # ---------------------------------------------------------------------------
 # polyphase resampling (reference core/numerical.py:523-632)
 # ---------------------------------------------------------------------------
+def _resample_plan(pro, L, M, fs, fir, axis, kwargs):
+    """(chunksize, anti-aliasing taps) of a rational resampling of ``pro`` -- the rules of the
+    reference's preamble (core/numerical.py:566-587), which its outputs depend on:
+      * a decimation factor that is not smaller than the stream is refused (ValueError);
+      * at least three chunks: the chunksize is capped at a third of the stream's length, then
+        raised to the next multiple of M (every chunk decimates without a remainder);
+      * the interpolation / anti-aliasing filter is a low-pass at the tighter of the two Nyquist
+        rates, fs / (2 max(L, M)), with a transition band of a tenth of that on either side,
+        0.1 dB ripple and 40 dB attenuation unless ``fpass`` / ``fstop`` / ``gpass`` / ``gstop``
+        say otherwise (they are consumed from ``kwargs``)."""
+    nsamples = pro.shape[axis]
+    if M >= nsamples:
+        raise ValueError(f"cannot decimate by M = {M}: the data have only {nsamples} samples along "
+                         f"axis {axis} (M must be smaller)")
+    edge = fs / (2 * max(L, M))
+    band = {"fpass": kwargs.pop("fpass", edge - edge / 10), "fstop": kwargs.pop("fstop", edge + edge / 10)}
+    ripple = {"gpass": kwargs.pop("gpass", 0.1), "gstop": kwargs.pop("gstop", 40)}
+    taps = fir(band["fpass"], band["fstop"], fs, ripple["gpass"], ripple["gstop"]).coeffs
+    csize = min(pro.chunksize, nsamples // 3)
+    csize = -(-csize // M) * M if csize % M else csize
+    return max(int(csize), 1), taps
+
+
 @dev.chain_aware
 def polyphase_resample(pro, L, M, fs, fir, axis, **kwargs):
     """Rational L/M resampling of a producer (core/numerical.py:523-632) on
@@ -929,29 +952,13 @@ def polyphase_resample(pro, L, M, fs, fir, axis, **kwargs):
     neighbouring chunks, which reproduces
     ``scipy.signal.resample_poly(x, L, M, window=h)`` of the whole stream; the
     device kernel evaluates that definition directly and carries the input
-    history it needs.  Kept from the reference: the ``M >= N`` ValueError
-    (:569-571), the chunksize clamp to ``N // 3`` and rounding up to a
-    multiple of M (:574-587, applied to ``pro`` in place like
-    ``producer(pro, csize, axis)`` at :590), and the default Kaiser low-pass
-    (:579-583) built through ``fir``.
+    history it needs.  What the outputs depend on in the reference's preamble
+    is kept by ``_resample_plan`` (the refusal of M >= N, at least three chunks
+    of a multiple of M samples, the default low-pass); the new chunksize is
+    applied to ``pro`` in place, as ``producer(pro, csize, axis)`` does at :590.
     """
-    if M >= pro.shape[axis]:
-        msg = "Decimation factor must M={} be < pro.shape[{}] = {}"
-        raise ValueError(msg.format(M, axis, pro.shape[axis]))
-
-    csize = pro.chunksize
-    if csize > pro.shape[axis] // 3:
-        csize = pro.shape[axis] // 3
-
-    cutoff = fs / (2 * max(L, M))
-    fstop = kwargs.pop("fstop", cutoff + cutoff / 10)
-    fpass = kwargs.pop("fpass", cutoff - cutoff / 10)
-    gpass, gstop = kwargs.pop("gpass", 0.1), kwargs.pop("gstop", 40)
-    h = fir(fpass, fstop, fs, gpass, gstop).coeffs
-
-    if csize % M > 0:
-        csize = int(np.ceil(csize / M) * M)
-    pro = producer(pro, max(csize, 1), axis)
+    csize, h = _resample_plan(pro, L, M, fs, fir, axis, kwargs)
+    pro = producer(pro, csize, axis)
 
     layout = dev.Layout(pro.shape, axis)
     stream = dev.PolyStream(h, int(L), int(M), layout.nch)

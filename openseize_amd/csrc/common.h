@@ -127,7 +127,11 @@ __device__ __forceinline__ buf_d2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned l
 // bit 1 = `nt` -- they do not displace the spectrum in L2 / the Infinity Cache; with the same hint
 // on the rows' LDS-DMA requests the zero-phase chain runs 2 % faster, profiles/README.md round 5)
 __device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes) {
+#ifdef OSZ_NO_NT      // (A/B builds only)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_u2, v), r, lane_bytes, row_bytes, 0);
+#else
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_u2, v), r, lane_bytes, row_bytes, 2);
+#endif
 }
 
 // rccl.hip: in-place all-reduce(sum) of `count` float64 / int64 elements over

@@ -52,7 +52,11 @@ __device__ __forceinline__ void zp_request_rows(const double *src, int nrows, in
         asm volatile("s_mov_b32 %0, m0\n\t"
                      "s_mov_b32 m0, %1\n\t"
                      "s_nop 0\n\t"
+#ifdef OSZ_NO_NT      // (A/B builds only)
+                     "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+#else
                      "buffer_load_dwordx4 %2, %3, 0 offen nt lds\n\t"     // (read once: non-temporal)
+#endif
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "s"(ldsb + 4096u * m), "v"(voff + 4096u * m), "s"(rx)   // (the range check sees the lane offset)
