@@ -188,6 +188,14 @@ __device__ __forceinline__ void zpn_bwd_bursts(double *im, double *c7, const dou
 // osz_chain_forward): no left tail -- no backward bursts, no rows held back, no output lag, the
 // fit reads the right tail's amplitudes only (tables of spec::build_specn), the runs are cut
 // evenly (the NaN seal behind the launch finds their ends that way).
+// Diagnostic builds (benchmarks/zpn_variant.hip, never the library): OSZ_ABL_NOEPI / NOSTORE / NOH /
+// NODMA / NOLDS drop the fit and bursts / the row stores / the spectrum loads / the row requests /
+// the cube's LDS traffic (results then meaningless: OSZ_ABL_ANY also switches the NaN bookkeeping
+// off so that garbage does not take the slow paths); OSZ_CLK records the shader clock and the
+// 100 MHz clock over one workgroup's life (profiles/r05_zpn_ablation.txt).
+#ifdef OSZ_CLK
+__device__ unsigned long long g_zpn_clk[4];
+#endif
 template <int NB, int NM, int NS, int RM = kSpecRMax, bool ZP = true>
 __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     constexpr int D = 32 - NB, S = 256 * NB, NHI = NB - 16, NP = (NB + 1) / 2;
@@ -225,6 +233,11 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     const int lastf = p1 - 1;
     const bool closes = run == g.nruns - 1;
 
+#ifdef OSZ_CLK
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 7)
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0), "=s"(rt0)::"memory");
+#endif
     NegaWindow<NHI> P{a, cube_lds, tw2l};
     {
         fft::cube::TwPow w2;                               // (its sixteen rows go to LDS below)
@@ -237,7 +250,9 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     double cr[D];                    // the previous block's rows NB .. 31: this block's rows 0 .. D-1
 #pragma unroll
     for (int j = 0; j < D; ++j) cr[j] = 0.0;
+#ifndef OSZ_ABL_NODMA
     if (first <= lastf) zp_request_rows<NP>(xr + (int64_t)first * S, NB, t, cube_lds);
+#endif
     {
         // lrow | ptab | mtab are one table on the device too (g.Lrow)
         const int ntab = Rt * NM * 2 + 20 * NM * 2 + NMROWS * ns;
@@ -250,7 +265,11 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     for (int r = 0; r < RM; ++r) held[r] = 0.0;
     // `bad` is uniform (a scalar), and sticky: the stream went bad in an earlier chunk, or a block
     // of this run held non-finite samples -- behind the transform they are everywhere
+#ifdef OSZ_ABL_ANY
+    bool bad = false;
+#else
     bool bad = ZP ? g.nanpos[c] != 0x7fffffffffffffffLL : false;
+#endif
     int64_t bad_at = 0;
     int par = 0;
     int younger = -1;                // vector-memory operations behind the pending requests
@@ -310,19 +329,24 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
         int tt = t;
         asm volatile("" : "+v"(tt));
         const unsigned lane8 = 8u * (unsigned)tt;
+#ifndef OSZ_ABL_NOEPI
         if (tt < nh) fitbuf[tt] = im[15];
         else if (tt >= 256 - nh) fitbuf[tt - 256 + ns] = im[15];
+#endif
 #pragma unroll
         for (int j = 0; j < D; ++j) re[j] += cr[j];
         OSZ_BSTAMP(11);   // fit samples to LDS + overlap add
+#ifndef OSZ_ABL_NOEPI
         __syncthreads();
         OSZ_BSTAMP(12);   // barrier 5
         zpn_fit_kappa<NM, NS, RM, ZP>(tt, nh, Rt, fitbuf, mtab, lrow, kmu, knu, kapP + (par ^ 1) * (Rt * NS * 2));
         __syncthreads();
+#endif
         OSZ_BSTAMP(13);   // fit + barrier 6
         double c7[RM];
 #pragma unroll
         for (int r = 0; r < RM; ++r) c7[r] = 0.0;
+#ifndef OSZ_ABL_NOEPI
         {
             double Pr[NS], Pi[NS];
             zpn_powers<NM, NS>(ptab, 0, tt, Pr, Pi);
@@ -351,11 +375,14 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
             }
             // non-finite samples are everywhere behind the transform: every amplitude of the fit
             // and with it every lane's burst values (looked at once, behind both halves)
+#ifndef OSZ_ABL_ANY
             if (!bad && __builtin_amdgcn_readfirstlane((int)sos_not_finite(ca))) {
                 bad = true;
                 bad_at = o;
             }
+#endif
         }
+#endif
         OSZ_BSTAMP(14);   // bursts
         const double qn = spec_qnan();
         const bool own = p >= p0;                      // (a run's first block may be its neighbour's)
@@ -365,11 +392,13 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
             // previous chunk's last L samples, complete with this block's +nu
             nst = -1;
             const double *ci = g.carry_in + (int64_t)c * kSpecLdc + tt;
+#ifndef OSZ_ABL_ANY
             if (!bad &&
                 __builtin_amdgcn_readfirstlane((int)sos_not_finite(g.carry_in[(int64_t)c * kSpecLdc + 4095 + 256 * R]))) {
                 bad = true;
                 bad_at = 0;
             }
+#endif
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 re[j] += ci[256 * j];
@@ -391,7 +420,11 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 const __amdgpu_buffer_rsrc_t ry = buf_rsrc(yr + (o - S + L));
 #pragma unroll
                 for (int r = 0; r < RM; ++r)
+#ifdef OSZ_ABL_NOSTORE
+                    if (r < R && held[r] + c7[r] == 1.2345e300) buf_store(held[r] + c7[r], ry, lane8, 2048u * (NB - 1 - r));
+#else
                     if (r < R) buf_store(held[r] + c7[r], ry, lane8, 2048u * (NB - 1 - r));
+#endif
                 if (nst >= 0) nst += R;
             } else {
                 nst = -1;
@@ -433,11 +466,21 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 if (!bad && !edge && o + L >= n0) {
                     // the common case: whole rows into the current output
                     const __amdgpu_buffer_rsrc_t ry = buf_rsrc(yr + (o + L));
+#ifdef OSZ_ABL_NOSTORE     // (the values stay live through a store that never happens)
+                    double acc_ = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        acc_ += re[j];
+                        if (j < NHI - R) acc_ += im[j];
+                    }
+                    if (acc_ == 1.2345e300) buf_store(acc_, ry, lane8, 0);
+#else
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         buf_store(re[j], ry, lane8, 2048u * j);
                         if (j < NHI - R) buf_store(im[j], ry, lane8, 2048u * (j + 16));
                     }
+#endif
                     if (nst >= 0) nst += NB - R;
                 } else {
                     nst = -1;
@@ -472,6 +515,16 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     }
 #endif
     if (closes) block(lastf + 1, std::true_type{});
+#ifdef OSZ_CLK
+    if (blockIdx.x == 0 && blockIdx.y == 7) {
+        unsigned long long clk1, rt1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1), "=s"(rt1)::"memory");
+        if (threadIdx.x == 0) {
+            g_zpn_clk[0] = clk1 - clk0;
+            g_zpn_clk[1] = rt1 - rt0;
+        }
+    }
+#endif
 #undef OSZ_ZP_PUT
     // where the forward stream of this channel first went bad (chain_zp.hip: later launches start
     // bad, osz_chain_zp_seal settles the chunks the reference loses)

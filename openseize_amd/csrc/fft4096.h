@@ -307,6 +307,16 @@ OSZ_HD void i1(int t, double *re, double *im, const TwPow &w1, const C2 *L) {
 // with views A (l = n0, m = n1 | k0 = 0..15), B (k0, l = n0 | m = n1, k1), C (k0, m = k1 | l = n0,
 // k2): lanes walk l in A and B (16 consecutive slots), m in C (l ^ m distinct): conflict free for
 // the b128 lane groups (tests/host/fft_host_check.cpp).
+// (diagnostic builds of benchmarks/zpn_variant.hip only: OSZ_ABL_NOLDS drops the cube's loads and
+// stores -- what the LDS exchanges cost a kernel, its results then meaningless)
+#ifdef OSZ_ABL_NOLDS
+#define OSZ_LDS_ST(slot_, r_, i_) do { } while (0)
+#define OSZ_LDS_LD(slot_, r_, i_) do { } while (0)
+#else
+#define OSZ_LDS_ST(slot_, r_, i_) slot_ = C2{r_, i_}
+#define OSZ_LDS_LD(slot_, r_, i_) do { const C2 v_ = slot_; r_ = v_.re; i_ = v_.im; } while (0)
+#endif
+
 namespace cube2 {
 
 using cube::C2;
@@ -337,28 +347,24 @@ OSZ_HD void f1(int t, double *re, double *im, const TwPow &w1, C2 *L) {
     fwd16(re, im);
     tw_mul<false>(re, im, w1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) L[slot_a(t, dr(r))] = C2{re[r], im[r]};
+    for (int r = 0; r < 16; ++r) OSZ_LDS_ST(L[slot_a(t, dr(r))], re[r], im[r]);
 }
 
 OSZ_HD void f2(int t, double *re, double *im, const TwPow &w2, C2 *L) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const C2 v = L[slot_b(t, j)];
-        re[j] = v.re;
-        im[j] = v.im;
+        OSZ_LDS_LD(L[slot_b(t, j)], re[j], im[j]);
     }
     fwd16(re, im);
     tw_mul<false>(re, im, w2);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) L[slot_b(t, dr(r))] = C2{re[r], im[r]};
+    for (int r = 0; r < 16; ++r) OSZ_LDS_ST(L[slot_b(t, dr(r))], re[r], im[r]);
 }
 
 OSZ_HD void f3(int t, double *re, double *im, const C2 *L) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const C2 v = L[slot_c(t, j)];
-        re[j] = v.re;
-        im[j] = v.im;
+        OSZ_LDS_LD(L[slot_c(t, j)], re[j], im[j]);
     }
     fwd16(re, im);
 }
@@ -366,28 +372,24 @@ OSZ_HD void f3(int t, double *re, double *im, const C2 *L) {
 OSZ_HD void i3(int t, double *re, double *im, C2 *L) {
     inv16(re, im);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) L[slot_c(t, j)] = C2{re[j], im[j]};
+    for (int j = 0; j < 16; ++j) OSZ_LDS_ST(L[slot_c(t, j)], re[j], im[j]);
 }
 
 OSZ_HD void i2(int t, double *re, double *im, const TwPow &w2, C2 *L) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const C2 v = L[slot_b(t, dr(r))];
-        re[r] = v.re;
-        im[r] = v.im;
+        OSZ_LDS_LD(L[slot_b(t, dr(r))], re[r], im[r]);
     }
     tw_mul<true>(re, im, w2);
     inv16(re, im);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) L[slot_b(t, j)] = C2{re[j], im[j]};
+    for (int j = 0; j < 16; ++j) OSZ_LDS_ST(L[slot_b(t, j)], re[j], im[j]);
 }
 
 OSZ_HD void i1(int t, double *re, double *im, const TwPow &w1, const C2 *L) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const C2 v = L[slot_a(t, dr(r))];
-        re[r] = v.re;
-        im[r] = v.im;
+        OSZ_LDS_LD(L[slot_a(t, dr(r))], re[r], im[r]);
     }
     tw_mul<true>(re, im, w1);
     inv16(re, im);
@@ -533,7 +535,7 @@ OSZ_HD void f1(int t, double *re, double *im, const TwPowN &w1, C2 *L) {
     fwd16(re, im);
     tw_mul<false>(re, im, w1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) L[cube2::slot_a(t, dr(r))] = C2{re[r], im[r]};
+    for (int r = 0; r < 16; ++r) OSZ_LDS_ST(L[cube2::slot_a(t, dr(r))], re[r], im[r]);
 }
 
 // (in two halves: once the loads have returned the thread's slots of the cube are free -- the
@@ -541,9 +543,7 @@ OSZ_HD void f1(int t, double *re, double *im, const TwPowN &w1, C2 *L) {
 OSZ_HD void i1_load(int t, double *re, double *im, const C2 *L) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const C2 v = L[cube2::slot_a(t, dr(r))];
-        re[r] = v.re;
-        im[r] = v.im;
+        OSZ_LDS_LD(L[cube2::slot_a(t, dr(r))], re[r], im[r]);
     }
 }
 

@@ -115,12 +115,22 @@ struct NegaWindow {
         double hr[16], hi[16];
         const unsigned lane16 = 16u * ((unsigned)t & 255u);
         const __amdgpu_buffer_rsrc_t rh = buf_rsrc(a.H);
+#ifdef OSZ_ABL_NOH      // (diagnostic builds: no spectrum loads)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            hr[r] = 1.0 / 4096 + 1e-9 * r;
+            hi[r] = 1e-7 * (double)(t & 3);
+        }
+        (void)rh;
+        (void)lane16;
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const buf_d2 h = buf_load2(rh, lane16, 4096u * r);
             hr[r] = h.x;
             hi[r] = h.y;
         }
+#endif
         OSZ_WSTAMP(3);    // pass 2 + spectrum requests
         wave_lds_fence();
         fft::cube2::f3(t, re, im, L);
@@ -137,10 +147,12 @@ struct NegaWindow {
         __syncthreads();
         OSZ_WSTAMP(8);    // barrier 4
         fft::nega::i1_load(t, re, im, L);
+#ifndef OSZ_ABL_NODMA   // (diagnostic builds: no row requests)
         if (next) {
             asm volatile("s_waitcnt lgkmcnt(0) ; osz:dma" ::: "memory");
             zp_request_rows<NP>(next, nrows, t_in, L);
         }
+#endif
         OSZ_WSTAMP(9);    // inverse pass 1's loads + the next block's requests
         fft::nega::i1_finish(re, im, tw1);
         OSZ_WSTAMP(10);   // inverse pass 1 + unpack
