@@ -235,8 +235,9 @@ int osz_chain_wait(osz_sos_t sos, void *stream);
  *
  *   osz_chain_zp_lag        samples of delay (a multiple of 256), or -1 when the pair
  *                           of filters does not take this kernel (poles that repeat,
- *                           ringing longer than the transform's guard rows, FIR longer
- *                           than 1793 taps or partitioned)
+ *                           ringing longer than the transform's guard rows -- twelve rows
+ *                           of 256 samples at most --, a partitioned FIR, i.e. one of more
+ *                           than 2049 taps)
  *   osz_chain_zp_tolerance  where the bursts are cut, relative to the norm of the composite
  *                           impulse response (0: the default, 1e-15; before osz_chain_zp_lag /
  *                           _open; also the cut of osz_chain_forward's spectral kernels for

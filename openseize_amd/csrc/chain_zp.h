@@ -72,7 +72,7 @@ __device__ __forceinline__ double zp_dot(const double *kk, const double *pr, con
     return c;
 }
 
-// chain_zpn_*.hip: the kernel for NB rows per block (24 .. 30), NM modes (2, 4, 6, 8) of which the
+// chain_zpn_*.hip: the kernel for NB rows per block (20 .. 30), NM modes (2, 4, 6, 8) of which the
 // first NS (2, 4, 6) are slow
 using zp_kern_t = void (*)(ZpArgs);
 zp_kern_t zpn_kernel_for(int nb, int nm, int ns, int r);

@@ -199,7 +199,7 @@ __device__ unsigned long long g_zpn_clk[4];
 template <int NB, int NM, int NS, int RM = kSpecRMax, bool ZP = true>
 __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     constexpr int D = 32 - NB, S = 256 * NB, NHI = NB - 16, NP = (NB + 1) / 2;
-    static_assert(NB >= 24 && NB <= 30, "rows per block");
+    static_assert(NB >= 20 && NB <= 30, "rows per block");
     extern __shared__ fft::cube::C2 cube_lds[];
     const int Rt = g.R;                                // rows of the amplitude tables
     const int R = ZP ? g.R : 0;                        // rows of the left tail, and of the lag
@@ -371,7 +371,11 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                 case 5: zpn_bwd_bursts<NM, NS, 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
                 case 6: zpn_bwd_bursts<NM, NS, RM >= 6 ? 6 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
                 case 7: zpn_bwd_bursts<NM, NS, RM >= 7 ? 7 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
-                default: zpn_bwd_bursts<NM, NS, RM >= 8 ? 8 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                case 8: zpn_bwd_bursts<NM, NS, RM >= 8 ? 8 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                case 9: zpn_bwd_bursts<NM, NS, RM >= 9 ? 9 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                case 10: zpn_bwd_bursts<NM, NS, RM >= 10 ? 10 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                case 11: zpn_bwd_bursts<NM, NS, RM >= 11 ? 11 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
+                default: zpn_bwd_bursts<NM, NS, RM >= 12 ? 12 : 5>(im, c7, knu, ptab, 255 - tt, Qr, Qi); break;
             }
             // non-finite samples are everywhere behind the transform: every amplitude of the fit
             // and with it every lane's burst values (looked at once, behind both halves)
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
 #else
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        buf_store(re[j], ry, lane8, 2048u * j);
+                        if (RM <= NHI || j < NB - R) buf_store(re[j], ry, lane8, 2048u * j);   // (R <= RM <= NHI: every lower row)
                         if (j < NHI - R) buf_store(im[j], ry, lane8, 2048u * (j + 16));
                     }
 #endif
@@ -488,14 +492,16 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
                     asm volatile("" : "+v"(off));
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        OSZ_ZP_PUT(off + 256 * j, bad ? qn : re[j]);
+                        if (RM <= NHI || j < NB - R) OSZ_ZP_PUT(off + 256 * j, bad ? qn : re[j]);
                         if (j < NHI - R) OSZ_ZP_PUT(off + 256 * (j + 16), bad ? qn : im[j]);
                     }
                 }
             }
+            // (row NB - 1 - r: in the window's upper half as long as r < NHI, below it for the long
+            // left tails of blocks of 20 ... 23 rows)
 #pragma unroll
             for (int r = 0; r < RM; ++r)
-                if (r < R) held[r] = im[(NHI - 1 - r) & 15];
+                if (r < R) held[r] = r < NHI ? im[(NHI - 1 - r) & 15] : re[(NB - 1 - r) & 15];
 #pragma unroll
             for (int j = 0; j < D; ++j) cr[j] = im[NHI + j];
         }
@@ -541,9 +547,12 @@ static zp_kern_t zpn_kernel_nb(int nb, int r) {
                                    chain_zpn_kernel<26, NM, NS>, chain_zpn_kernel<27, NM, NS>,
                                    chain_zpn_kernel<28, NM, NS>, chain_zpn_kernel<29, NM, NS>,
                                    chain_zpn_kernel<30, NM, NS>};
-    // more than five burst rows: blocks of 24 ... 26 rows (R <= 32 - NB)
+    // more than five burst rows: blocks of 24 ... 26 rows (R <= 32 - NB); more than eight: 20 ... 23
     static const zp_kern_t k8[3] = {chain_zpn_kernel<24, NM, NS, 8>, chain_zpn_kernel<25, NM, NS, 8>,
                                     chain_zpn_kernel<26, NM, NS, 8>};
+    static const zp_kern_t k12[4] = {chain_zpn_kernel<20, NM, NS, 12>, chain_zpn_kernel<21, NM, NS, 12>,
+                                     chain_zpn_kernel<22, NM, NS, 12>, chain_zpn_kernel<23, NM, NS, 12>};
+    if (nb < 24) return r <= 12 ? k12[nb - 20] : nullptr;
     if (r > kSpecRMax) return nb <= 26 && r <= 8 ? k8[nb - 24] : nullptr;
     return k[nb - 24];
 }
@@ -553,7 +562,7 @@ static zp_kern_t zpn_kernel_nb(int nb, int r) {
 // zpn_kernel_nm2 / 4 / 6 / 8 (nb, ns, r)
 zp_kern_t OSZ_ZPN_CAT(zpn_kernel_nm, OSZ_ZPN_NM)(int nb, int ns, int r) {
     constexpr int NM = OSZ_ZPN_NM;
-    if (nb < 24 || nb > 30) return nullptr;
+    if (nb < 20 || nb > 30) return nullptr;
     if (ns == 2) return zpn_kernel_nb<NM, 2>(nb, r);
     if (NM >= 4 && ns == 4) return zpn_kernel_nb<NM, (NM >= 4 ? 4 : 2)>(nb, r);
     if (NM >= 6 && ns == 6) return zpn_kernel_nb<NM, (NM >= 6 ? 6 : 2)>(nb, r);

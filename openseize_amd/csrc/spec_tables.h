@@ -32,7 +32,7 @@ typedef long double ld_t;
 
 constexpr int kFit = 64;      // samples of row 15 the fit reads (one wave)
 constexpr int kRMax = 5;      // burst rows supported (the pair kernels)
-constexpr int kRMaxN = 8;     // ... by the one-block kernel (chain_zpn_body.h: its instances hold 5 or 8 rows)
+constexpr int kRMaxN = 12;    // ... by the one-block kernel (chain_zpn_body.h: its instances hold 5, 8 or 12 rows)
 // Where a burst is cut off, relative to the norm of the composite impulse response.  What is cut
 // is an error proportional to the INPUT's magnitude (a block's ringing is driven by everything in
 // it, offsets included, and only cancels between neighbouring blocks as far as both were kept):
@@ -522,9 +522,10 @@ inline TablesZp build_zp(const double *taps, int wlen, const double *sos, int ns
 //         bursts run over NS modes -- all NM only in the left tail's first row.  (The FIT still
 //         has every mode in its basis: the fast ones are alive in row 31's first samples.)
 //         NM is 2, 4, 6 or 8, NS 2, 4 or 6.
-//   R     up to kRMaxN = 8 rows (a left tail of 2048 samples) where the guard rows hold them:
-//         R <= D = 32 - NB, i.e. blocks of 24 rows for R = 8 -- the cascade alone (the identity
-//         as the FIR: nothing but the guard row in front of the left tail) needs them first.
+//   R     up to kRMaxN = 12 rows (a left tail of 3072 samples) where the guard rows hold them:
+//         R <= D = 32 - NB, i.e. blocks of 24 rows for R = 8, of 20 for R = 12 -- the cascade alone
+//         (the identity as the FIR: nothing but the guard row in front of the left tail) needs
+//         them first, the more so at the default cut of 1e-15.
 inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int nsec, bool forgets,
                           int lds_budget = 15360, ld_t tail_tol = kTailTol, ld_t fit_floor = 3e-7L,
                           int rmax = kRMaxN) {
@@ -581,7 +582,7 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
     int NBmax = (7937 - wlen) / 256;
     if (NBmax > 30) NBmax = 30;
     int NB = 0, R = 0, Rf = 0;
-    for (int cand = NBmax; cand >= 24 && !NB; --cand) {
+    for (int cand = NBmax; cand >= 20 && !NB; --cand) {
         const int S = 256 * cand, D = 32 - cand;
         int rb = 0, rf = 0;
         for (int r = 1; r <= rmax && !(rb && rf); ++r) {
@@ -590,7 +591,9 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
             if (!rf && sqrtl(right2[ir]) <= tail_tol * tot) rf = r;
             if (!rb && sqrtl(left2[il]) <= tail_tol * tot) rb = r;
         }
-        if (rb && rf && rf <= rb && rf <= kRMax && rb <= D && D + rf <= cand) {   // (the right tail: five rows at most)
+        // (the right tail: five rows at most, and its second landing place, rows D .. D + rf - 1,
+        // inside the window's lower half, which the kernel's forward bursts address)
+        if (rb && rf && rf <= rb && rf <= kRMax && rb <= D && D + rf <= cand && D + rf <= 16) {
             NB = cand;
             R = rb;
             Rf = rf;

@@ -118,7 +118,7 @@ def test_zero_phase_stream_against_scipy(dev, case, split):
 
 def test_what_the_kernel_refuses(dev):
     """Pairs of filters outside the scheme report -1 (and the public generators then take
-    the two-kernel step): a FIR too long for row 15 to stay free, a cascade that hardly
+    the two-kernel step): a FIR long enough to be partitioned, a cascade that hardly
     forgets, poles that repeat."""
     def lag(taps_n, sos):
         fir, iir = dev.FirStream(sps.firwin(taps_n, 0.2), 2), dev.SosStream(sos, 2)
@@ -128,7 +128,8 @@ def test_what_the_kernel_refuses(dev):
             fir.close()
             iir.close()
     assert lag(1024, BP) == 768          # three rows of left tail at the default cut (1e-15)
-    assert lag(1900, BP) == -1
+    assert lag(1900, BP) == 768         # (blocks of 23 rows since round 5; rounds 3-4 refused above 1793 taps)
+    assert lag(3000, BP) == -1          # a partitioned FIR
     assert lag(256, sps.butter(4, [0.0002, 0.0016], "bandpass", output="sos")) == -1
     assert lag(256, np.vstack([sps.butter(2, 0.2, output="sos")] * 2)) == -1
 
@@ -230,6 +231,11 @@ def test_plain_sosfiltfilt_takes_the_zero_phase_kernel(dev, fed):
                                         (sps.cheby1(6, 0.5, 0.2, output="sos"), 3, 100001, 100001 * 6 + 17, -1, True),
                                         # a left tail of six rows: blocks of 26, the eight-row instance
                                         (sps.butter(6, [0.05, 0.2], "bandpass", output="sos"), 4, 131072,
+                                         131072 * 6 + 77, -1, True),
+                                        # a left tail of nine rows (the alpha / beta band-pass of SURVEY 8d at the
+                                        # default cut): blocks of 23, the twelve-row instance, held rows in both
+                                        # halves of the window
+                                        (sps.butter(6, [8 / 250, 30 / 250], "bandpass", output="sos"), 4, 131072,
                                          131072 * 6 + 77, -1, True),
                                         (narrow, 4, 131072, 131072 * 6 + 5, -1, False),
                                         (BP, 4, 131072, 131072 * 5, -1, False)):
