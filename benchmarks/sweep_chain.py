@@ -10,7 +10,8 @@ tutorials run 4 channels.  One JSON line per (workload, channels):
          2^20 samples per launch, as numerical.sosfiltfilt steps a resident stream of C channels (round 5:
          `chunks_per_launch`); `chain_1` is the same with every chunk its own launch (rounds 3-4)
   fir    FIR(1024) overlap-add alone (osz_fir_push)
-  welch  Welch PSD nperseg 4096, 50 % overlap, segment average (osz_spec_push)
+  welch  Welch PSD nperseg 4096, 50 % overlap, segment average (osz_spec_push), pushes of 2^28 / C samples per
+         channel as psd() makes them of a resident array (round 5; rounds 3-4: 2^20)
   sosfiltfilt  the 6-section cascade alone, zero phase: one osz_chain_zp_step per chunk with the
          identity as its FIR (what numerical.sosfiltfilt runs on long streams; `dual_ms`: the
          separate kernels' osz_sosfiltfilt_step on the same box)
@@ -117,12 +118,14 @@ def welch(C, steps=24, warm=6):
     from openseize_amd import _device as dev
     from openseize_amd import _lib
     win = sps.get_window("hann", 4096)
-    ring = [dev.synth_normal(C, CHUNK, seed=0, n0=k * CHUNK) for k in range(3)]
+    # what psd() pushes of a resident array: views of up to 2^28 elements (numerical._batched)
+    g = max(1, min(1 << 24, (1 << 28) // C) // CHUNK)
+    ring = [dev.synth_normal(C, g * CHUNK, seed=0, n0=k * g * CHUNK) for k in range(3)]
     spec = dev.SpecStream(4096, 4096, 2048, win, 1.0 / (4096.0 * float((win ** 2).sum())), "constant",
                           _lib.SPEC_PSD_MEAN, C)
-    dt = timed(lambda k: spec.push(ring[k % 3]), steps, warm)
+    dt = timed(lambda k: spec.push(ring[k % 3]), steps, warm) / g
     spec.close()
-    return dt, 8
+    return dt, 8, {"chunks_per_launch": g}
 
 
 if __name__ == "__main__":

@@ -1076,7 +1076,12 @@ def _batched(pro, axis, nch):
     stream is cut, so the cuts are moved, not the result."""
     target = max(1, min(1 << 20, (1 << 25) // max(int(nch), 1)))
     if isinstance(pro, ArrayProducer):
-        # an in-memory array: larger views of it, no copies
+        # an in-memory array: larger views of it, no copies -- and of a RESIDENT array views of up
+        # to 2^28 elements (the size of the headline's 256 x 2^20 chunk), whatever the channel
+        # count: a launch over 2^25 elements of 32 channels is too short to hide what it pays once
+        # (cfg-4's 8-GPU shard ran at 0.84 of the 256-channel rate, DESIGN 5)
+        if dev.is_tensor(pro.data) and pro.data.is_cuda:
+            target = max(1, min(1 << 24, (1 << 28) // max(int(nch), 1)))
         n = pro.data.shape[axis]
         for start in range(0, n, target):
             yield slice_along_axis(pro.data, start, min(start + target, n), axis=axis)

@@ -190,9 +190,17 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
     extern __shared__ C2 cube_lds[];
     C2 *L = cube_lds;
     __shared__ double red[4][4];
+    // pass 2's twiddles W256^(n0 k1), k1 = 1 .. 15, as a table [k1 - 1][n0] behind the cube: fifteen
+    // products per pair where the power scheme (W^b, then (W^4)^a) takes twenty-six, and no
+    // resident powers of that base (16 registers)
+    C2 *tw2t = cube_lds + fft::cube::SLOTS;
     const int t = threadIdx.x;
     const int run = blockIdx.x;
     const int c = blockIdx.y;
+    if (t < 240) {
+        const int k1 = 1 + (t >> 4), n0 = t & 15;
+        tw2t[t] = C2{a.tb.t2[(n0 * 16 + k1) * 2], a.tb.t2[(n0 * 16 + k1) * 2 + 1]};
+    }
     const double *cr = a.carry + (int64_t)c * a.ncap;
     const double *xr = a.x + (int64_t)c * a.ldx;
     const int64_t npairs = (a.nseg + 1) / 2;
@@ -201,8 +209,11 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
     const double mid = 0.5 * (fft::N - 1);
     const double s2 = a.scale * a.scale;
 
-    fft::cube::TwPow tw1, tw2;
-    fft::cube::tw_load(t, a.tb, tw1, tw2);
+    fft::cube::TwPow tw1;
+    {
+        fft::cube::TwPow tw2;
+        fft::cube::tw_load(t, a.tb, tw1, tw2);
+    }
     double win[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) win[j] = a.window[256 * j + t];
@@ -216,6 +227,8 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
     for (int j = 0; j < 16; ++j) acc[j] = 0.0;
     double keep[HALF ? 8 : 1];
     bool have_keep = false;
+    double half_sum = 0.0;          // this thread's sum over the half the next pair begins with
+    bool have_sum = false;
     // mean mode at 50 % overlap: the next pair's sixteen new rows are requested by LDS-DMA into
     // this wave's own pieces of the cube (nega_window.h: zp_request_rows) as soon as pass 3 has
     // read them -- view C and view A of fft::cube are the same 1 KB piece per plane and wave --
@@ -284,14 +297,35 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
         }
         // ---- trend: block sums
         double sum_a = 0.0, sum_b = 0.0, lin_a = 0.0, lin_b = 0.0;
+        if (HALF && !LINEAR) {
+            // at 50 % overlap a segment is two halves, and every half belongs to two segments: a
+            // thread sums each half ONCE (the first half of segment a was the second half of the
+            // previous pair's segment b)
+            double s0 = half_sum, s1 = 0.0, s2 = 0.0;
+            if (!have_sum) {
+                s0 = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int i = 256 * j + t;
-            sum_a += re[j];
-            sum_b += im[j];
-            if (LINEAR) {
-                lin_a += (i - mid) * re[j];
-                lin_b += (i - mid) * im[j];
+                for (int j = 0; j < 8; ++j) s0 += re[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s1 += re[8 + j];
+                s2 += im[8 + j];
+            }
+            sum_a = s0 + s1;
+            sum_b = has_b ? s1 + s2 : 0.0;
+            half_sum = s2;
+            have_sum = has_b;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = 256 * j + t;
+                sum_a += re[j];
+                sum_b += im[j];
+                if (LINEAR) {
+                    lin_a += (i - mid) * re[j];
+                    lin_b += (i - mid) * im[j];
+                }
             }
         }
         sum_a = wave_sum63(sum_a);
@@ -320,18 +354,41 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
             const int i = 256 * j + t;
             if (LINEAR) {
                 re[j] = (re[j] - mean_a - slope_a * (i - mid)) * win[j];
-                im[j] = has_b ? (im[j] - mean_b - slope_b * (i - mid)) * win[j] : 0.0;
+                im[j] = (im[j] - mean_b - slope_b * (i - mid)) * win[j];
             } else {
                 re[j] = (re[j] - mean_a) * win[j];
-                im[j] = has_b ? (im[j] - mean_b) * win[j] : 0.0;
+                im[j] = (im[j] - mean_b) * win[j];
             }
+        }
+        if (!has_b) {       // (a run's last, odd segment: a scalar branch, not sixteen selects per pair)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) im[j] = 0.0;
         }
         // ---- forward transform of a + i b
         int tt = t;   // opaque copy: keeps the LDS slot numbers out of loop-invariant registers
         asm volatile("" : "+v"(tt));
         fft::cube::f1(tt, re, im, tw1, L);
         __syncthreads();
-        fft::cube::f2(tt, re, im, tw2, L);
+        {
+            // pass 2 (fft::cube::f2) with its twiddles from the table
+            const int base = fft::cube::base_b(tt);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const C2 v = L[base + 16 * j];
+                re[j] = v.re;
+                im[j] = v.im;
+            }
+            fft::fwd16(re, im);
+            const C2 *twp = tw2t + (tt >> 4);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) {
+                const int k1 = fft::dr(r);          // (register 0 holds k1 = 0)
+                const C2 w = twp[16 * (k1 - 1)];
+                fft::cube::cmul(re[r], im[r], w.re, w.im);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) L[base + 16 * fft::dr(r)] = C2{re[r], im[r]};
+        }
         __syncthreads();
         if (MODE == OSZ_SPEC_PSD_MEAN && HALF) {
             // pass 3 with the request between its loads and its butterflies
@@ -1628,7 +1685,7 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
              {spec_cube_kernel<1, true, false>, spec_cube_kernel<1, true, true>}},
             {{spec_cube_kernel<2, false, false>, spec_cube_kernel<2, false, true>},
              {spec_cube_kernel<2, true, false>, spec_cube_kernel<2, true, true>}}};
-        const size_t clds = sizeof(fft::cube::C2) * fft::cube::SLOTS;
+        const size_t clds = sizeof(fft::cube::C2) * (fft::cube::SLOTS + 240);     // the cube + pass 2's twiddle table
         const kern_t ckern = ck[h->mode][h->detrend == OSZ_DETREND_LINEAR ? 1 : 0]
                                [h->stride == 2048 ? 1 : 0];
         OSZ_DYN_LDS(ckern, clds);
