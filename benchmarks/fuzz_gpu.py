@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 13
+        kind = it % 14
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -171,7 +171,7 @@ def main():
                 taps = int(rng.choice([2, 64, 301, 512, 1024, 1025, 2049]))
                 C = int(rng.integers(1, 6))
                 cs = int(rng.integers(65536, 140000))
-                nch_ = int(rng.integers(5, 9))
+                nch_ = int(rng.integers(5, 9)) if rng.random() < 0.5 else int(rng.integers(9, 26))   # (long: grouped steps)
                 total = cs * (nch_ - 1) + int(rng.integers(1, cs + 1))
                 h = rng.standard_normal(taps) / np.sqrt(taps)
                 sos = designs[int(rng.integers(0, len(designs)))]
@@ -188,6 +188,21 @@ def main():
                 finally:
                     del os.environ["OSZ_CHAIN_API"]
                 e, what = rel(got_, ref_) * 100, f"api chain taps={taps} C={C} cs={cs} total={total}"
+            elif kind == 13:   # plain sosfiltfilt of a long resident stream, any layout: grouped zero-phase steps
+                ndim = int(rng.integers(1, 4))
+                axis = int(rng.integers(0, ndim))
+                cs = int(rng.integers(65536, 90000))
+                nch_ = int(rng.integers(6, 22))
+                total = cs * (nch_ - 1) + int(rng.integers(1, cs + 1))
+                shape = [int(rng.integers(1, 3)) for _ in range(ndim)]
+                shape[axis] = total
+                sos = designs[int(rng.integers(0, len(designs)))]
+                xh = rng.standard_normal(shape)
+                xdev = torch.from_numpy(xh).cuda()
+                got_ = torch.cat(list(nm.sosfiltfilt(producer(xdev, cs, axis), sos, axis)), axis).cpu().numpy()
+                x2 = np.moveaxis(xh, axis, -1)
+                ref_ = orc.sosfiltfilt(x2.reshape(-1, total), sos, cs).reshape(x2.shape)
+                e, what = rel(np.moveaxis(got_, axis, -1), ref_), f"long sosfiltfilt shape={tuple(shape)} axis={axis} cs={cs}"
             elif kind == 12:   # FIR producer -> sosfilt through the API: one launch per chunk vs SciPy
                 from functools import partial
                 taps = int(rng.choice([2, 64, 301, 512, 1024, 1025, 2049]))

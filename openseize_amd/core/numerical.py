@@ -571,12 +571,17 @@ def _zp_group(nch):
 def _row_joined(a, b):
     """The (C, na + nb) view of two 2-D device views of ONE storage whose rows continue each
     other (b's row r starts where a's row r ends), or None."""
-    if (a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0] or a.stride() != b.stride() or a.stride(1) != 1
+    if (a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0] or a.stride(1) != 1 or b.stride(1) != 1
             or a.dtype != b.dtype or a.device != b.device
             or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
             or b.storage_offset() != a.storage_offset() + a.shape[1]):
         return None
-    return a.as_strided((a.shape[0], a.shape[1] + b.shape[1]), a.stride(), a.storage_offset())
+    n = a.shape[1] + b.shape[1]
+    if a.shape[0] == 1:                    # (a single row: its pitch is whatever a view says -- make it the length)
+        return a.as_strided((1, n), (n, 1), a.storage_offset())
+    if a.stride(0) != b.stride(0) or a.stride(0) < n:
+        return None                        # rows of different arrays, or rows that would run into each other
+    return a.as_strided((a.shape[0], n), a.stride(), a.storage_offset())
 
 
 def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, total, lcut, rcut, lag, device,

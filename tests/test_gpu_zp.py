@@ -441,6 +441,18 @@ def test_few_channels_take_several_chunks_per_launch(dev):
         u = np.concatenate(orc.oaconvolve(xh, taps, "same"), -1) if after_fir else xh
         want = orc.sosfiltfilt(u, BP, cs)
         assert np.max(np.abs(y[pick].cpu().numpy() - want)) < RTOL * np.max(np.abs(want))
+    # a single channel as a 1-D array (its chunk views carry a row pitch of their own length: the
+    # joined view must not inherit it -- found by benchmarks/fuzz_gpu.py)
+    x1 = x[3, :cs * 9 + 99].contiguous()
+    sizes, plain = [], dev.chain_zp_step
+    dev.chain_zp_step = lambda *a, **k: (sizes.append(a[2].shape[1] // cs), plain(*a, **k))[1]
+    try:
+        y1 = torch.cat(list(nm.sosfiltfilt(producer(x1, cs, 0), BP, 0)), 0).cpu().numpy()
+    finally:
+        dev.chain_zp_step = plain
+    assert sizes == [1, 7], sizes
+    want1 = orc.sosfiltfilt(x1.cpu().numpy()[None], BP, cs)[0]
+    assert np.max(np.abs(y1 - want1)) < RTOL * np.max(np.abs(want1))
     # host data: every chunk through the staging ring, one launch each
     _, sizes = run(x.cpu().numpy()[:, :cs * 7], True)
     assert sizes == [1] * 5, sizes
