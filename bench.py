@@ -511,15 +511,17 @@ def run_chain(args, R, h, sos):
         fir.close()
         iir.close()
         extra["full_stream"] = full_stream_leg(R, ring, h, sos)
-    if zp and R.world > 1 and args.scaling == "weak":
+    # (OSZ_BENCH_STRONG=1: the leg also at one rank -- how its code is exercised on a one-GPU box)
+    if zp and (R.world > 1 or os.environ.get("OSZ_BENCH_STRONG") == "1") and args.scaling == "weak":
         del fwd, y_out, fir_out, ring
         fir.close()
         iir.close()
-        extra["strong"] = strong_leg(args, R, h, sos, R.world * C * CHUNK * launches / elapsed / 1e6)
+        extra["strong"] = strong_leg(args, R, h, sos, R.world * C * CHUNK * launches / elapsed / 1e6,
+                                     steady["Msamples_s"] if steady else None)
     return elapsed, kernels, roofline_of(kernels, C * NS), extra
 
 
-def strong_leg(args, R, h, sos, weak_value):
+def strong_leg(args, R, h, sos, weak_value, weak_steady=None):
     """Beside the weak line of an N > 1 run: the metric's OWN job -- 256 channels, split
     channel_block-wise over the ranks (32 per GPU at 8) -- timed the same way (barrier,
     K steps, max over ranks).  A rank steps its C = 256 / N channels 256 / C chunks per launch (what
@@ -572,8 +574,11 @@ def strong_leg(args, R, h, sos, weak_value):
     return {"job": "256 channels split channel_block-wise over the ranks", "channels_per_gpu": C,
             "chunks_per_launch": g, "steps": launches * g, "ms_per_step": elapsed / (launches * g) * 1e3,
             "ms_per_step_by_rank": [float(v) for v in per_rank], "value": value, "unit": "Msamples/s",
-            "efficiency": value / weak_value,
-            "note": "efficiency = this rate / the weak line's `value` (N x one GPU's 256-channel rate)"}
+            "efficiency": value / (weak_steady or weak_value),
+            "efficiency_vs_value": value / weak_value,
+            "note": "efficiency = this rate / the weak job's rate (N x one GPU's 256-channel rate) with the GPU's power "
+                    "state settled in both (the weak line's `steady_state`; this leg runs behind it); "
+                    "efficiency_vs_value: against the weak line's `value`, which times the first launches after idle"}
 
 
 def chain_channels(args, R):
