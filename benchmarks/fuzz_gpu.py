@@ -264,6 +264,14 @@ def main():
                     elif ok.any():
                         e = max(e, float(np.max(np.abs(got[ok] - want[ok])) / np.max(np.abs(want[ok]))))
                 what = f"nonfinite C={C} n={n} cs={cs} dev={dev_in}"
+                if e == float("inf"):     # where the masks differ, for a replay
+                    for nm_, got, want in (("sosfilt", y, ry), ("sosfiltfilt", z, rz)):
+                        diff = np.isfinite(got) != np.isfinite(want)
+                        for c_ in np.flatnonzero(diff.any(-1)):
+                            idx = np.flatnonzero(diff[c_])
+                            badx = np.flatnonzero(~np.isfinite(x[c_]))
+                            what += (f" | {nm_} ch {c_}: {len(idx)} samples {idx[0]}..{idx[-1]} differ, got finite there: "
+                                     f"{bool(np.isfinite(got[c_, idx[0]]))}; input non-finite at {badx[:4].tolist()} ({len(badx)})")
         except Exception as exc:   # noqa: BLE001 - report and continue
             e, what = float("inf"), f"kind {kind} raised {type(exc).__name__}: {exc}"
         if not e < (1e-8 if kind in (4, 5) else TOL):

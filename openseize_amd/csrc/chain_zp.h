@@ -72,6 +72,22 @@ __device__ __forceinline__ double zp_dot(const double *kk, const double *pr, con
     return c;
 }
 
+// Where a channel's input FIRST holds a non-finite sample, exactly.  A block whose transform has
+// gone bad says "somewhere in my samples"; the NaN reach of sosfiltfilt is decided per CHUNK
+// (osz_chain_zp_seal), and the blocks of a step over several chunks (round 5: few channels) straddle
+// chunk boundaries, so the block's start is not good enough -- it may lie a chunk early.  Called
+// by a whole workgroup, once, when its run goes bad (a rare path): every thread looks through its
+// share of the block's `count` input samples from `xb` on and lowers nanpos to `base` + the index
+// of a non-finite one.  Returns whether any thread found one (if none: the bad values came in from
+// before the block, and the caller falls back to the block's start).
+__device__ __forceinline__ bool zp_exact_nanpos(const double *xb, int count, int t, long long *nanpos, long long base) {
+    int hit = -1;
+    for (int i = t; i < count && hit < 0; i += 256)
+        if (!(fabs(xb[i]) <= 1.79769313486231570815e308)) hit = i;
+    if (hit >= 0) atomicMin(nanpos, base + hit);
+    return __syncthreads_or(hit >= 0) != 0;
+}
+
 // chain_zpn_*.hip: the kernel for NB rows per block (20 .. 30), NM modes (2, 4, 6, 8) of which the
 // first NS (2, 4, 6) are slow
 using zp_kern_t = void (*)(ZpArgs);

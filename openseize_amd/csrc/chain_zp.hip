@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             if (!bad && __builtin_amdgcn_readfirstlane((int)(sos_not_finite(ca) || sos_not_finite(cb)))) {
                 bad = true;
                 bad_at = o;
+                if (zp_exact_nanpos(xr + o, 2 * S, tt, reinterpret_cast<long long *>(g.nanpos + c), g.pos + o)) bad_at = -1;
             }
             __builtin_amdgcn_sched_barrier(0);
             zp_powers<NM>(ptab, 255 - tt, Pr, Pi);
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
             if (!bad && __builtin_amdgcn_readfirstlane((int)nf)) {
                 bad = true;
                 bad_at = o;
+                if (zp_exact_nanpos(xr + o, la + lb, t, reinterpret_cast<long long *>(g.nanpos + c), g.pos + o)) bad_at = -1;
             }
         }
         double Pfr[NM], Pfi[NM], Pbr[NM], Pbi[NM];
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
     // (No sealing of the later runs in here: overwriting what workgroups on other XCDs have
     // written wants an agent-scope release from each of them, a write-back of the XCD's L2 --
     // 12 us per workgroup on average, 50 at the worst, benchmarks/zp_timeline.hip.)
-    if (bad && t == 0) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
+    if (bad && bad_at >= 0 && t == 0) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
     OSZ_ZMARK(4);
 #ifdef OSZ_ZP_MARKS
     if (g_zp_marks && threadIdx.x == 0) {

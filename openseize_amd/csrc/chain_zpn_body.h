@@ -383,6 +383,9 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
             if (!bad && __builtin_amdgcn_readfirstlane((int)sos_not_finite(ca))) {
                 bad = true;
                 bad_at = o;
+                // (the exact position where it can be had: chain_zp.h)
+                if (ZP && zp_exact_nanpos(xr + o, closing ? g.la : S, tt, reinterpret_cast<long long *>(g.nanpos + c), g.pos + o))
+                    bad_at = -1;
             }
 #endif
         }
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
 #undef OSZ_ZP_PUT
     // where the forward stream of this channel first went bad (chain_zp.hip: later launches start
     // bad, osz_chain_zp_seal settles the chunks the reference loses)
-    if (ZP && bad && t == 0) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
+    if (ZP && bad && bad_at >= 0 && t == 0) atomicMin(reinterpret_cast<long long *>(g.nanpos + c), g.pos + bad_at);
 }
 
 // (one translation unit per mode count: chain_zpn_{2,4,6,8}.hip define OSZ_ZPN_NM and include

@@ -206,3 +206,30 @@ def test_nonfinite_reach_at_the_headline_geometry(nm):
     keep[77] = False
     assert np.array_equal(sums[:, keep], clean_sums[:, keep])      # bit patterns, channel by channel
     assert np.array_equal(sums[0], clean_sums[0])
+
+
+def test_nan_reach_is_decided_by_the_sample_not_by_the_block(nm):
+    """sosfiltfilt of a long resident stream of few channels runs several chunks per zero-phase
+    launch (round 5), so the kernel's blocks straddle chunk boundaries; the reference's NaN reach
+    is per CHUNK (core/numerical.py:397-411: a chunk is NaN as a whole when the forward stream is
+    NaN in it or in the chunk after it).  A NaN tail that begins 2579 samples into chunk 3 lies in
+    a block that begins in chunk 2: the kernel records the SAMPLE (zp_exact_nanpos, chain_zp.h),
+    chunk 1 stays finite as in the reference (found by benchmarks/fuzz_gpu.py, seed 505)."""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    C, cs, n = 5, 90112, 689048
+    rng = np.random.default_rng(505)
+    x = rng.standard_normal((C, n))
+    x[3, 3 * cs + 2579:] = np.nan
+    x[1, 5 * cs + 7] = np.inf
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    xd = torch.from_numpy(x).cuda()
+    for axis, data in ((-1, xd), (0, xd.t().contiguous())):
+        got = torch.cat(list(nm.sosfiltfilt(producer(data, cs, axis), sos, axis)), axis).cpu().numpy()
+        got = got if axis == -1 else got.T
+        want = orc.sosfiltfilt(x, sos, cs)
+        assert np.array_equal(np.isfinite(got), np.isfinite(want))
+        ok = np.isfinite(want)
+        assert ok[3, :2 * cs].all() and not ok[3, 2 * cs:].any()
+        assert np.max(np.abs(got[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
