@@ -12,9 +12,9 @@ tutorials run 4 channels.  One JSON line per (workload, channels):
   fir    FIR(1024) overlap-add alone (osz_fir_push)
   welch  Welch PSD nperseg 4096, 50 % overlap, segment average (osz_spec_push), pushes of 2^28 / C samples per
          channel as psd() makes them of a resident array (round 5; rounds 3-4: 2^20)
-  sosfiltfilt  the 6-section cascade alone, zero phase: one osz_chain_zp_step per chunk with the
-         identity as its FIR (what numerical.sosfiltfilt runs on long streams; `dual_ms`: the
-         separate kernels' osz_sosfiltfilt_step on the same box)
+  sosfiltfilt  the 6-section cascade alone, zero phase: osz_chain_zp_step with the identity as its FIR,
+         256 / C chunks per launch (what numerical.sosfiltfilt runs on long resident streams; `dual_ms`:
+         the separate kernels' osz_sosfiltfilt_step per chunk on the same box)
 `rel_256` is the rate relative to the same workload at 256 channels (printed last)."""
 import json
 import os
@@ -77,27 +77,34 @@ def sosfiltfilt(C, steps=24, warm=6):
     import scipy.signal as sps
     import torch
     from openseize_amd import _device as dev
+    from openseize_amd.core import numerical as nm
     sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
-    ring = [dev.synth_normal(C, CHUNK, seed=0, n0=k * CHUNK) for k in range(3)]
+    g = nm._zp_group(C)                                  # chunks per launch, as the generator steps a resident stream
+    n = g * CHUNK
+    ring = [dev.synth_normal(C, n, seed=0, n0=k * n) for k in range(3)]
     fir, iir = dev.FirStream(np.array([1.0, 0.0]), C), dev.SosStream(sos, C)
     lag = dev.chain_zp_lag(fir, iir)
-    ys = [torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda") for _ in range(4)]
+    ys = [torch.zeros((C, n), dtype=torch.float64, device="cuda") for _ in range(3)]
     iir.set_state_scaled(ring[0], 0)
     dev.chain_zp_open(fir, iir, 0)
 
     def step(k):
-        dev.chain_zp_step(fir, iir, ring[k % 3], out=ys[k % 4][:, :CHUNK - lag], tail=ys[(k - 1) % 4][:, CHUNK - lag:])
-        if k >= 2:
-            dev.chain_zp_seal(fir, iir, ys[(k - 2) % 4], (k - 2) * CHUNK, 0, CHUNK)
+        dev.chain_zp_step(fir, iir, ring[k % 3], out=ys[k % 3][:, :n - lag], tail=ys[(k - 1) % 3][:, n - lag:])
+        if k >= 1:
+            for j in range(g):
+                dev.chain_zp_seal(fir, iir, ys[(k - 1) % 3][:, j * CHUNK:(j + 1) * CHUNK], ((k - 1) * g + j) * CHUNK, 0, CHUNK)
 
-    dt = timed(step, steps, warm)
+    dt = timed(step, steps, warm) / g
     fir.close()
     iir.close()
+    del ring, ys
+    ring = [dev.synth_normal(C, CHUNK, seed=0, n0=k * CHUNK) for k in range(3)]
+    ys = [torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda") for _ in range(4)]
     iir = dev.SosStream(sos, C)
     iir.set_state_scaled(ring[0], 0)
     dt2 = timed(lambda k: iir.step(ring[k % 3], ys[(k + 1) % 3], ys[(k + 2) % 3], f_out=ys[k % 3], y_out=ys[3]), steps, warm)
     iir.close()
-    return dt, 32, {"dual_ms": dt2 * 1e3}
+    return dt, 32, {"dual_ms": dt2 * 1e3, "chunks_per_launch": g}
 
 
 def fir_only(C, steps=24, warm=6):
