@@ -337,7 +337,9 @@ def roofline_of(kernels, samples_per_step):
         out["unfused_equivalent_frac"] = ueq / HBM_PEAK_GBPS
         # the limiter is not HBM: vector issue + LDS latency at two waves per SIMD;
         # `bound` names the roofline the kernel's bytes are priced against
-        out["limiter"] = "vector issue / LDS latency at 2 waves per SIMD, not HBM (profiles/r04_pmc_bench.json)"
+        out["limiter"] = ("power-held: the shader clock runs at 2.0 GHz under this kernel's 4.1 TB/s of HBM traffic and at "
+                          "2.4 GHz with either half of it removed (profiles/r05_zpn_ablation.txt); vector issue 57 % at "
+                          "2 waves per SIMD (profiles/r05_pmc_bench.json)")
     if dom == "chain_step":
         # two kernels side by side under one call: the duration is that of the pair
         # (HIP events on the caller's stream around osz_chain_step), the bytes what the two
