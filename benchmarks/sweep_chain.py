@@ -9,7 +9,8 @@ tutorials run 4 channels.  One JSON line per (workload, channels):
   chain  FIR(1024) -> sosfiltfilt(6 sections) on osz_chain_zp_step (+ a seal per chunk): 256 / C chunks of
          2^20 samples per launch, as numerical.sosfiltfilt steps a resident stream of C channels (round 5:
          `chunks_per_launch`); `chain_1` is the same with every chunk its own launch (rounds 3-4)
-  fir    FIR(1024) overlap-add alone (osz_fir_push)
+  fir    FIR(1024) overlap-add alone (osz_fir_push), 256 / C chunks per push as numerical.oaconvolve joins the
+         adjacent views of a resident stream (round 5)
   welch  Welch PSD nperseg 4096, 50 % overlap, segment average (osz_spec_push), pushes of 2^28 / C samples per
          channel as psd() makes them of a resident array (round 5; rounds 3-4: 2^20)
   sosfiltfilt  the 6-section cascade alone, zero phase: osz_chain_zp_step with the identity as its FIR,
@@ -111,13 +112,16 @@ def fir_only(C, steps=24, warm=6):
     import scipy.signal as sps
     import torch
     from openseize_amd import _device as dev
+    from openseize_amd.core import numerical as nm
     h = sps.firwin(1024, 0.2)
-    ring = [dev.synth_normal(C, CHUNK, seed=0, n0=k * CHUNK) for k in range(3)]
+    g = nm._zp_group(C)                  # chunks per push, as numerical.oaconvolve joins a resident stream's views
+    n = g * CHUNK
+    ring = [dev.synth_normal(C, n, seed=0, n0=k * n) for k in range(3)]
     fir = dev.FirStream(h, C)
-    out = torch.zeros((C, CHUNK), dtype=torch.float64, device="cuda")
-    dt = timed(lambda k: fir.push(ring[k % 3], 0, out=out), steps, warm)
+    out = torch.zeros((C, n), dtype=torch.float64, device="cuda")
+    dt = timed(lambda k: fir.push(ring[k % 3], 0, out=out), steps, warm) / g
     fir.close()
-    return dt, 16
+    return dt, 16, {"chunks_per_launch": g}
 
 
 def welch(C, steps=24, warm=6):

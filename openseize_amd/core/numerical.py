@@ -142,17 +142,51 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
             fir.close()
         return
     pro = _chain_first(first, chunks) if first is not None else ()
+    # Few channels: chunks of a resident source that lie one behind the other in memory (the views
+    # an ArrayProducer cuts from one tensor) are pushed several at a time -- 256 / C of them, as the
+    # zero-phase chain does (_zp_group) -- and handed on chunk by chunk: `cuts` are the lengths the
+    # open buffer is handed on in.
+    gmax = _zp_group(layout.nch)
+    cuts = []
 
     def emit(buf, cols):
-        return layout.from2d(buf if cols == buf.shape[1] else buf[:, :cols], host)
+        if len(cuts) <= 1:
+            yield layout.from2d(buf if cols == buf.shape[1] else buf[:, :cols], host)
+            return
+        at = 0
+        for m in cuts:                       # (a last buffer may be short of its end: mode 'valid')
+            if at >= cols:
+                break
+            yield layout.from2d(buf[:, at:min(at + m, cols)], host)
+            at += m
+
+    def joined(source):
+        """(2-D chunk, came from the host, lengths of the produced chunks it holds)"""
+        held, sizes = None, []
+        for arr in source:
+            x2d, from_host = layout.to2d(arr)
+            if x2d.shape[1] == 0:
+                continue
+            if from_host or gmax == 1:
+                if held is not None:
+                    yield held, False, sizes
+                    held, sizes = None, []
+                yield x2d, from_host, [x2d.shape[1]]
+                continue
+            both = _row_joined(held, x2d) if held is not None and len(sizes) < gmax else None
+            if both is None:
+                if held is not None:
+                    yield held, False, sizes
+                held, sizes = x2d, [x2d.shape[1]]
+            else:
+                held, sizes = both, sizes + [x2d.shape[1]]
+        if held is not None:
+            yield held, False, sizes
 
     try:
-        for arr in pro:
-            x2d, host = layout.to2d(arr)
+        for x2d, host, sizes in joined(pro):
             device = x2d.device
             n = x2d.shape[1]
-            if n == 0:
-                continue
             skip = min(max(lcut - pos, 0), n)
             pos += n
             if host:
@@ -170,17 +204,18 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
                     done = skip + part
                     skip = 0
                 if fill == cur.shape[1]:
-                    yield emit(cur, fill)
+                    yield from emit(cur, fill)
                     cur, fill = None, 0
             if done < n:
                 if cur is None:
                     cur = torch.empty((layout.nch, n), dtype=torch.float64, device=device)
                     fill = 0
+                    cuts = sizes
                 cnt = n - done - skip
                 fir.push(x2d[:, done:], skip, out=cur[:, fill:fill + cnt])
                 fill += cnt
                 if fill == cur.shape[1]:
-                    yield emit(cur, fill)
+                    yield from emit(cur, fill)
                     cur, fill = None, 0
         if pos > 0:
             skip = min(max(lcut - pos, 0), wlen - 1)
@@ -194,7 +229,7 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
                     skip += part
                     cnt -= part
             if cur is not None and fill > 0:
-                yield emit(cur, fill)
+                yield from emit(cur, fill)
             if cnt > 0:
                 tail = fir.flush(device, skip=skip, drop=rcut)
                 yield layout.from2d(tail, host)

@@ -1306,3 +1306,43 @@ def test_fir_block_heights_of_the_one_block_kernel(osz, taps_n):
         want = np.stack([np.convolve(row, h, mode) for row in xh])
         assert got.shape == want.shape, (taps_n, mode)
         assert rel_err(got, want) < RTOL, (taps_n, mode)
+
+
+@pytest.mark.gpu
+def test_oaconvolve_few_channels_joined_chunks():
+    """A resident stream of few channels goes through the FIR kernel several chunks per launch (round
+    5: 256 / C adjacent views of one tensor at a time, as the zero-phase chain); the pieces the
+    generator yields are the same chunk-aligned arrays as with one push per chunk (OSZ_ZP_GROUP=1),
+    and their concatenation is np.convolve in every mode (core/numerical.py:158-298)."""
+    import os
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev
+    from openseize_amd.core import numerical as nm
+    C, cs, total = 4, 30000, 30000 * 9 + 1234
+    x = dev.synth_normal(C, total, seed=9)
+    xh = x.cpu().numpy()
+    for taps_n in (64, 255, 1024):
+        h = sps.firwin(taps_n, 0.3)
+        for mode in ("same", "full", "valid"):
+            pushes, plain = [], dev.FirStream.push
+
+            def spy(self, x2d, *a, **k):
+                pushes.append(x2d.shape[1])
+                return plain(self, x2d, *a, **k)
+
+            dev.FirStream.push = spy
+            try:
+                got = list(nm.oaconvolve(producer(x, cs, -1), h, -1, mode))
+            finally:
+                dev.FirStream.push = plain
+            assert max(pushes) > cs, (mode, pushes)            # several chunks in one push
+            os.environ["OSZ_ZP_GROUP"] = "1"
+            try:
+                one = list(nm.oaconvolve(producer(x, cs, -1), h, -1, mode))
+            finally:
+                del os.environ["OSZ_ZP_GROUP"]
+            assert [g.shape[-1] for g in got] == [o.shape[-1] for o in one], (taps_n, mode)
+            y = torch.cat(got, -1).cpu().numpy()
+            want = np.stack([np.convolve(xh[c], h, mode) for c in range(C)])
+            assert y.shape == want.shape and np.max(np.abs(y - want)) < 1e-12 * np.max(np.abs(want)), (taps_n, mode)
