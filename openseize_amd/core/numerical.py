@@ -98,6 +98,7 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
     wlen = len(window)
     lcut, rcut = _oa_cuts(wlen, mode)
     nsamples = pro.shape[axis]
+    chunk_len = int(getattr(pro, "chunksize", 1 << 20))
     if nsamples < wlen:
         raise ValueError(
             f"operands could not be convolved: data has {nsamples} samples "
@@ -142,11 +143,11 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
             fir.close()
         return
     pro = _chain_first(first, chunks) if first is not None else ()
-    # Few channels: chunks of a resident source that lie one behind the other in memory (the views
-    # an ArrayProducer cuts from one tensor) are pushed several at a time -- 256 / C of them, as the
-    # zero-phase chain does (_zp_group) -- and handed on chunk by chunk: `cuts` are the lengths the
-    # open buffer is handed on in.
-    gmax = _zp_group(layout.nch)
+    # Few channels or short chunks: chunks of a resident source that lie one behind the other in
+    # memory (the views an ArrayProducer cuts from one tensor) are pushed several at a time -- as
+    # many as make 2^28 channel-samples, as the zero-phase chain does (_zp_group) -- and handed on
+    # chunk by chunk: `cuts` are the lengths the open buffer is handed on in.
+    gmax = _zp_group(layout.nch, chunk_len)
     cuts = []
 
     def emit(buf, cols):
@@ -594,13 +595,15 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
     return gen
 
 
-def _zp_group(nch):
-    """Chunks per step of the zero-phase kernel for ``nch`` channels: as many as make a step of
-    256 channel-chunks (``OSZ_ZP_GROUP`` overrides; 1: every chunk its own launch)."""
+def _zp_group(nch, cs=1 << 20):
+    """Chunks of ``cs`` samples per launch for a resident stream of ``nch`` channels: as many as make
+    a launch of 2^28 channel-samples -- the headline's 256 x 2^20, 2 GiB in and out: few channels
+    OR short chunks both leave a one-chunk launch too few blocks per workgroup to hide what it pays
+    once -- at most 64 (``OSZ_ZP_GROUP`` overrides; 1: every chunk its own launch)."""
     env = os.environ.get("OSZ_ZP_GROUP")
     if env:
         return max(1, int(env))
-    return max(1, 256 // max(int(nch), 1))
+    return max(1, min(64, (1 << 28) // max(int(nch) * max(int(cs), 1), 1)))
 
 
 def _row_joined(a, b):
@@ -677,14 +680,14 @@ def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, 
     junk = torch.empty((C, shift), dtype=torch.float64, device=device)     # outputs before sample 0
     ys = {0: fresh(0)}
     dev.chain_zp_step(fir, iir, x0, out=ys[0][:, :cs - shift], tail=junk)
-    # Few channels: a launch over ONE chunk has too few blocks per workgroup to hide what it
-    # pays once (tables, the pre-roll block of every run, the launch itself: 32 channels x 2^20
-    # run at 0.7 of the 256-channel rate).  Chunks of a resident source that lie one
-    # behind the other in memory -- the views an ArrayProducer cuts from one tensor -- therefore
-    # go through the kernel several at a time: `gmax` of them make one step of as many
-    # channel-samples as a 256-channel chunk; the results are handed on chunk by chunk as
-    # before (views of the step's output buffer).
-    gmax = _zp_group(C) if pipe is None else 1
+    # Few channels (or short chunks): a launch over ONE chunk has too few blocks per workgroup to
+    # hide what it pays once (tables, the pre-roll block of every run, the launch itself: 32
+    # channels x 2^20 run at 0.7 of the 256-channel rate).  Chunks of a resident source
+    # that lie one behind the other in memory -- the views an ArrayProducer cuts from one tensor
+    # -- therefore go through the kernel several at a time: `gmax` of them make one step of as
+    # many channel-samples as a 256-channel chunk of 2^20; the results are handed on chunk by
+    # chunk as before (views of the step's output buffer).
+    gmax = _zp_group(C, cs) if pipe is None else 1
     group, emitted = [], 0                                    # [(k, 2-D view)]; chunks handed on so far
 
     def run_group():

@@ -399,7 +399,7 @@ def test_few_channels_take_several_chunks_per_launch(dev):
     """At 32 channels a launch over one 2^20-sample chunk runs at 0.7 of the 256-channel rate
     (what it pays once -- tables, every run's pre-roll block, the launch -- over ten blocks per
     workgroup).  Chunks of a resident source that lie one behind the other in memory go through
-    the zero-phase kernel 256 / C at a time (numerical._zp_group); the generator still yields
+    the zero-phase kernel 2^28 / (C x chunksize) at a time (numerical._zp_group); the generator still yields
     chunk-sized arrays, the same as with one launch per chunk (OSZ_ZP_GROUP=1) to rounding and
     within 1e-9 of the oracle's chunk-local scheme (core/numerical.py:338-411).  Host-fed
     streams and sources whose chunks are separate buffers keep one launch per chunk."""
@@ -425,8 +425,15 @@ def test_few_channels_take_several_chunks_per_launch(dev):
 
     for after_fir in (True, False):
         got, sizes = run(x, after_fir)
-        # chunk 0 alone (the stream's start), then groups of 256 / 32 = 8: chunks 1-8, 9-16, 17-20
-        assert sizes == [1, 8, 8, 4], sizes
+        # chunk 0 alone (the stream's start), then as many as make 2^28 channel-samples (64 at most):
+        # chunks 1-20 -- all there are before the stream's last two -- in one step
+        assert sizes == [1, 20], sizes
+        os.environ["OSZ_ZP_GROUP"] = "8"
+        try:
+            _, sizes8 = run(x, after_fir)
+        finally:
+            del os.environ["OSZ_ZP_GROUP"]
+        assert sizes8 == [1, 8, 8, 4], sizes8
         assert [g.shape[-1] for g in got] == [cs] * (nchunks - 1) + [4321]
         os.environ["OSZ_ZP_GROUP"] = "1"
         try:
