@@ -76,6 +76,32 @@ def _oa_cuts(wlen, mode):
     raise KeyError(mode)
 
 
+def _joined_resident(source, layout, gmax):
+    """The chunks of ``source`` as 2-D arrays, those of a resident stream that lie one behind the
+    other in memory joined up to ``gmax`` at a time (``_row_joined``): yields (2-D chunk, came from
+    the host, lengths of the produced chunks it holds).  Empty chunks are dropped."""
+    held, sizes = None, []
+    for arr in source:
+        x2d, from_host = layout.to2d(arr)
+        if x2d.shape[1] == 0:
+            continue
+        if from_host or gmax == 1:
+            if held is not None:
+                yield held, False, sizes
+                held, sizes = None, []
+            yield x2d, from_host, [x2d.shape[1]]
+            continue
+        both = _row_joined(held, x2d) if held is not None and len(sizes) < gmax else None
+        if both is None:
+            if held is not None:
+                yield held, False, sizes
+            held, sizes = x2d, [x2d.shape[1]]
+        else:
+            held, sizes = both, sizes + [x2d.shape[1]]
+    if held is not None:
+        yield held, False, sizes
+
+
 @dev.chain_aware
 def oaconvolve(pro, window, axis, mode, nfft_factor=32):
     """Streaming overlap-add convolution of a producer with a 1-D window
@@ -161,31 +187,8 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
             yield layout.from2d(buf[:, at:min(at + m, cols)], host)
             at += m
 
-    def joined(source):
-        """(2-D chunk, came from the host, lengths of the produced chunks it holds)"""
-        held, sizes = None, []
-        for arr in source:
-            x2d, from_host = layout.to2d(arr)
-            if x2d.shape[1] == 0:
-                continue
-            if from_host or gmax == 1:
-                if held is not None:
-                    yield held, False, sizes
-                    held, sizes = None, []
-                yield x2d, from_host, [x2d.shape[1]]
-                continue
-            both = _row_joined(held, x2d) if held is not None and len(sizes) < gmax else None
-            if both is None:
-                if held is not None:
-                    yield held, False, sizes
-                held, sizes = x2d, [x2d.shape[1]]
-            else:
-                held, sizes = both, sizes + [x2d.shape[1]]
-        if held is not None:
-            yield held, False, sizes
-
     try:
-        for x2d, host, sizes in joined(pro):
+        for x2d, host, sizes in _joined_resident(pro, layout, gmax):
             device = x2d.device
             n = x2d.shape[1]
             skip = min(max(lcut - pos, 0), n)
@@ -283,11 +286,17 @@ def sosfilt(pro, sos, axis, zi=None):
                 _chain_first(first, chunks),
                 lambda x2d: stream.forward(x2d) if x2d.shape[1] else None)
             return
-        for subarr in _chain_first(first, chunks):
-            x2d, host = layout.to2d(subarr)
-            if x2d.shape[1] == 0:
+        # (adjacent views of a resident stream go through the kernel several at a time, _zp_group)
+        gmax = _zp_group(layout.nch, int(getattr(pro, "chunksize", 1 << 20)))
+        for x2d, host, sizes in _joined_resident(_chain_first(first, chunks), layout, gmax):
+            y = stream.forward(x2d)
+            if len(sizes) == 1:
+                yield layout.from2d(y, host)
                 continue
-            yield layout.from2d(stream.forward(x2d), host)
+            at = 0
+            for m in sizes:
+                yield layout.from2d(y[:, at:at + m], host)
+                at += m
     finally:
         stream.close()
 

@@ -1234,7 +1234,14 @@ def test_fir_then_sosfilt_through_the_api_fused(osz):
         for k, (a, b) in enumerate(zip(got, ref)):
             err = float((a - b).abs().max()) / float(b.abs().max())
             assert err < 1e-11, (taps_n, C, k, err)
-        assert len({g.untyped_storage().data_ptr() for g in got}) == len(got)    # arrays of their own
+        # arrays of their own: no two of them share a sample (adjacent chunks of few channels may be
+        # column ranges of ONE buffer since round 5 -- still memory nobody else writes)
+        keep = [g.clone() for g in got]
+        for k, g in enumerate(got):
+            g.fill_(float(k))
+        assert all(bool((g == float(k)).all()) for k, g in enumerate(got))
+        for g, v in zip(got, keep):
+            g.copy_(v)
         pick = [0, C // 2, C - 1]
         xh = x[pick].cpu().numpy()
         want, _ = orc.sosfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, cs,
