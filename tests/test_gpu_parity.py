@@ -1353,3 +1353,32 @@ def test_oaconvolve_few_channels_joined_chunks():
             y = torch.cat(got, -1).cpu().numpy()
             want = np.stack([np.convolve(xh[c], h, mode) for c in range(C)])
             assert y.shape == want.shape and np.max(np.abs(y - want)) < 1e-12 * np.max(np.abs(want)), (taps_n, mode)
+
+
+@pytest.mark.gpu
+def test_reference_iir_chunksize_test_replayed():
+    """The reference's own `test_sosfiltfilt_chunksizes` (/root/reference/tests/test_iir.py:132-158),
+    statement for statement on the GPU path: a nine-section Chebyshev type I band-pass (200-600 Hz at
+    fs 2500), a (101 400, 2, 4) array filtered along axis 0 at nine random chunksizes through the
+    class API with dephase=True.  Its own bar -- allclose to SciPy's whole-array sosfiltfilt at
+    atol 1e-4, the chunk-local backward passes being what they are (Q1) -- and this suite's: 1e-9 of
+    the oracle's chunk-local scheme (core/numerical.py:338-411) at every one of them."""
+    import scipy.signal as sps
+    from oracle import oracle as orc
+    from openseize_amd.filtering import iir
+    rng = np.random.default_rng(9)
+    axis, fs = 0, 2500
+    arr = rng.random((101400, 2, 4))
+    csizes = rng.integers(1000, 12300, size=9)
+    filt = iir.Cheby1(fpass=[200, 600], fstop=[150, 650], fs=fs)
+    assert filt.coeffs.shape == (9, 6)
+    spresult = sps.sosfiltfilt(filt.coeffs, arr, axis=axis, padtype=None)
+    flat = np.moveaxis(arr, axis, -1).reshape(8, -1)
+    for csize in csizes:
+        pro = producer(arr, chunksize=csize, axis=axis)
+        pro_filt = filt(pro, chunksize=csize, axis=axis, dephase=True)
+        oresult = np.concatenate([a for a in pro_filt], axis=axis)
+        assert np.allclose(oresult, spresult, atol=1e-4), csize                 # the reference's assertion
+        want = orc.sosfiltfilt(flat, filt.coeffs, int(csize))
+        got = np.moveaxis(oresult, axis, -1).reshape(8, -1)
+        assert np.max(np.abs(got - want)) < RTOL * np.max(np.abs(want)), csize
