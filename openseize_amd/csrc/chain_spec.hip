@@ -457,8 +457,8 @@ static int spec_build(ChainSpec *s) {
         const spec::TablesZp Tn = spec::build_specn(fir->htaps.data(), wlen, sos->coef, nsec, sos->warm_len <= (1 << 20),
                                                     15360 - 1024, tol);
         if (Tn.eligible) {
-            const size_t nl = (size_t)Tn.R * Tn.NM * 2;
-            std::vector<double> cat(Tn.L.begin(), Tn.L.begin() + nl);
+            const size_t nl = (size_t)Tn.NM * 2;               // lambda^256: row 1 of the table
+            std::vector<double> cat(Tn.L.begin() + nl, Tn.L.begin() + 2 * nl);
             cat.insert(cat.end(), Tn.P.begin(), Tn.P.end());
             cat.insert(cat.end(), Tn.M.begin(), Tn.M.end());
             if ((rcu = up(&s->dH, spec_permuted_spectrum(Tn.H))) || (rcu = up(&s->dT, cat))) return rcu;
@@ -641,7 +641,7 @@ static int specn_forward(ChainSpec *s, const double *x, int64_t ldx, int64_t n, 
     if (!kern) return fail(OSZ_ERR_STATE, "forward chain kernel: no instance for %d rows, %d modes (%d slow)", NB, s->NM, s->NS);
     const int ns = 2 * s->nh;
     const size_t lds = sizeof(fft::cube::C2) * fft::cube::SLOTS +
-                       sizeof(double) * (ns + 3 * s->R * s->NS * 2 + s->R * s->NM * 2 + 20 * s->NM * 2 + 2 * s->NS * ns) + 1024;
+                       sizeof(double) * (ns + 2 * s->R * s->NS * 2 + s->NM * 2 + 20 * s->NM * 2 + 2 * s->NS * ns) + 1024;
     OSZ_DYN_LDS(kern, lds);
     {
         KernelTimer kt("chain_fwd", st);

@@ -694,7 +694,7 @@ static size_t zp_lds_bytes(const ChainZp *s) {
     const int NM = s->NM, R = s->R, ns = 2 * s->nh;
     if (s->nega)
         return sizeof(fft::cube::C2) * fft::cube::SLOTS +
-               sizeof(double) * (ns + R * (3 * s->NS + NM) * 2 + R * NM * 2 + 20 * NM * 2 + (2 * s->NS + 2 * NM) * ns) +
+               sizeof(double) * (ns + R * (2 * s->NS + NM) * 2 + NM * 2 + 20 * NM * 2 + (2 * s->NS + 2 * NM) * ns) +
                1024;   // + W256 rows
     return sizeof(fft::cube::C2) * fft::cube::SLOTS +
            sizeof(double) * (2 * ns + 8 * R * NM * 2 + R * NM * 2 + 20 * NM * 2 + 4 * NM * ns);
@@ -756,11 +756,13 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
                 };
                 int rc;
                 // one table, in the order of the kernel's LDS: a workgroup fetches it in one sweep
-                const size_t nl = (size_t)T.R * T.NM * 2, np = (size_t)20 * T.NM * 2,
+                // (the one-block kernel keeps lambda^256 alone -- row 1 -- and forms the burst rows by products)
+                const size_t nl = s->nega ? (size_t)T.NM * 2 : (size_t)T.R * T.NM * 2, np = (size_t)20 * T.NM * 2,
                              nm = (size_t)(s->nega ? 2 * T.NS + 2 * T.NM : 4 * T.NM) * 2 * T.nh;
-                if (T.L.size() < nl || T.P.size() != np || T.M.size() != nm)
+                const size_t l0 = s->nega ? (size_t)T.NM * 2 : 0;
+                if (T.L.size() < l0 + nl || T.P.size() != np || T.M.size() != nm)
                     return fail(OSZ_ERR_STATE, "zero-phase tables: %zu %zu %zu", T.L.size(), T.P.size(), T.M.size());
-                std::vector<double> cat(T.L.begin(), T.L.begin() + nl);
+                std::vector<double> cat(T.L.begin() + l0, T.L.begin() + l0 + nl);
                 cat.insert(cat.end(), T.P.begin(), T.P.end());
                 cat.insert(cat.end(), T.M.begin(), T.M.end());
                 if ((rc = up(&s->dH, spec_permuted_spectrum(T.H))) || (rc = up(&s->dT, cat))) return rc;

@@ -46,13 +46,15 @@ namespace osz {
 // row) share one amplitude -- the right tail's mu of a slow mode (NS of them) or the left tail's
 // nu of any mode (NM): each lane takes a sixteenth of the 2 nh fit samples for the real AND the
 // imaginary row of M, four DPP steps add the parts up in the row's last lane, and that lane
-// writes kappa[r] = amplitude * lambda^(256 r), r < R:
-//   kmu[r][q], q < NS    this block's mu;  kapN[r][q]: what the NEXT block meets as the previous one's
+// writes kappa[r] = amplitude * lambda^(256 r), r < R (row after row: one product by lambda^256 each;
+// round 5 -- until then a table of R rows of powers sat in LDS for this one lane):
+//   kmu[r][q], q < NS    this block's mu: read by this block's bursts AND, one block later, as the
+//                        previous block's (the caller alternates between two such arrays)
 //   knu[r][q], q < NM    this block's nu (rows behind the first are read for the slow modes only)
-// M's rows: Re mu [NS], Im mu [NS], Re nu [NM], Im nu [NM].
+// M's rows: Re mu [NS], Im mu [NS], Re nu [NM], Im nu [NM].  l256[q] = lambda_q^256.
 template <int NM, int NS, int PER, int RM, bool ZP>
 __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fitbuf, const double *mtab,
-                                                const double *lrow, double *kmu, double *knu, double *kapN) {
+                                                const double *l256, double *kmu, double *knu) {
     constexpr int ns = 16 * PER;
     constexpr int NA = NS + (ZP ? NM : 0);       // amplitudes: the forward chain has no left tail
     if ((tt & ~63) >= 16 * NA) return;           // whole waves without an amplitude skip the stage
@@ -87,20 +89,21 @@ __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fit
     sr += dpp_row_shr0<8>(sr);
     si += dpp_row_shr0<8>(si);
     if (p16 == 15 && valid) {
+        const double lr = l256[q * 2 + 0], li = l256[q * 2 + 1];
+        double kr = sr, ki = si;
 #pragma unroll
         for (int r = 0; r < RM; ++r) {
             if (r < R) {
-                const double lr = lrow[(r * NM + q) * 2 + 0], li = lrow[(r * NM + q) * 2 + 1];
-                const double kr = sr * lr - si * li, ki = sr * li + si * lr;
                 if (is_mu) {
                     kmu[(r * NS + q) * 2 + 0] = kr;
                     kmu[(r * NS + q) * 2 + 1] = ki;
-                    kapN[(r * NS + q) * 2 + 0] = kr;
-                    kapN[(r * NS + q) * 2 + 1] = ki;
                 } else {
                     knu[(r * NM + q) * 2 + 0] = kr;
                     knu[(r * NM + q) * 2 + 1] = ki;
                 }
+                const double nr = kr * lr - ki * li;
+                ki = kr * li + ki * lr;
+                kr = nr;
             }
         }
     }
@@ -109,10 +112,10 @@ __device__ __forceinline__ void zpn_fit_kappa_n(int tt, int R, const double *fit
 // nh is 16, 24 or 32 (spec::build_zpn)
 template <int NM, int NS, int RM, bool ZP>
 __device__ __forceinline__ void zpn_fit_kappa(int tt, int nh, int R, const double *fitbuf, const double *mtab,
-                                              const double *lrow, double *kmu, double *knu, double *kapN) {
-    if (nh == 24) zpn_fit_kappa_n<NM, NS, 3, RM, ZP>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
-    else if (nh == 32) zpn_fit_kappa_n<NM, NS, 4, RM, ZP>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
-    else zpn_fit_kappa_n<NM, NS, 2, RM, ZP>(tt, R, fitbuf, mtab, lrow, kmu, knu, kapN);
+                                              const double *l256, double *kmu, double *knu) {
+    if (nh == 24) zpn_fit_kappa_n<NM, NS, 3, RM, ZP>(tt, R, fitbuf, mtab, l256, kmu, knu);
+    else if (nh == 32) zpn_fit_kappa_n<NM, NS, 4, RM, ZP>(tt, R, fitbuf, mtab, l256, kmu, knu);
+    else zpn_fit_kappa_n<NM, NS, 2, RM, ZP>(tt, R, fitbuf, mtab, l256, kmu, knu);
 }
 
 // lambda_q^e, q = q0 .. q0 + NG - 1, e = 0..255, from the three-level table [20][NM][2]
@@ -207,11 +210,10 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
     constexpr int NMROWS = 2 * NS + (ZP ? 2 * NM : 0);  // rows of the fit matrix
     double *xl = reinterpret_cast<double *>(cube_lds) + 2 * fft::cube::SLOTS;   // behind the cube
     double *fitbuf = xl;                               // [2 nh]
-    double *kmu = fitbuf + ns;                         // [Rt][NS][2]: this block's mu (slow modes)
-    double *knu = kmu + Rt * NS * 2;                   // [Rt][NM][2]: this block's nu (ZP)
-    double *kapP = knu + (ZP ? Rt * NM * 2 : 0);       // [2 parity][Rt][NS][2]: the previous block's mu
-    double *lrow = kapP + 2 * Rt * NS * 2;             // [Rt][NM][2]
-    double *ptab = lrow + Rt * NM * 2;                 // [20][NM][2]
+    double *kapP = fitbuf + ns;                        // [2 parity][Rt][NS][2]: this block's mu and the previous block's (slow modes)
+    double *knu = kapP + 2 * Rt * NS * 2;              // [Rt][NM][2]: this block's nu (ZP)
+    double *lrow = knu + (ZP ? Rt * NM * 2 : 0);       // [NM][2]: lambda^256
+    double *ptab = lrow + NM * 2;                      // [20][NM][2]
     double *mtab = ptab + 20 * NM * 2;                 // [2 NS (+ 2 NM)][2 nh]
     fft::cube::C2 *tw2l = reinterpret_cast<fft::cube::C2 *>(mtab + NMROWS * ns);   // [4 q][16 n0]
     const FirArgs &a = g.f;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
 #endif
     {
         // lrow | ptab | mtab are one table on the device too (g.Lrow)
-        const int ntab = Rt * NM * 2 + 20 * NM * 2 + NMROWS * ns;
+        const int ntab = NM * 2 + 20 * NM * 2 + NMROWS * ns;
 #pragma unroll 8
         for (int i = t; i < ntab; i += 256) lrow[i] = g.Lrow[i];
     }
@@ -339,7 +341,9 @@ __global__ __launch_bounds__(256, 2) void chain_zpn_kernel(ZpArgs g) {
 #ifndef OSZ_ABL_NOEPI
         __syncthreads();
         OSZ_BSTAMP(12);   // barrier 5
-        zpn_fit_kappa<NM, NS, RM, ZP>(tt, nh, Rt, fitbuf, mtab, lrow, kmu, knu, kapP + (par ^ 1) * (Rt * NS * 2));
+        // (this block's mu where the next block will look for the previous one's)
+        double *kmu = kapP + (par ^ 1) * (Rt * NS * 2);
+        zpn_fit_kappa<NM, NS, RM, ZP>(tt, nh, Rt, fitbuf, mtab, lrow, kmu, knu);
         __syncthreads();
 #endif
         OSZ_BSTAMP(13);   // fit + barrier 6

@@ -645,12 +645,12 @@ inline TablesZp build_zpn(const double *taps, int wlen, const double *sos, int n
     int NS = (std::max(ns_needed, 1) + 1) & ~1;
     if (NS > NM) NS = NM;
     if (NS > 6) return T;                 // (eight slow modes: no instance)
-    // LDS behind the cube: fit samples [2 nh], kappa: this block's mu [R][NS][2] and nu
-    // [R][NM][2], the previous block's mu [2 parity][R][NS][2], L [R][NM][2], P [20][NM][2],
+    // LDS behind the cube: fit samples [2 nh], kappa: this block's and the previous block's mu
+    // [2 parity][R][NS][2] and this block's nu [R][NM][2], lambda^256 [NM][2], P [20][NM][2],
     // M [2 NS + 2 NM][2 nh]
     int nh = 0;
     for (int cand = 32; cand >= 16 && !nh; cand -= 8) {
-        const int bytes = 8 * (2 * cand + R * (3 * NS + NM) * 2 + R * NM * 2 + 20 * NM * 2 +
+        const int bytes = 8 * (2 * cand + R * (2 * NS + NM) * 2 + NM * 2 + 20 * NM * 2 +
                                (2 * NS + 2 * NM) * 2 * cand);
         if (bytes <= lds_budget) nh = cand;
     }
@@ -863,11 +863,11 @@ inline TablesZp build_specn(const double *taps, int wlen, const double *sos, int
     int NS = (std::max(ns_needed, 1) + 1) & ~1;
     if (NS > NM) NS = NM;
     if (NS > 6) return T;
-    // LDS behind the cube: fit samples [2 nh], this block's mu [Rf][NS][2], the previous block's
-    // [2 parity][Rf][NS][2], L [Rf][NM][2], P [20][NM][2], M [2 NS][2 nh]
+    // LDS behind the cube: fit samples [2 nh], this block's and the previous block's mu
+    // [2 parity][Rf][NS][2], lambda^256 [NM][2], P [20][NM][2], M [2 NS][2 nh]
     int nh = 0;
     for (int cand = 32; cand >= 16 && !nh; cand -= 8) {
-        const int bytes = 8 * (2 * cand + Rf * 3 * NS * 2 + Rf * NM * 2 + 20 * NM * 2 + 2 * NS * 2 * cand);
+        const int bytes = 8 * (2 * cand + Rf * 2 * NS * 2 + NM * 2 + 20 * NM * 2 + 2 * NS * 2 * cand);
         if (bytes <= lds_budget) nh = cand;
     }
     if (!nh) return T;

@@ -237,6 +237,10 @@ def test_plain_sosfiltfilt_takes_the_zero_phase_kernel(dev, fed):
                                         # halves of the window
                                         (sps.butter(6, [8 / 250, 30 / 250], "bandpass", output="sos"), 4, 131072,
                                          131072 * 6 + 77, -1, True),
+                                        # eight sections alone: its fit wants 2 x 24 samples, which fit beside the
+                                        # cube since the burst rows come by products instead of from a table
+                                        (sps.butter(8, [0.05, 0.3], "bandpass", output="sos"), 3, 131072,
+                                         131072 * 6 + 4099, -1, True),
                                         (narrow, 4, 131072, 131072 * 6 + 5, -1, False),
                                         (BP, 4, 131072, 131072 * 5, -1, False)):
         xd = dev.synth_normal(C, total, seed=71)
