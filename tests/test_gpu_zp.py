@@ -263,7 +263,7 @@ def test_plain_sosfiltfilt_takes_the_zero_phase_kernel(dev, fed):
         assert [g.shape for g in got] == [r.shape for r in ref]
         assert all(isinstance(g, np.ndarray) == (fed == "host") for g in got)
         to_np = (lambda a: a) if fed == "host" else (lambda a: a.cpu().numpy())
-        tol = 1e-9 if (C, cs) == (4, 131072) and zp else 1e-11
+        tol = 1e-9 if (C, cs) in ((4, 131072), (3, 131072)) and zp else 1e-11      # (the ill-conditioned fits: 1e-16 / ratio)
         for k, (a, b) in enumerate(zip(got, ref)):
             a, b = to_np(a), to_np(b)
             assert np.max(np.abs(a - b)) < tol * np.max(np.abs(b)), (C, cs, k)
