@@ -10,10 +10,13 @@
 #include "../openseize_amd/csrc/chain_spec.hip"
 #include "../openseize_amd/csrc/chain_zp.hip"
 #define OSZ_ZPN_NM 6
+#define OSZ_ZPN_NO_DISPATCH          // the headline's instance alone (seconds instead of minutes to compile)
 #include "../openseize_amd/csrc/chain_zpn_body.h"
 namespace osz {
-// (the six-mode instances only: the headline's cascade)
-zp_kern_t zpn_kernel_for(int nb, int nm, int ns, int r) { return nm == 6 ? zpn_kernel_nm6(nb, ns, r) : nullptr; }
+zp_kern_t zpn_kernel_for(int nb, int nm, int ns, int r) {
+    return (nm == 6 && nb == 27 && ns == 2 && r <= 5) ? chain_zpn_kernel<27, 6, 2> : nullptr;
+}
+zp_kern_t zpn_fwd_kernel_for(int, int, int) { return nullptr; }
 }
 
 #include <vector>
