@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 14
+        kind = it % 15
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -188,6 +188,35 @@ def main():
                 finally:
                     del os.environ["OSZ_CHAIN_API"]
                 e, what = rel(got_, ref_) * 100, f"api chain taps={taps} C={C} cs={cs} total={total}"
+            elif kind == 14:   # non-finite samples through FIR -> sosfiltfilt on the one-kernel route: the reference's reach
+                from functools import partial
+                taps = int(rng.choice([64, 256, 513, 1024]))
+                C = int(rng.integers(1, 5))
+                cs = int(rng.integers(65536, 140000))
+                nch_ = int(rng.integers(6, 13))
+                total = cs * (nch_ - 1) + int(rng.integers(1, cs + 1))
+                h = sps.firwin(taps, 0.3)
+                sos = designs[1]
+                xh = rng.standard_normal((C, total))
+                for _ in range(int(rng.integers(1, 4))):
+                    c, at = int(rng.integers(0, C)), int(rng.integers(0, total))
+                    r = rng.random()
+                    if r < 0.25:
+                        xh[c, at:] = np.nan
+                    else:
+                        xh[c, at] = np.nan if r < 0.8 else np.inf
+                data = torch.from_numpy(xh).cuda() if rng.random() < 0.6 else xh
+                src = producer(data, cs, -1)
+                fir_ = producer(partial(nm.oaconvolve, src, h, -1, "same"), cs, -1, shape=src.shape)
+                got_ = np.concatenate([o.cpu().numpy() if torch.is_tensor(o) else o for o in nm.sosfiltfilt(fir_, sos, -1)], -1)
+                with np.errstate(invalid="ignore"):
+                    ref_ = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xh, h, "same"), -1), sos, cs)
+                ok = np.isfinite(ref_)
+                if not np.array_equal(ok, np.isfinite(got_)):
+                    e = float("inf")
+                else:
+                    e = float(np.max(np.abs(got_[ok] - ref_[ok])) / np.max(np.abs(ref_[ok]))) if ok.any() else 0.0
+                what = f"chain nonfinite taps={taps} C={C} cs={cs} total={total} resident={torch.is_tensor(data)}"
             elif kind == 13:   # plain sosfiltfilt of a long resident stream, any layout: grouped zero-phase steps
                 ndim = int(rng.integers(1, 4))
                 axis = int(rng.integers(0, ndim))

@@ -246,6 +246,12 @@ int osz_chain_wait(osz_sos_t sos, void *stream);
  *                           rounding on any input; a caller whose streams are zero-mean may
  *                           relax it (1e-12: one burst row less each way, 2 % less time, 6e-13
  *                           of the output scale on such data).
+ *   osz_chain_zp_reach      how far a non-finite INPUT sample reaches in the reference's FIR: it works
+ *                           in segments of `step` input samples, one FFT each (core/numerical.py:
+ *                           202-217, 258-283), so the forward stream is bad from the start of the
+ *                           segment that holds the sample -- osz_chain_zp_seal then counts chunks
+ *                           from there (0, the default: from the sample itself; the kernels record
+ *                           the exact sample)
  *   osz_chain_zp_min_chunk  shortest chunk osz_chain_zp_step takes (two blocks)
  *   osz_chain_zp_open       starts a stream at sample 0: the FIR's overlap tail must be
  *                           zero; the forward cascade starts from the state on the SOS
@@ -277,6 +283,7 @@ int osz_chain_wait(osz_sos_t sos, void *stream);
  */
 int64_t osz_chain_zp_lag(osz_fir_t fir, osz_sos_t sos);
 int osz_chain_zp_tolerance(osz_fir_t fir, osz_sos_t sos, double tol);
+int osz_chain_zp_reach(osz_fir_t fir, osz_sos_t sos, int64_t step);
 int64_t osz_chain_zp_min_chunk(osz_fir_t fir, osz_sos_t sos);
 int osz_chain_zp_open(osz_fir_t fir, osz_sos_t sos, int64_t skip, void *stream);
 int osz_chain_zp_step(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t ldx,

@@ -742,6 +742,12 @@ def chain_zp_tolerance(fir, sos, tol):
     _lib.check(fir.lib.osz_chain_zp_tolerance(fir.h, sos.h, float(tol)))
 
 
+def chain_zp_reach(fir, sos, step):
+    """The reference FIR's segment length in input samples (C ABI: osz_chain_zp_reach): the NaN
+    reach of the chain counts from the start of the segment that holds a non-finite sample."""
+    _lib.check(fir.lib.osz_chain_zp_reach(fir.h, sos.h, int(step)))
+
+
 def zp_tolerance():
     """The cut the generators ask for: the library's default (1e-15 of the response's norm -- what
     is cut scales with the INPUT's magnitude, about 0.3 tol max|x|, and at 1e-15 that is float64's

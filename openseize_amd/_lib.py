@@ -83,6 +83,7 @@ SIGNATURES = {
     "osz_chain_wait": (ctypes.c_int, [c_vp, c_vp]),
     "osz_chain_zp_lag": (c_i64, [c_vp, c_vp]),
     "osz_chain_zp_tolerance": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double]),
+    "osz_chain_zp_reach": (ctypes.c_int, [c_vp, c_vp, c_i64]),
     "osz_chain_zp_min_chunk": (c_i64, [c_vp, c_vp]),
     "osz_chain_zp_open": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "osz_chain_zp_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),

@@ -485,8 +485,11 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
             lag = dev.chain_zp_lag(fir, iir)
             if (lag >= 0 and nchunks >= 6 and os.environ.get("OSZ_CHAIN_ZP", "1") != "0"
                     and cs >= max(4 * (lcut + lag), warm + lcut + lag, 2 * dev.chain_zp_min_chunk(fir, iir))):
+                # (the reference FIR's NaN reach, segment by segment; OSZ_ZP_REACH=0: the kernels' own,
+                # from the sample itself)
+                reach = 0 if os.environ.get("OSZ_ZP_REACH") == "0" else _oa_reference_step(total, wlen)
                 yield from _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, total,
-                                              lcut, rcut, lag, device)
+                                              lcut, rcut, lag, device, ref_step=reach)
                 return
 
             def feed(arr):
@@ -631,8 +634,21 @@ def _row_joined(a, b):
     return a.as_strided((a.shape[0], n), a.stride(), a.storage_offset())
 
 
+def _oa_reference_step(nsamples, wlen):
+    """Input samples per FFT segment of the reference's overlap-add (core/numerical.py:202-217):
+    nfft = 8 * 2^ceil(log2 wlen) * 32 unless a segment of that size is longer than the data, then
+    min(8 * 2^ceil(log2 wlen), N); step = nfft - wlen + 1.  A non-finite input sample makes its whole
+    segment's output non-finite there (:258-283): the NaN reach of a chain behind the FIR counts from
+    the segment's start."""
+    base = int(8 * 2 ** math.ceil(math.log2(wlen)))
+    nfft = base * 32
+    if nfft - wlen + 1 > nsamples:
+        nfft = min(base, int(nsamples))
+    return max(nfft - wlen + 1, 1)
+
+
 def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, total, lcut, rcut, lag, device,
-                       what="sosfiltfilt after oaconvolve"):
+                       what="sosfiltfilt after oaconvolve", ref_step=0):
     """The body of ``_sosfiltfilt_after_fir`` on the zero-phase kernel (C ABI: osz_chain_zp_*,
     csrc/chain_zp.hip): FIR, forward and backward cascade of an input chunk in ONE launch.
 
@@ -651,7 +667,17 @@ def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, 
     k delivers output samples [k cs - shift, (k + 1) cs - shift), i.e. the tail of output
     chunk k - 1 and the head of chunk k, which is where the kernel writes them.  Output
     chunk j is handed on two steps later, after ``osz_chain_zp_seal`` (NaN reach: a NaN in
-    the forward stream of chunk j + 1 makes chunk j NaN as a whole)."""
+    the forward stream of chunk j + 1 makes chunk j NaN as a whole).
+
+    ``ref_step`` > 0 (a real FIR in front): the reference's FIR turns a non-finite input sample
+    into a whole non-finite SEGMENT of ``ref_step`` samples (``_oa_reference_step``), so its
+    forward stream is bad from the segment's START -- up to ``ref_step`` samples before the
+    sample.  The kernels record the exact sample, ``osz_chain_zp_reach`` makes the seal count
+    from the segment's start, and output chunks are held back for as many more steps as that
+    reach spans chunks, so that the chunks the reference loses are still here to be lost.  In
+    the stream's last two chunks (separate kernels, whose FIR makes its own 4096-point blocks
+    non-finite) the forward stream is recomputed from a cleaned copy and poisoned by the
+    reference's rule when a channel first goes bad there."""
     import torch
     C = layout.nch
     wlen = len(taps)
@@ -686,6 +712,9 @@ def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, 
     iir.set_state(iir.get_state() - seen)
     fir.reset()
     dev.chain_zp_open(fir, iir, lcut)
+    dev.chain_zp_reach(fir, iir, ref_step)
+    # chunks the reach of a non-finite sample spans beyond the two the backward pass's does
+    extra = max(-(-(ref_step + lcut) // cs) - 1, 0) if ref_step else 0
     junk = torch.empty((C, shift), dtype=torch.float64, device=device)     # outputs before sample 0
     ys = {0: fresh(0)}
     dev.chain_zp_step(fir, iir, x0, out=ys[0][:, :cs - shift], tail=junk)
@@ -710,7 +739,7 @@ def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, 
             ys[a + i] = Y[:, i * cs:(i + 1) * cs]
         dev.chain_zp_step(fir, iir, X, out=Y[:, :g * cs - shift], tail=ys[a - 1][:, cs - shift:])
         group.clear()
-        while emitted <= a + g - 3:                           # complete: the forward stream of chunk j + 1 is known
+        while emitted <= a + g - 3 - extra:                   # complete: the forward stream of chunk j + 1 is known
             j = emitted
             dev.chain_zp_seal(fir, iir, ys[j], lcut + j * cs, lcut, cs)
             yield from emit(ys.pop(j))
@@ -739,8 +768,6 @@ def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, 
     dev.chain_zp_finish(fir, iir, x2d[:, :m], out=ys[k - 1][:, cs - shift:])
     off = lcut & 1                                            # chunk views on even columns
     n_last = total - (nchunks - 1) * cs
-    F = torch.empty((C, off + lcut + cs + n_last + 2), dtype=torch.float64, device=device)
-    dev.chain_forward(fir, iir, x2d, out=F[:, off:off + cs])
     last = next(chunks, None)
     while last is not None and last.shape[layout.axis] == 0:
         last = next(chunks, None)
@@ -749,18 +776,52 @@ def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, 
     xl = feed(last)
     if xl.shape[1] != n_last:
         raise RuntimeError(f"{what}: the last chunk has {xl.shape[1]} of {n_last} samples")
-    dev.chain_forward(fir, iir, xl, out=F[:, off + cs:off + cs + n_last])
     cnt = max(wlen - 1 - rcut, 0)
-    if cnt > 0:
-        F[:, off + cs + n_last:off + cs + n_last + cnt].copy_(iir.forward(fir.flush(device, skip=0, drop=rcut)))
+    F = torch.empty((C, off + lcut + cs + n_last + 2), dtype=torch.float64, device=device)
+    kept = (fir.get_state(), iir.get_state()) if ref_step else None      # (the states at the start of chunk n-2)
+
+    def forward_tail(xa, xb):
+        """The forward stream of the last two chunks and the overhang, FIR 'full' sample
+        (n - 2) cs + j at column off + j."""
+        dev.chain_forward(fir, iir, xa, out=F[:, off:off + cs])
+        dev.chain_forward(fir, iir, xb, out=F[:, off + cs:off + cs + n_last])
+        if cnt > 0:
+            F[:, off + cs + n_last:off + cs + n_last + cnt].copy_(iir.forward(fir.flush(device, skip=0, drop=rcut)))
+
+    forward_tail(x2d, xl)
+    late = None
+    if ref_step:
+        # A channel that FIRST goes bad in these two chunks: the separate kernels' FIR makes its
+        # own 4096-point blocks non-finite, the reference its segments of ref_step samples.  Rare,
+        # and only then: the exact sample from the inputs, the forward stream once more from a
+        # cleaned copy (every sample the bad one does not reach is then what it should be), and the
+        # reference's reach laid over it.  (Channels bad from before arrive with poisoned states:
+        # their forward stream is non-finite from column `off` on, the seal below knows the rest.)
+        first_bad = torch.isfinite(F[:, off]) & ~torch.isfinite(F[:, off + cs + n_last + cnt - 1])
+        if bool(first_bad.any()):
+            xa = torch.cat([x2d, xl], 1)
+            nonfinite = ~torch.isfinite(xa)
+            at = nonfinite.to(torch.int8).argmax(1).to(torch.int64) + (nchunks - 2) * cs     # the first one per channel
+            seg = torch.div(at, ref_step, rounding_mode="floor") * ref_step                   # its segment's first sample
+            fir.set_state(kept[0])
+            iir.set_state(kept[1])
+            xa = torch.where(nonfinite & first_bad[:, None], torch.zeros((), dtype=xa.dtype, device=xa.device), xa)
+            forward_tail(xa[:, :cs], xa[:, cs:])
+            col = off + (seg - (nchunks - 2) * cs).clamp(min=0)
+            cols = torch.arange(F.shape[1], device=F.device)
+            F.masked_fill_(first_bad[:, None] & (cols[None, :] >= col[:, None]), float("nan"))
+            # the first output chunk the reference loses: the one before the chunk the segment starts in
+            late = (first_bad, torch.div((seg - lcut).clamp(min=0), cs, rounding_mode="floor") - 1)
     fa = F[:, off + lcut:off + lcut + cs]
     fb = F[:, off + lcut + cs:off + lcut + cs + n_last]
     # NaN reach across the seam: the zero-phase steps have seen chunk n-2 only up to its head
-    for j in (nchunks - 4, nchunks - 3):
+    for j in range(emitted, nchunks - 2):
         dev.chain_zp_seal(fir, iir, ys[j], lcut + j * cs, lcut, cs)
-    ys[nchunks - 3].masked_fill_(~torch.isfinite(fa[:, -1:]), float("nan"))
-    yield from emit(ys.pop(nchunks - 4))
-    yield from emit(ys.pop(nchunks - 3))
+        if j == nchunks - 3:
+            ys[j].masked_fill_(~torch.isfinite(fa[:, -1:]), float("nan"))
+        if late is not None:
+            ys[j].masked_fill_((late[0] & (late[1] <= j))[:, None], float("nan"))
+        yield from emit(ys.pop(j))
     yield from emit(iir.backward(fa, fb))
     yield from emit(iir.backward(fb, None))
     while flying:

@@ -601,11 +601,16 @@ __global__ __launch_bounds__(256, 2) void chain_zp_kernel(ZpArgs g) {
 // NaN reach of sosfiltfilt (sos_tile.h): a chunk of the reference's output is NaN as a
 // whole when the forward stream is NaN anywhere in it or in the chunk after it.  y holds
 // output samples [s0, s0 + n) of channel c; chunks are cs samples from `origin` on.
+// step > 0: the reference's FIR in front of the cascade works in segments of `step` input
+// samples (core/numerical.py:202-217, :258-283: one FFT per segment), and a non-finite sample
+// makes the whole segment's output non-finite -- the forward stream is bad from the START of the
+// segment that holds the sample (osz_chain_zp_reach).
 __global__ void zp_seal_kernel(double *y, int64_t ldy, int64_t n, long long s0, long long origin, long long cs,
-                               const long long *nanpos) {
+                               const long long *nanpos, long long step) {
     const int c = blockIdx.y;
-    const long long np = nanpos[c];
+    long long np = nanpos[c];
     if (np == 0x7fffffffffffffffLL) return;
+    if (step > 0) np = (np / step) * step;
     long long k = (np - origin) / cs;
     if (np < origin) k = 0;
     const long long from = origin + (k - 1) * cs;       // the chunk before the one that holds the NaN
@@ -653,6 +658,7 @@ struct ChainZp {
     size_t fin_cap = 0;            // doubles
     hipEvent_t fin_done = nullptr; // behind the last copy out of dfin: a later finish may come on another stream
     double *dzero = nullptr;       // (nsec, nch, 2) zeros: start state of the opening's backward pass
+    int64_t ref_step = 0;          // osz_chain_zp_reach: the reference FIR's segment length (0: none)
 };
 
 // OSZ_ZP_NEGA=0: the pair kernel of this file instead of chain_zpn.hip's (one real block per
@@ -918,6 +924,17 @@ int osz_chain_zp_tolerance(osz_fir_t fir, osz_sos_t sos, double tol) {
     return OSZ_OK;
 }
 
+int osz_chain_zp_reach(osz_fir_t fir, osz_sos_t sos, int64_t step) {
+    OSZ_REQUIRE(fir && sos && step >= 0, "osz_chain_zp_reach: step=%lld", (long long)step);
+    ChainZp *s = nullptr;
+    int rc = zp_get(fir, sos, &s);
+    if (rc) return rc;
+    if (!s->eligible)
+        return fail(OSZ_ERR_UNSUPPORTED, "osz_chain_zp_reach: this filter pair does not take the zero-phase kernel");
+    s->ref_step = step;
+    return OSZ_OK;
+}
+
 int64_t osz_chain_zp_min_chunk(osz_fir_t fir, osz_sos_t sos) {
     if (!fir || !sos) return -1;
     ChainZp *s = nullptr;
@@ -1048,7 +1065,7 @@ int osz_chain_zp_seal(osz_fir_t fir, osz_sos_t sos, double *y, int64_t ldy, int6
     OSZ_REQUIRE(s && s->fir == fir, "osz_chain_zp_seal: no zero-phase stream");
     if (n == 0) return OSZ_OK;
     hipLaunchKernelGGL(zp_seal_kernel, dim3(4, fir->nch), dim3(256), 0, as_stream(stream), y, ldy, n,
-                       (long long)s0, (long long)origin, (long long)cs, s->dnanpos);
+                       (long long)s0, (long long)origin, (long long)cs, s->dnanpos, (long long)s->ref_step);
     OSZ_HIP(hipGetLastError());
     return OSZ_OK;
 }

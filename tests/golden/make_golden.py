@@ -625,6 +625,39 @@ def g18_chain_long():
          piece_lengths=np.array([p.shape[-1] for p in pieces], dtype=np.int64))
 
 
+# --------------------------------------------------------------------------
+# G19 how far a non-finite input sample reaches in the reference's FIR -> sosfiltfilt chain: the FIR's
+# overlap-add makes the whole SEGMENT (nfft - wlen + 1 input samples) of a non-finite sample
+# non-finite (core/numerical.py:258-283), the cascade everything behind it, sosfiltfilt whole chunks.
+# 256 taps (segments of 65 281 samples), chunksize 65 664, nine chunks; one placement per channel (the
+# placements of tests/test_gpu_nonfinite.py::test_fir_chain_nan_reach_is_the_references).  Stored:
+# the positions and, per channel and chunk, whether the reference's output chunk is non-finite (a
+# mask depends on where the bad samples are, not on the other values).
+# --------------------------------------------------------------------------
+def g19_fir_chain_nonfinite():
+    taps_n, cs, nchunks = 256, 65664, 9
+    total = cs * (nchunks - 1) + 4321
+    h = sps.firwin(taps_n, 0.3)
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    step = 8 * 256 * 32 - taps_n + 1
+    where = [3 * cs + 777, (4 * cs // step + 1) * step - 3, (4 * cs // step + 1) * step + 2, 5,
+             (nchunks - 2) * cs + 9 * cs // 10, (nchunks - 1) * cs + 17, (nchunks - 1) * cs + 4000]
+    C = len(where) + 2
+    x = np.random.default_rng(77).standard_normal((C, total))
+    for c, at in enumerate(where):
+        x[c, at] = np.nan if c != 2 else np.inf
+    x[len(where) - 1, where[-1]:] = np.nan
+    x[C - 2, (nchunks - 2) * cs + 100] = np.nan
+    src = producer(x, cs, axis=-1)
+    fir = producer(partial(nm.oaconvolve, src, h, -1, "same"), cs, axis=-1, shape=x.shape)
+    y = np.concatenate(list(nm.sosfiltfilt(fir, sos, -1)), axis=-1)
+    lost = np.array([[bool((~np.isfinite(y[c, k * cs:(k + 1) * cs])).all()) for k in range(nchunks)] for c in range(C)])
+    partly = np.array([[bool((~np.isfinite(y[c, k * cs:(k + 1) * cs])).any()) for k in range(nchunks)] for c in range(C)])
+    assert np.array_equal(lost, partly)          # sosfiltfilt loses whole chunks
+    save("g19_fir_chain_nonfinite.npz", where=np.array(where, dtype=np.int64), chunksize=np.int64(cs),
+         taps=np.int64(taps_n), total=np.int64(total), step=np.int64(step), lost_chunks=lost)
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1:                      # regenerate the named blocks only
@@ -649,3 +682,4 @@ if __name__ == "__main__":
     g16_remez()
     g17_responses()
     g18_chain_long()
+    g19_fir_chain_nonfinite()

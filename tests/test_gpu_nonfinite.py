@@ -100,10 +100,14 @@ def test_nonfinite_reach_fused_chain(nm, zero_phase):
     and, with OSZ_CHAIN_ZP=0, on the two-kernel step (several runs per channel that
     start from nothing; backward pass beside it): a NaN in the input reaches the
     end of the stream in the forward half, so from the chunk before the NaN on every
-    output chunk of that channel is NaN; the other channels equal the oracle.  (How
-    far a NaN spreads inside the FIR differs from the reference by construction -- an
-    FFT block is NaN as a whole and the block lengths differ -- which is why the
-    chunks BEFORE are only required to be finite up to one chunk ahead of the NaN.)"""
+    output chunk of that channel is NaN; the other channels equal the oracle.  How far
+    a NaN spreads inside the FIR: on the zero-phase route as in the reference -- its
+    overlap-add loses the sample's whole segment of 261 121 input samples at 1024 taps,
+    i.e. the chain from up to two of these chunks before the sample (round 5:
+    osz_chain_zp_reach; the oracle runs the reference's segments) --, on the two-kernel
+    step by this library's own 4096-point blocks (an FFT block is NaN as a whole: a
+    documented divergence), which is why there the chunks BEFORE are only required to
+    be finite up to one chunk ahead of the NaN."""
     import scipy.signal as sps
     import torch
     from oracle import oracle as orc
@@ -137,17 +141,28 @@ def test_nonfinite_reach_fused_chain(nm, zero_phase):
     some_nan = np.array([[bool(np.isnan(got[c, k * cs:(k + 1) * cs]).any()) for k in range(nchunks)]
                          for c in range(C)])
     assert np.array_equal(nan_chunk, some_nan)            # a chunk is NaN as a whole or not at all
-    assert nan_chunk[9].tolist() == [False, False, True, True, True, True, True]
-    assert nan_chunk[30].tolist() == [False, False, False, False, True, True, True]
-    assert nan_chunk[50].tolist() == [False, False, True, True, True, True, True]
+    if zero_phase:
+        xb = x[[9, 30, 50]].cpu().numpy()
+        with np.errstate(invalid="ignore"):
+            wb = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xb, taps, "same"), -1), sos, cs)
+        ref_lost = [[bool(np.isnan(wb[i, k * cs:(k + 1) * cs]).all()) for k in range(nchunks)] for i in range(3)]
+        assert nan_chunk[[9, 30, 50]].tolist() == ref_lost
+        assert ref_lost[0] == [True] * 7                  # (the segment of sample 3 cs + 8000 starts in chunk 1)
+        ok = np.isfinite(wb)
+        assert np.array_equal(ok, np.isfinite(got[[9, 30, 50]]))
+        assert np.max(np.abs(got[[9, 30, 50]][ok] - wb[ok])) < RTOL * np.max(np.abs(wb[ok]))
+    else:
+        assert nan_chunk[9].tolist() == [False, False, True, True, True, True, True]
+        assert nan_chunk[30].tolist() == [False, False, False, False, True, True, True]
+        assert nan_chunk[50].tolist() == [False, False, True, True, True, True, True]
     clean = [c for c in range(C) if c not in (9, 30, 50)]
     assert not nan_chunk[clean].any()
     pick = [0, 31, 63]
     xh = x[pick].cpu().numpy()
     want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(xh, taps, "same"), -1), sos, cs)
     assert np.max(np.abs(got[pick] - want)) < RTOL * np.max(np.abs(want))
-    # and the finite chunks of the two NaN channels equal the oracle on their finite prefix
-    for c, upto in ((9, 2), (30, 4)):
+    # and (two-kernel step) the finite chunks of the two NaN channels equal the oracle on their finite prefix
+    for c, upto in (() if zero_phase else ((9, 2), (30, 4))):
         # chunks < upto see the forward output up to chunk `upto`, i.e. the input up to
         # 511 samples into the next chunk: no NaN there
         xc = x[c:c + 1, :(upto + 1) * cs + 600].cpu().numpy()
@@ -233,3 +248,67 @@ def test_nan_reach_is_decided_by_the_sample_not_by_the_block(nm):
         ok = np.isfinite(want)
         assert ok[3, :2 * cs].all() and not ok[3, 2 * cs:].any()
         assert np.max(np.abs(got[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
+
+
+@pytest.mark.parametrize("fed", ["resident", "host"])
+@pytest.mark.parametrize("taps_n, cs", [(256, 65664), (513, 65536), (1024, 131072)])
+def test_fir_chain_nan_reach_is_the_references(nm, fed, taps_n, cs):
+    """FIR -> sosfiltfilt on the one-kernel route: the reference's FIR turns a non-finite input
+    sample into a whole non-finite SEGMENT of its overlap-add (nfft - wlen + 1 input samples,
+    core/numerical.py:202-217, :258-283 -- 65 281 at 256 taps, 261 632 at 513), so its chain is
+    lost from the segment's start: up to a segment BEFORE the sample.  The kernels record the exact
+    sample, the seal counts from the segment's start (osz_chain_zp_reach) and the generator holds
+    chunks back for as long as that reach spans -- three more steps at 513 taps in chunks of
+    65 536 --; a channel that first goes bad in the stream's last two chunks has its forward
+    stream recomputed from a cleaned copy.  Masks equal to the oracle's (which runs the
+    reference's segments), values to 1e-9 where finite: a sample mid-stream, samples on either
+    side of a segment boundary, in chunk 0, in the last two chunks, an EDF-style tail, an Inf."""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    nchunks = 9
+    total = cs * (nchunks - 1) + 4321
+    taps = sps.firwin(taps_n, 0.3)
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    step = orc.oa_plan(total, taps_n)[1]
+    where = [3 * cs + 777,                         # mid-stream
+             (4 * cs // step + 1) * step - 3,      # the last samples of a segment ...
+             (4 * cs // step + 1) * step + 2,      # ... and the first of the next
+             5,                                    # chunk 0
+             (nchunks - 2) * cs + 9 * cs // 10,    # chunk n-2, behind the head the zero-phase steps see
+             (nchunks - 1) * cs + 17,              # the last chunk, first block
+             (nchunks - 1) * cs + 4000]            # the last chunk (an EDF-style tail from here on)
+    C = len(where) + 2
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((C, total))
+    for c, at in enumerate(where):
+        x[c, at] = np.nan if c != 2 else np.inf
+    x[len(where) - 1, where[-1]:] = np.nan
+    x[C - 2, (nchunks - 2) * cs + 100] = np.nan    # chunk n-2, inside that head
+    src_data = x if fed == "host" else torch.from_numpy(x).cuda()
+    steps, plain = [], dev_module().chain_zp_step
+    dev_module().chain_zp_step = lambda *a, **k: (steps.append(a[2].shape[1]), plain(*a, **k))[1]
+    try:
+        src = producer(src_data, cs, -1)
+        fir = producer(partial(nm.oaconvolve, src, taps, -1, "same"), cs, -1, shape=src.shape)
+        pieces = list(nm.sosfiltfilt(fir, sos, -1))
+    finally:
+        dev_module().chain_zp_step = plain
+    assert sum(steps) == (nchunks - 2) * cs, steps                       # the one-kernel route
+    got = np.concatenate([p if isinstance(p, np.ndarray) else p.cpu().numpy() for p in pieces], -1)
+    want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(x, taps, "same"), -1), sos, cs)
+    ok = np.isfinite(want)
+    bad_chunks = lambda a: [[bool(~np.isfinite(a[c, k * cs:(k + 1) * cs]).all()) for k in range(nchunks)] for c in range(C)]
+    assert bad_chunks(got) == bad_chunks(want)
+    if (taps_n, cs) == (256, 65664):          # the REFERENCE's own record of these placements (g19)
+        from conftest import load_golden
+        g = load_golden("g19_fir_chain_nonfinite.npz")
+        assert list(g["where"]) == where and np.array_equal(np.array(bad_chunks(got)), g["lost_chunks"])
+    assert np.array_equal(ok, np.isfinite(got))
+    assert ok[C - 1].all() and not ok[3].any()            # the clean channel; a NaN in chunk 0 loses everything
+    assert np.max(np.abs(got[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
+
+
+def dev_module():
+    from openseize_amd import _device
+    return _device

@@ -213,3 +213,27 @@ def test_oracle_chain_at_the_zero_phase_geometry(golden):
     got = orc.sosfiltfilt(u, sos, cs)
     for c in range(x.shape[0]):
         assert np.max(np.abs(got[c] - want[c])) < 1e-10 * np.max(np.abs(want[c])), c
+
+
+def test_oracle_nonfinite_reach_through_the_fir(golden):
+    """g19: which output chunks the REFERENCE's FIR -> sosfiltfilt chain loses to a non-finite input
+    sample -- its overlap-add makes the sample's whole segment non-finite (core/numerical.py:258-283),
+    so the chain is lost from up to a segment before the sample.  The oracle's restatement runs the
+    same segments: same chunks lost, for every placement."""
+    import scipy.signal as sps
+    g = golden("g19_fir_chain_nonfinite.npz")
+    where, cs, total, taps_n = g["where"], int(g["chunksize"]), int(g["total"]), int(g["taps"])
+    assert orc.oa_plan(total, taps_n)[1] == int(g["step"])
+    nchunks = -(-total // cs)
+    C = len(where) + 2
+    x = np.random.default_rng(5).standard_normal((C, total))       # (a mask depends on where the bad samples are only)
+    for c, at in enumerate(where):
+        x[c, at] = np.nan if c != 2 else np.inf
+    x[len(where) - 1, where[-1]:] = np.nan
+    x[C - 2, (nchunks - 2) * cs + 100] = np.nan
+    h = sps.firwin(taps_n, 0.3)
+    sos = sps.butter(6, [0.05, 0.3], "bandpass", output="sos")
+    with np.errstate(invalid="ignore"):
+        y = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(x, h, "same"), axis=-1), sos, cs)
+    lost = np.array([[bool((~np.isfinite(y[c, k * cs:(k + 1) * cs])).all()) for k in range(nchunks)] for c in range(C)])
+    assert np.array_equal(lost, g["lost_chunks"])
