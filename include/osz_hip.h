@@ -85,7 +85,9 @@ int osz_profile_query(const char *name, int64_t *launches, double *total_ms);
 int osz_sos_create(osz_sos_t *h, const double *sos, int nsec, int nch);
 int osz_sos_destroy(osz_sos_t h);
 /* zi/zf host arrays laid out (nsec, nch, 2) like the reference's zi argument
- * (core/numerical.py:313-329).  zi == NULL zeroes the state. Synchronous. */
+ * (core/numerical.py:313-329).  zi == NULL zeroes the state.  Synchronous -- or, handed a
+ * DEVICE array of the same layout, a copy ordered on `stream` that nothing waits for (a
+ * snapshot the caller may never need: core/numerical.py's zero-phase stream, before its end). */
 int osz_sos_set_state(osz_sos_t h, const double *zi, void *stream);
 int osz_sos_get_state(osz_sos_t h, double *zf, void *stream);
 /* zi_unit (nsec, 2) is the steady-state unit-step state the reference gets from
@@ -154,7 +156,8 @@ int osz_fir_destroy(osz_fir_t h);
 int osz_fir_reset(osz_fir_t h, void *stream);
 /* Checkpoint / resume (the de-facto state of the reference's
  * generator is the overlap tail, core/numerical.py:223, :269): the carried
- * tail(s) as osz_fir_state_size() host doubles.  Synchronous. */
+ * tail(s) as osz_fir_state_size() host doubles.  Synchronous; with a device array instead,
+ * ordered on `stream` and not waited for (as osz_sos_get_state). */
 int64_t osz_fir_state_size(osz_fir_t h);
 int osz_fir_get_state(osz_fir_t h, double *state, void *stream);
 int osz_fir_set_state(osz_fir_t h, const double *state, void *stream);

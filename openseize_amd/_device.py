@@ -552,6 +552,29 @@ class _Handle:
             raise ValueError(f"state must have {int(n)} entries, got {buf.shape}")
         _lib.check(getattr(self.lib, self._state + "_set_state")(self.h, host_dp(buf), stream_ptr()))
 
+    def _state_count(self):
+        return int(getattr(self.lib, self._state + "_state_size")(self.h))
+
+    _device_state = False  # osz_fir_* / osz_sos_*: the state calls take device arrays too
+
+    def snapshot(self):
+        """The carried state as a device tensor: a copy ordered on the current stream that
+        nothing waits for (the C ABI takes a device array in place of the host one)."""
+        if not self._device_state:
+            raise TypeError(f"{type(self).__name__}: the state holds host scalars, use get_state")
+        buf = torch.empty(self._state_count(), dtype=torch.float64, device="cuda")
+        _lib.check(getattr(self.lib, self._state + "_get_state")(
+            self.h, ctypes.cast(buf.data_ptr(), _lib.c_dp), stream_ptr()))
+        return buf
+
+    def restore(self, snap):
+        """Back to a ``snapshot`` of this handle, ordered on the current stream."""
+        if (not self._device_state or snap.shape != (self._state_count(),) or snap.dtype != torch.float64
+                or not snap.is_cuda or not snap.is_contiguous()):
+            raise ValueError("restore: not a snapshot of this handle")
+        _lib.check(getattr(self.lib, self._state + "_set_state")(
+            self.h, ctypes.cast(snap.data_ptr(), _lib.c_dp), stream_ptr()))
+
     def close(self):
         if self.h:
             getattr(self.lib, self._destroy)(self.h)
@@ -588,6 +611,12 @@ class SosStream(_Handle):
                 f"Invalid zi shape. Expected {(self.nsec, self.nch, 2)}, "
                 f"got {zi.shape}")
         _lib.check(self.lib.osz_sos_set_state(self.h, host_dp(zi), stream_ptr()))
+
+    _state = "osz_sos"
+    _device_state = True
+
+    def _state_count(self):
+        return self.nsec * self.nch * 2
 
     def get_state(self):
         zf = np.empty((self.nsec, self.nch, 2))
@@ -646,6 +675,7 @@ class FirStream(_Handle):
     """One iterator's overlap-add state (C ABI: osz_fir_*)."""
     _destroy = "osz_fir_destroy"
     _state = "osz_fir"
+    _device_state = True
 
     def __init__(self, taps, nch):
         super().__init__()

@@ -778,7 +778,8 @@ def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, 
         raise RuntimeError(f"{what}: the last chunk has {xl.shape[1]} of {n_last} samples")
     cnt = max(wlen - 1 - rcut, 0)
     F = torch.empty((C, off + lcut + cs + n_last + 2), dtype=torch.float64, device=device)
-    kept = (fir.get_state(), iir.get_state()) if ref_step else None      # (the states at the start of chunk n-2)
+    # (the states at the start of chunk n-2, should the rare path below want them: device copies, no wait)
+    kept = (fir.snapshot(), iir.snapshot()) if ref_step else None
 
     def forward_tail(xa, xb):
         """The forward stream of the last two chunks and the overhang, FIR 'full' sample
@@ -803,8 +804,8 @@ def _zero_phase_stream(fir, iir, layout, pipe, flying, first, chunks, taps, cs, 
             nonfinite = ~torch.isfinite(xa)
             at = nonfinite.to(torch.int8).argmax(1).to(torch.int64) + (nchunks - 2) * cs     # the first one per channel
             seg = torch.div(at, ref_step, rounding_mode="floor") * ref_step                   # its segment's first sample
-            fir.set_state(kept[0])
-            iir.set_state(kept[1])
+            fir.restore(kept[0])
+            iir.restore(kept[1])
             xa = torch.where(nonfinite & first_bad[:, None], torch.zeros((), dtype=xa.dtype, device=xa.device), xa)
             forward_tail(xa[:, :cs], xa[:, cs:])
             col = off + (seg - (nchunks - 2) * cs).clamp(min=0)

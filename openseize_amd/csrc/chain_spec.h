@@ -7,6 +7,7 @@
 #include "common.h"
 #include "fft4096.h"
 #include "sos_tile.h"
+#include "spec_kept.h"
 #include "spec_tables.h"
 
 namespace osz {

@@ -454,8 +454,10 @@ static int spec_build(ChainSpec *s) {
         return !(e && e[0] == '0');
     }();
     if (nega_on) {
-        const spec::TablesZp Tn = spec::build_specn(fir->htaps.data(), wlen, sos->coef, nsec, sos->warm_len <= (1 << 20),
-                                                    15360 - 1024, tol);
+        const bool forgets = sos->warm_len <= (1 << 20);
+        const spec::TablesZp Tn = spec::kept_tables(spec::kKeptSpecn, fir->htaps, sos->coef, nsec, (double)tol, forgets, [&] {
+            return spec::build_specn(fir->htaps.data(), wlen, sos->coef, nsec, forgets, 15360 - 1024, tol);
+        });
         if (Tn.eligible) {
             const size_t nl = (size_t)Tn.NM * 2;               // lambda^256: row 1 of the table
             std::vector<double> cat(Tn.L.begin() + nl, Tn.L.begin() + 2 * nl);

@@ -722,33 +722,11 @@ static int zp_get(osz_fir_s *fir, osz_sos_s *sos, ChainZp **out) {
             spec::TablesZp T;
             const double tol = sos->zp_tol > 0.0 ? sos->zp_tol : (double)spec::kTailTol;
             if (zp_nega()) {
-                // The tables of the last few (taps, cascade, tolerance) are kept: the same filters
-                // run over recording after recording, and 5 ms of long-double arithmetic per
-                // stream are 4 % of a 1e8-sample stream of 256 channels.
                 const bool forgets = sos->warm_len <= (1 << 20);
-                std::vector<double> key(fir->htaps);
-                key.insert(key.end(), sos->coef, sos->coef + 6 * (size_t)sos->nsec);
-                key.push_back(tol);
-                key.push_back(forgets ? 1.0 : 0.0);
-                static std::mutex mu;
-                static std::vector<std::pair<std::vector<double>, spec::TablesZp>> kept;
-                bool found = false;
-                {
-                    std::lock_guard<std::mutex> lock(mu);
-                    for (const auto &e : kept)
-                        if (e.first == key) {
-                            T = e.second;
-                            found = true;
-                            break;
-                        }
-                }
-                if (!found) {
-                    T = spec::build_zpn(fir->htaps.data(), fir->ntaps, sos->coef, sos->nsec, forgets, 15360 - 1024,
-                                        (spec::ld_t)tol);
-                    std::lock_guard<std::mutex> lock(mu);
-                    if (kept.size() >= 8) kept.erase(kept.begin());
-                    kept.emplace_back(std::move(key), T);
-                }
+                T = spec::kept_tables(spec::kKeptZpn, fir->htaps, sos->coef, sos->nsec, tol, forgets, [&] {
+                    return spec::build_zpn(fir->htaps.data(), fir->ntaps, sos->coef, sos->nsec, forgets, 15360 - 1024,
+                                           (spec::ld_t)tol);
+                });
                 s->nega = T.eligible;
             }
             if (!T.eligible)

@@ -30,6 +30,17 @@ int fail(int code, const char *fmt, ...);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Where a caller's state array lives: the get/set_state entry points take host arrays (and wait
+// for the copy) or device arrays (the copy is ordered on the stream, nothing waits).
+inline bool on_device(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();               // plain host memory: not an error of ours
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: this
 // sets it once per (kernel, device) pair (mutex-guarded map in lib.hip).
 int ensure_dyn_lds(const void *kern, size_t bytes);

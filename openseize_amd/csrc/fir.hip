@@ -698,25 +698,28 @@ int64_t osz_fir_state_size(osz_fir_t h) {
     return n;
 }
 
-static int fir_state_copy(osz_fir_t h, double *host, bool to_host, hipStream_t st) {
-    double *p = host;
+static int fir_state_copy(osz_fir_t h, double *state, bool out, hipStream_t st) {
+    const bool dev = on_device(state);
+    double *p = state;
+    auto copy = [&](double *own, size_t n) -> int {
+        if (out)
+            OSZ_HIP(hipMemcpyAsync(p, own, sizeof(double) * n, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+        else
+            OSZ_HIP(hipMemcpyAsync(own, p, sizeof(double) * n, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        p += n;
+        return OSZ_OK;
+    };
     for (auto &pt : h->parts) {
         const size_t n = (size_t)h->nch * (pt.ntaps - 1);
         if (n == 0) continue;
-        if (to_host)
-            OSZ_HIP(hipMemcpyAsync(p, pt.dstate[pt.cur], sizeof(double) * n, hipMemcpyDeviceToHost, st));
-        else
-            OSZ_HIP(hipMemcpyAsync(pt.dstate[pt.cur], p, sizeof(double) * n, hipMemcpyHostToDevice, st));
-        p += n;
+        int rc = copy(pt.dstate[pt.cur], n);
+        if (rc) return rc;
     }
     if (h->dlen > 0) {
-        const size_t n = (size_t)h->nch * h->dlen;
-        if (to_host)
-            OSZ_HIP(hipMemcpyAsync(p, h->dD, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-        else
-            OSZ_HIP(hipMemcpyAsync(h->dD, p, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        int rc = copy(h->dD, (size_t)h->nch * h->dlen);
+        if (rc) return rc;
     }
-    OSZ_HIP(hipStreamSynchronize(st));
+    if (!dev) OSZ_HIP(hipStreamSynchronize(st));
     return OSZ_OK;
 }
 

@@ -1451,12 +1451,13 @@ int osz_sos_set_state(osz_sos_t h, const double *zi, void *stream) {
         int rc = spec_touch(h->spec, st);
         if (rc) return rc;
     }
+    const bool dev = zi && on_device(zi);
     if (zi) {
-        OSZ_HIP(hipMemcpyAsync(h->dstate, zi, sb, hipMemcpyHostToDevice, st));
+        OSZ_HIP(hipMemcpyAsync(h->dstate, zi, sb, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     } else {
         OSZ_HIP(hipMemsetAsync(h->dstate, 0, sb, st));
     }
-    OSZ_HIP(hipStreamSynchronize(st));
+    if (!dev) OSZ_HIP(hipStreamSynchronize(st));
     return OSZ_OK;
 }
 
@@ -1468,8 +1469,9 @@ int osz_sos_get_state(osz_sos_t h, double *zf, void *stream) {
         int rc = spec_settle(h->spec, st);
         if (rc) return rc;
     }
-    OSZ_HIP(hipMemcpyAsync(zf, h->dstate, sb, hipMemcpyDeviceToHost, st));
-    OSZ_HIP(hipStreamSynchronize(st));
+    const bool dev = on_device(zf);
+    OSZ_HIP(hipMemcpyAsync(zf, h->dstate, sb, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    if (!dev) OSZ_HIP(hipStreamSynchronize(st));
     return OSZ_OK;
 }
 

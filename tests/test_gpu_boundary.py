@@ -108,6 +108,34 @@ def test_checkpoint_resume_all_iterators():
     f.close()
 
 
+def test_state_snapshots_on_the_device():
+    """osz_fir_* / osz_sos_*_state handed a DEVICE array: the same numbers as the host array,
+    and a handle restored from the snapshot repeats its output bit for bit; the polyphase
+    handle's state starts with host scalars and says so."""
+    import scipy.signal as sps
+    import torch
+    from openseize_amd import _device as dev
+    C, n = 5, 40_000
+    x = dev.synth_normal(C, 2 * n, seed=43)
+    f = dev.FirStream(sps.firwin(255, 0.2), C)
+    s = dev.SosStream(sps.butter(4, [0.1, 0.3], "bandpass", output="sos"), C)
+    for h in (f, s):
+        run = (lambda a: h.push(a)) if h is f else (lambda a: h.forward(a))
+        run(x[:, :n].contiguous())
+        snap = h.snapshot()
+        assert snap.is_cuda and np.array_equal(snap.cpu().numpy().ravel(), np.asarray(h.get_state()).ravel())
+        first = run(x[:, n:].contiguous()).clone()
+        h.restore(snap)
+        assert torch.equal(run(x[:, n:].contiguous()), first)
+        with pytest.raises(ValueError):
+            h.restore(snap[:-1])
+        h.close()
+    p = dev.PolyStream(sps.firwin(91, 1 / 3), 3, 2, C)
+    with pytest.raises(TypeError):
+        p.snapshot()
+    p.close()
+
+
 def test_psd_device_input_stays_on_device():
     """psd() of a CUDA tensor returns a CUDA tensor averaged on the device
     (osz_spec_mean_device) and equals the host-input result."""
