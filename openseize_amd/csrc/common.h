@@ -131,6 +131,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *base) {
 __device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, row_bytes, 0));
 }
+// (non-temporal: the last read of a line that other lines are wanted in the cache after)
+__device__ __forceinline__ double buf_load_nt(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, row_bytes, 2));
+}
 __device__ __forceinline__ buf_d2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes) {
     return __builtin_bit_cast(buf_d2, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, row_bytes, 0));
 }

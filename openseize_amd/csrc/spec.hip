@@ -1232,6 +1232,13 @@ static int specmix_run(osz_spec_s *h, const double *src, int64_t ld, void *out, 
     a.N = h->nfft;
     a.M = h->nfft / 2;
     a.npass = h->mix_npass;
+    {
+        static const bool half_on = [] {           // (OSZ_MIX_HALF=0: every segment sums both its halves, A/B runs)
+            const char *e = getenv("OSZ_MIX_HALF");
+            return !(e && e[0] == '0');
+        }();
+        a.halfcarry = half_on && 2 * h->stride == h->nwin && h->nwin == h->nfft && h->mix_radix[0] % 2 == 0;
+    }
     for (int q = 0, B = a.M; q < h->mix_npass; ++q) {
         a.radix[q] = h->mix_radix[q];
         const int S = B / a.radix[q], nblk = a.M / B;

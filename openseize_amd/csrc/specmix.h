@@ -44,6 +44,8 @@ struct Args {
     const int *pos;         // slot of Z[k] after the passes, k < M
     int64_t ldx, nseg;
     int stride, nwin, nch, nruns, N, M, npass;
+    int halfcarry;          // 50 % overlap of unpadded segments, even first radix: a segment's second half
+                            // is the next one's first half in the same threads (its sums are carried)
     int radix[kMaxPass];
     // per pass: how butterflies map to lanes (host: the cheaper of the two under the
     // ds_read_b128 bank model) and the divisor of that map with its 2^32 reciprocal
@@ -262,8 +264,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double *base, i
 constexpr unsigned kOffRange = 0x7ffffff0u;   // a byte offset beyond every row
 
 // first half: the block sums of the trend over the thread's points (the samples themselves are not
-// kept: second half), and the twiddles of the pass requested
-template <int R0, bool LINEAR, int NT>
+// kept: second half), and the twiddles of the pass requested.  The points q < R0 / 2 of a butterfly
+// are the segment's first half, the others its second half (R0 even): summed apart, and with
+// `full` false the first half is not read at all -- its sums came with the previous segment.
+template <int R0, bool LINEAR, int NT, int HALF>
 __device__ __forceinline__ void head_sums(C2 *w1, double &sum, double &lin, const double *xs,
                                           const Args &a, int t) {
     constexpr int NI = (10 + R0 - 1) / R0;
@@ -276,7 +280,7 @@ __device__ __forceinline__ void head_sums(C2 *w1, double &sum, double &lin, cons
         const int b = t + i * NT;
         const bool on = b < S0;
 #pragma unroll
-        for (int q = 0; q < R0; ++q) {
+        for (int q = HALF ? R0 / 2 : 0; q < (HALF ? R0 : R0 / 2); ++q) {
             // samples 2 j and 2 j + 1 of point j = b + q S0
             const int j = b + q * S0;
             const unsigned at = on ? 16u * (unsigned)j : kOffRange;
@@ -285,8 +289,19 @@ __device__ __forceinline__ void head_sums(C2 *w1, double &sum, double &lin, cons
             if (LINEAR) lin += (2 * j - mid) * x0 + (2 * j + 1 - mid) * x1;
         }
         // W_M^b of the pass, back by the time the barrier is behind us (tstep = N / M = 2)
-        if (i < kPreBf0) w1[i] = *reinterpret_cast<const C2 *>(a.tw + 4 * (on ? b : 0));
+        if (HALF && i < kPreBf0) w1[i] = *reinterpret_cast<const C2 *>(a.tw + 4 * (on ? b : 0));
     }
+}
+
+template <bool LINEAR, int NT, int HALF>
+__device__ __forceinline__ void head_sums_any(int r0, C2 *w1, double &sum, double &lin, const double *xs,
+                                              const Args &a, int t) {
+    if (r0 == 10) head_sums<10, LINEAR, NT, HALF>(w1, sum, lin, xs, a, t);
+    else if (r0 == 4) head_sums<4, LINEAR, NT, HALF>(w1, sum, lin, xs, a, t);
+    else if (r0 == 5) head_sums<5, LINEAR, NT, HALF>(w1, sum, lin, xs, a, t);
+    else if (r0 == 2) head_sums<2, LINEAR, NT, HALF>(w1, sum, lin, xs, a, t);
+    else if (r0 == 3) head_sums<3, LINEAR, NT, HALF>(w1, sum, lin, xs, a, t);
+    else head_sums<7, LINEAR, NT, HALF>(w1, sum, lin, xs, a, t);
 }
 
 // second half, behind the barrier: the samples once more (from L2: they came by a microsecond ago;
@@ -310,7 +325,16 @@ __device__ __forceinline__ void head_finish(C2 *z, const C2 *w1, double mean, do
             for (int q = 0; q < R0; ++q) {
                 const int j = b + q * S0;
                 const unsigned at = 16u * (unsigned)j;
-                const double x0 = buf_load(rx, at, 0), x1 = buf_load(rx, at + 8, 0);
+                // (with the usual 50 % overlap a first half is read for the last time: it shall not
+                // displace the halves still to come back; a hint, and one in the instruction's encoding:
+                // a run-time choice between the two loads spills)
+#ifdef OSZ_MIX_NO_NT     // (A/B builds only)
+                const bool last_use = false;
+#else
+                const bool last_use = q < R0 / 2;
+#endif
+                const double x0 = last_use ? buf_load_nt(rx, at, 0) : buf_load(rx, at, 0);
+                const double x1 = last_use ? buf_load_nt(rx, at + 8, 0) : buf_load(rx, at + 8, 0);
                 const double g0 = buf_load(rw, at, 0), g1 = buf_load(rw, at + 8, 0);   // 0 in the padding
                 if (LINEAR) {
                     u[q].re = (x0 - mean - slope * (2 * j - mid)) * g0;
@@ -337,11 +361,18 @@ __device__ __forceinline__ void head_finish(C2 *z, const C2 *w1, double mean, do
     }
 }
 
+// a value every thread of the workgroup holds alike, into scalar registers
+__device__ __forceinline__ double uniform(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 template <int MODE, bool LINEAR, int NT>
 __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
     extern __shared__ C2 zmix[];
     constexpr int NWV = (NT + 63) / 64;
-    __shared__ double red[NWV][2];
+    __shared__ double red[NWV][4];
     C2 *z = zmix;
     const int t = threadIdx.x;
     const int run = blockIdx.x;
@@ -355,36 +386,57 @@ __global__ __launch_bounds__(NT, 4) void specmix_kernel(Args a) {
 #pragma unroll
     for (int m = 0; m < kAcc; ++m) acc[m] = 0.0;
 
+    double carry_sum = 0.0, carry_lin = 0.0;     // sums over the previous segment's second half
     for (int64_t s = s0; s < s1; ++s) {
         const double *xs = xr + s * (int64_t)a.stride;
         // ---- samples, trend, window and the first pass: one LDS store per point (head_sums / head_finish)
         {
             const int r0 = a.radix[0];
             C2 w0[kPreBf0];
-            double sum = 0.0, lin = 0.0;
+            const bool full = !a.halfcarry || s == s0;
             // opaque thread index, again before every phase: hoisted out of the segment loop, the
             // addresses / masks / ramp values of all a thread's points would spill
             int tt = t;
             asm volatile("" : "+v"(tt));
-            if (r0 == 10) head_sums<10, LINEAR, NT>(w0, sum, lin, xs, a, tt);
-            else if (r0 == 4) head_sums<4, LINEAR, NT>(w0, sum, lin, xs, a, tt);
-            else if (r0 == 5) head_sums<5, LINEAR, NT>(w0, sum, lin, xs, a, tt);
-            else if (r0 == 2) head_sums<2, LINEAR, NT>(w0, sum, lin, xs, a, tt);
-            else if (r0 == 3) head_sums<3, LINEAR, NT>(w0, sum, lin, xs, a, tt);
-            else head_sums<7, LINEAR, NT>(w0, sum, lin, xs, a, tt);
-            sum = wave_sum63(sum);
-            if (LINEAR) lin = wave_sum63(lin);
-            if ((t & 63) == 63) {
-                red[t >> 6][0] = sum;
-                red[t >> 6][1] = lin;
+            if (full) {
+                double sum = 0.0, lin = 0.0;
+                head_sums_any<LINEAR, NT, 0>(r0, w0, sum, lin, xs, a, tt);
+                sum = wave_sum63(sum);
+                if (LINEAR) lin = wave_sum63(lin);
+                if ((t & 63) == 63) {
+                    red[t >> 6][0] = sum;
+                    red[t >> 6][1] = lin;
+                }
+            }
+            {
+                double sum = 0.0, lin = 0.0;
+                head_sums_any<LINEAR, NT, 1>(r0, w0, sum, lin, xs, a, tt);
+                sum = wave_sum63(sum);
+                if (LINEAR) lin = wave_sum63(lin);
+                if ((t & 63) == 63) {
+                    red[t >> 6][2] = sum;
+                    red[t >> 6][3] = lin;
+                }
             }
             __syncthreads();   // (also: the bin reads of the previous segment are done)
-            double tot = 0.0, tlin = 0.0;
+            double totA = 0.0, linA = 0.0, totB = 0.0, linB = 0.0;
 #pragma unroll
             for (int q = 0; q < NWV; ++q) {
-                tot += red[q][0];
-                if (LINEAR) tlin += red[q][1];
+                totA += red[q][0];
+                totB += red[q][2];
+                if (LINEAR) {
+                    linA += red[q][1];
+                    linB += red[q][3];
+                }
             }
+            if (!full) {
+                // the previous segment's second half, nwin / 2 samples further left in this one
+                totA = carry_sum;
+                linA = carry_lin - 0.5 * a.nwin * carry_sum;
+            }
+            carry_sum = uniform(totB);      // (the same in every thread: scalar registers)
+            if (LINEAR) carry_lin = uniform(linB);
+            const double tot = totA + totB, tlin = linA + linB;
             const double mean = tot / a.nwin;
             double slope = 0.0;
             if (LINEAR) {
