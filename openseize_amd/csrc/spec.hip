@@ -27,6 +27,7 @@
 #include "fft4096.h"
 #include "fft8.h"
 #include "specmix.h"
+#include "specsplit.h"
 #include "nega_window.h"
 
 namespace osz {
@@ -1014,9 +1015,12 @@ struct osz_spec_s {
     bool fused;          // nwin == nfft == 4096: on-chip path (spec_cube_kernel)
     bool fused8;         // nfft = 512 ... 8192, a power of two: on-chip path (spec8_kernel)
     const double *tab8;  // twiddle table of fft8.h
-    bool mixed;          // even nfft = 2 * (product of 2, 3, 5) <= 20480: on-chip path (specmix_kernel)
+    bool mixed;          // even nfft = 2 * (product of 2, 3, 5) <= 20412: on-chip path (specmix_kernel)
     int mix_npass, mix_radix[mix::kMaxPass];
+    bool split;          // even nfft whose half is beyond the LDS, nfft / 2 = R0 S0: specsplit_kernel
+    int split_r0, split_s0;
     int mix_blkfast[mix::kMaxPass];   // lane map per pass (specmix_lane_maps)
+    int mix_blkfast1[mix::kMaxPass];  // specsplit.h: of a self-paired workgroup's S0 points
     bool blue;           // any other nfft <= 4096: Bluestein on the fft8 transforms (spec_blue_kernel)
     int blue_m;          // its convolution length, a power of two >= 2 nfft - 1 (>= 512)
     double *dchirp;      // [blue_m][2]: w[j] = exp(-i pi j^2 / nfft), zeros behind nfft
@@ -1137,10 +1141,11 @@ static int specmix_read_cycles(const int *slot, const bool *active) {
 
 // For every pass: do consecutive lanes walk one block (inner index fastest) or
 // the blocks (block index fastest)?  Whichever reads with fewer bank conflicts.
-static void specmix_lane_maps(osz_spec_s *h) {
-    const int M = h->nfft / 2, NT = specmix_threads(M);
-    int B = M;
-    for (int p = 0; p < h->mix_npass; ++p) {
+// (M points in LDS, the passes from p0 on, the first of them over blocks of B0 points)
+static void specmix_lane_maps(osz_spec_s *h, int M, int B0, int p0, int *blkfast) {
+    const int NT = specmix_threads(M);
+    int B = B0;
+    for (int p = p0; p < h->mix_npass; ++p) {
         const int r = h->mix_radix[p], S = B / r, nb = M / r, nblk = M / B;
         long cost[2] = {0, 0};
         for (int mode = 0; mode < 2; ++mode)
@@ -1162,14 +1167,17 @@ static void specmix_lane_maps(osz_spec_s *h) {
                 }
             }
         (void)NT;
-        h->mix_blkfast[p] = cost[1] < cost[0] ? 1 : 0;
+        blkfast[p] = cost[1] < cost[0] ? 1 : 0;
         B = S;
     }
 }
 
 static int specmix_tables(osz_spec_s *h) {
-    specmix_lane_maps(h);
-    const int N = h->nfft, M = N / 2;
+    const int N = h->nfft;
+    // the whole half in LDS, or (specsplit.h) two of its R0 sub-transforms: their passes, their output slots
+    const int M = h->split ? h->split_s0 : N / 2, p0 = h->split ? 1 : 0;
+    specmix_lane_maps(h, h->split ? 2 * M : M, M, p0, h->mix_blkfast);
+    if (h->split) specmix_lane_maps(h, M, M, p0, h->mix_blkfast1);
     const long double PI = acosl(-1.0L);
     std::vector<double> tw(2 * (size_t)N);
     for (int j = 0; j < N; ++j) {
@@ -1180,7 +1188,7 @@ static int specmix_tables(osz_spec_s *h) {
     std::vector<int> pos(M);
     for (int k = 0; k < M; ++k) {
         int kk = k, S = M, p = 0;
-        for (int q = 0; q < h->mix_npass; ++q) {
+        for (int q = p0; q < h->mix_npass; ++q) {
             const int r = h->mix_radix[q];
             S /= r;
             p += (kk % r) * S;
@@ -1267,6 +1275,131 @@ static int specmix_run(osz_spec_s *h, const double *src, int64_t ld, void *out, 
         case 256: rc = specmix_launch_nt<256>(h, a, st); break;
         case 512: rc = specmix_launch_nt<512>(h, a, st); break;
         default: rc = specmix_launch_nt<1024>(h, a, st); break;
+    }
+    if (rc) return rc;
+    OSZ_HIP(hipGetLastError());
+    if (h->mode == OSZ_SPEC_PSD_MEAN) {
+        hipLaunchKernelGGL(spec_partial_reduce_n_kernel, dim3((h->nfreq + 255) / 256, h->nch), dim3(256),
+                           0, st, h->dpartial, h->dsum, (int)nruns, h->nfreq);
+        OSZ_HIP(hipGetLastError());
+    }
+    return OSZ_OK;
+}
+
+
+// ---- lengths whose half is beyond the LDS (specsplit.h) ------------------------------------
+// nfft / 2 = R0 S0 with the smallest R0 whose PAIR of S0-point transforms fits the LDS, S0 a
+// product of 2, 3, 5, 7 (the fewer workgroups read a segment the better; R0 itself is any
+// divisor up to 32: its pass is evaluated directly).  radix[0] = R0, radix[1 ..] = the plan of S0.
+static bool specsplit_plan(int nfft, int *r0, int *npass, int *radix) {
+    if (nfft < 4 || (nfft & 1)) return false;
+    const int M = nfft / 2;
+    if (M <= mix::kMaxM) return false;
+    static const int local_max = [] {           // (OSZ_SPLIT_LOCAL: fewer local points, more workgroups per segment)
+        const char *e = getenv("OSZ_SPLIT_LOCAL");
+        const int v = e ? atoi(e) : 0;
+        return v >= 1282 && v < mix::kMaxSplitLocal ? v : mix::kMaxSplitLocal;
+    }();
+    for (int R = 2; R <= mix::kMaxSplitR0; ++R) {
+        if (M % R) continue;
+        const int S0 = M / R;
+        if (2 * S0 > local_max || 2 * S0 <= 1280) continue;      // (three workgroup sizes are built)
+        int np = 0, rad[mix::kMaxPass];
+        if (!specmix_plan(2 * S0, &np, rad) || np + 1 > mix::kMaxPass) continue;
+        radix[0] = R;
+        for (int q = 0; q < np; ++q) radix[q + 1] = rad[q];
+        *npass = np + 1;
+        *r0 = R;
+        return true;
+    }
+    return false;
+}
+
+template <int NT>
+static int specsplit_launch_nt(osz_spec_s *h, const mix::SplitArgs &g, int64_t nblocks, hipStream_t st) {
+    using kern_t = void (*)(mix::SplitArgs);
+    static const kern_t ks[3][2] = {
+        {mix::specsplit_kernel<0, false, NT>, mix::specsplit_kernel<0, true, NT>},
+        {mix::specsplit_kernel<1, false, NT>, mix::specsplit_kernel<1, true, NT>},
+        {mix::specsplit_kernel<2, false, NT>, mix::specsplit_kernel<2, true, NT>}};
+    const kern_t k = ks[h->mode][h->detrend == OSZ_DETREND_LINEAR ? 1 : 0];
+    const size_t lds = sizeof(mix::C2) * 2 * (size_t)g.S0;
+    OSZ_DYN_LDS(k, lds);
+    KernelTimer kt("spec_fused", st);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT), lds, st, g);
+    return OSZ_OK;
+}
+
+// one launch of specsplit_kernel over nseg segments of a contiguous source
+static int specsplit_run(osz_spec_s *h, const double *src, int64_t ld, void *out, int64_t nseg,
+                         hipStream_t st) {
+    const int R0 = h->split_r0, S0 = h->split_s0, NW = (R0 + 1) / 2, Ml = 2 * S0;     // the pairs and the self-paired
+    // segments per run: long runs (a run's first segment sums both its halves) while a few
+    // rounds of workgroups remain
+    int64_t R = (nseg * h->nch * NW) / 2048;
+    if (R > 64) R = 64;
+    if (R < 1) R = 1;
+    const int64_t nruns = (nseg + R - 1) / R;
+    mix::SplitArgs g{};
+    mix::Args &a = g.a;
+    a.x = src;
+    a.window = h->dwindow;
+    a.out = out;
+    a.tw = h->dtwn;
+    a.pos = h->dpos;
+    a.ldx = ld;
+    a.nseg = nseg;
+    a.stride = h->stride;
+    a.nwin = h->nwin;
+    a.nch = h->nch;
+    a.nruns = (int)nruns;
+    a.N = h->nfft;
+    a.M = h->nfft / 2;
+    a.npass = h->mix_npass;
+    {
+        static const bool half_on = [] {
+            const char *e = getenv("OSZ_MIX_HALF");
+            return !(e && e[0] == '0');
+        }();
+        a.halfcarry = half_on && 2 * h->stride == h->nwin && h->nwin == h->nfft && a.M % 2 == 0;
+    }
+    a.radix[0] = R0;
+    for (int q = 1, B = S0; q < h->mix_npass; ++q) {
+        a.radix[q] = h->mix_radix[q];
+        const int S = B / a.radix[q], nblk = Ml / B;
+        a.blkfast[q] = h->mix_blkfast[q];
+        a.div[q] = a.blkfast[q] ? nblk : S;
+        a.inv[q] = a.div[q] > 1 ? (unsigned)(((1ull << 32) + a.div[q] - 1) / a.div[q]) : 0u;
+        g.blkfast1[q] = h->mix_blkfast1[q];
+        g.div1[q] = g.blkfast1[q] ? S0 / B : S;
+        g.inv1[q] = g.div1[q] > 1 ? (unsigned)(((1ull << 32) + g.div1[q] - 1) / g.div1[q]) : 0u;
+        B = S;
+    }
+    a.scale = h->scale;
+    g.R0 = R0;
+    g.S0 = S0;
+    g.NW = NW;
+    g.nunits = (int)(nruns * h->nch);
+    if (h->mode == OSZ_SPEC_PSD_MEAN) {
+        const int64_t need = (int64_t)h->nch * nruns * h->nfreq;
+        if (need > h->partial_cap) {
+            OSZ_HIP(hipStreamSynchronize(st));
+            (void)hipFree(h->dpartial);
+            h->dpartial = nullptr;
+            if (hipMalloc(&h->dpartial, sizeof(double) * need) != hipSuccess)
+                return fail(OSZ_ERR_NOMEM, "osz_spec_push: partial sums (%lld doubles)", (long long)need);
+            h->partial_cap = need;
+        }
+        a.partial = h->dpartial;
+    }
+    // workgroup ids: eight XCDs x (groups of units) x NW, specsplit.h
+    const int64_t nblocks = ((int64_t)g.nunits + 7) / 8 * NW * 8;
+    int rc;
+    switch (specmix_threads(Ml)) {
+        case 256: rc = specsplit_launch_nt<256>(h, g, nblocks, st); break;
+        case 512: rc = specsplit_launch_nt<512>(h, g, nblocks, st); break;
+        case 1024: rc = specsplit_launch_nt<1024>(h, g, nblocks, st); break;
+        default: return fail(OSZ_ERR_STATE, "specsplit_run: %d local points", Ml);
     }
     if (rc) return rc;
     OSZ_HIP(hipGetLastError());
@@ -1422,6 +1555,7 @@ static int blue_run(osz_spec_s *h, const double *src, int64_t ld, void *out, int
 static int spec8_run(osz_spec_s *h, const double *src, int64_t ld, void *out, int64_t nseg,
                      hipStream_t st) {
     if (h->mixed) return specmix_run(h, src, ld, out, nseg, st);
+    if (h->split) return specsplit_run(h, src, ld, out, nseg, st);
     if (h->blue) return blue_run(h, src, ld, out, nseg, st);
     const int64_t npairs = (nseg + 1) / 2;
     // runs: enough workgroups for a few rounds of the chip, long enough that the
@@ -1568,7 +1702,12 @@ int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride, const double 
         p->dpos = nullptr;
         p->mixed = !p->fused && !p->fused8 && !(em && atoi(em) == 0) &&
                    specmix_plan(nfft, &p->mix_npass, p->mix_radix);
-        if (p->mixed) {
+        // its half beyond the LDS: two of its R0 sub-transforms per workgroup (OSZ_SPEC_SPLIT=0: the staging route)
+        const char *es = getenv("OSZ_SPEC_SPLIT");
+        p->split = !p->fused && !p->fused8 && !p->mixed && !(em && atoi(em) == 0) && !(es && atoi(es) == 0) &&
+                   specsplit_plan(nfft, &p->split_r0, &p->mix_npass, p->mix_radix);
+        p->split_s0 = p->split ? nfft / 2 / p->split_r0 : 0;
+        if (p->mixed || p->split) {
             int rc = specmix_tables(p);
             if (rc) { (void)hipFree(p->dtwn); (void)hipFree(p->dpos); delete p->plans; delete p; return rc; }
         }
@@ -1644,7 +1783,7 @@ int osz_spec_push(osz_spec_t h, const double *x, int64_t ldx, int64_t n, void *o
     const int64_t total = h->ncarry + n;
     const int64_t nseg = osz_spec_seg_count(h, n);
     OSZ_REQUIRE(nseg == 0 || h->mode == OSZ_SPEC_PSD_MEAN || out, "osz_spec_push: null output");
-    if (nseg > 0 && (h->fused8 || h->mixed || h->blue)) {
+    if (nseg > 0 && (h->fused8 || h->mixed || h->split || h->blue)) {
         int rc = spec8_push(h, x, ldx, n, out, nseg, st);
         if (rc) return rc;
         h->count += nseg;

@@ -33,7 +33,7 @@ struct alignas(16) C2 {
 
 constexpr int kMaxPass = 14;   // 2^13 * ... : M <= 10240 needs at most 7 radix-4/2 passes
 constexpr int kAcc = 12;       // PSD sums per thread: bins t + NT m, m < kAcc
-constexpr int kMaxM = 10240;   // 160 KB of LDS
+constexpr int kMaxM = 10208;   // 16 B a point and the reduction's 512 B in 160 KB of LDS (nfft <= 20 412 = 2^2 3^6 7)
 
 struct Args {
     const double *x;        // one contiguous source: segment s starts at column s * stride

@@ -5,8 +5,9 @@ nfft whose half is a product of 2, 3, 5 and 7 -- what nfft = int(fs / resolution
 whole-array SciPy and the rocFFT route of this library (OSZ_SPEC_MIX=0), for
 PSD mean / PSD segments / STFT segments, both detrends, short windows, any
 overlap, chunked pushes.  Lengths the plan cannot factor take the chirp transform up to 4096
-(BLUE_SIZES); above that (odd, a prime factor above 7) and above 20 480 they stay on rocFFT and
-are checked by value.
+(BLUE_SIZES); even lengths whose half is beyond the LDS run as pairs of sub-transforms
+(csrc/specsplit.h, SPLIT_SIZES); what is left (odd above 4096, a large prime in the way) stays on
+rocFFT and is checked by value.
 """
 
 import os
@@ -21,6 +22,9 @@ SIZES = (96, 200, 500, 600, 1000, 1500, 2000, 5000, 10000, 20000, 98, 700, 1400,
 # lengths the mixed-radix plan cannot factor, up to 4096: Bluestein's chirp transform on the fft8
 # transforms (spec_blue_kernel) -- odd, prime, a factor 11, one below a power of two, tiny
 BLUE_SIZES = (347, 1001, 694, 2200, 3001, 4095, 2049, 129, 63, 22)
+# nfft / 2 = R0 S0 beyond the LDS (specsplit_kernel): R0 = 4 (512 threads), 3, 4, 11 (a prime first
+# pass), 5, 8, 9, 10
+SPLIT_SIZES = (20480, 30000, 32768, 44000, 50000, 65536, 88200, 100000)
 
 
 def rel_err(a, b):
@@ -56,7 +60,7 @@ class rocfft_route:
             os.environ["OSZ_SPEC_MIX"] = self.old
 
 
-@pytest.mark.parametrize("nfft", SIZES + BLUE_SIZES)
+@pytest.mark.parametrize("nfft", SIZES + BLUE_SIZES + SPLIT_SIZES)
 def test_psd_all_sizes_vs_oracle(nfft):
     """psd() with fs = nfft, resolution 1: host-fed in ragged chunks (the carry
     of every push feeds the head segments) and device-resident; the rocFFT
@@ -94,7 +98,7 @@ def test_psd_all_sizes_vs_oracle(nfft):
     assert cnt == rc and rel_err(p, rp) < RTOL
 
 
-@pytest.mark.parametrize("nfft", SIZES + BLUE_SIZES)
+@pytest.mark.parametrize("nfft", SIZES + BLUE_SIZES + SPLIT_SIZES)
 def test_stft_and_welch_segments_all_sizes(nfft):
     """STFT (complex segments) and the per-segment Welch producer."""
     import scipy.signal as sps
@@ -121,7 +125,8 @@ def test_short_window_padded_to_nfft():
     import scipy.signal as sps
     from openseize_amd.core import numerical as nm
     rng = np.random.default_rng(11)
-    for n, nfft in ((700, 1000), (300, 500), (5000, 10000), (2049, 6000), (1, 96), (300, 347), (2500, 3001), (7, 1001)):
+    for n, nfft in ((700, 1000), (300, 500), (5000, 10000), (2049, 6000), (1, 96), (300, 347), (2500, 3001), (7, 1001),
+                    (30000, 50000), (12345, 65536)):
         x = rng.standard_normal((4, n)) + 1.0
         for detrend in ("constant", "linear"):
             for scaling in ("density", "spectrum"):
@@ -136,12 +141,12 @@ def test_short_window_padded_to_nfft():
 
 
 def test_lengths_the_plan_leaves_to_rocfft():
-    """Above 4096 and not a product of 2, 3, 5, 7 (a prime, an odd length, twice a prime),
-    nfft / 2 above the LDS: the staging route answers, and it matches SciPy."""
+    """Above 4096 and not a product of 2, 3, 5, 7 (a prime, an odd length, twice a prime, below and
+    beyond the LDS): the staging route answers, and it matches SciPy."""
     import scipy.signal as sps
     from openseize_amd.core import numerical as nm
     rng = np.random.default_rng(3)
-    for nfft in (4099, 5001, 8198, 30000):
+    for nfft in (4099, 5001, 8198, 20014, 70001):
         x = rng.standard_normal((2, 4 * nfft + 50))
         freqs, pro = nm.welch(producer(x, 2 * nfft + 5, -1), float(nfft), nfft, "hann", 0.5, -1,
                               "constant", "density")
@@ -202,7 +207,8 @@ def test_which_route_a_length_takes():
             out[name] = n.value
         return out
 
-    for nfft in (1400, 347, 3001, 4095):
+    # (20 412: the longest whose half the LDS takes; 20 480, 50 000: pairs of sub-transforms)
+    for nfft in (1400, 347, 3001, 4095, 20412, 20480, 50000):
         got = launches(nfft)
         assert got["spec_fused"] > 0 and got["spec_rocfft"] == 0, (nfft, got)
     got = launches(4099)
