@@ -105,8 +105,10 @@ def main():
                 from openseize_amd.spectra.estimators import stft
                 fs = float(rng.choice([250, 500, 1000, 173.61, 700, 1111]))
                 res = float(rng.choice([0.5, 1.0, 2.0]))
+                if rng.random() < 0.1:
+                    fs, res = float(rng.choice([10240, 25000, 32768, 22000])), float(rng.choice([0.5, 1.0]))
                 nfft = int(fs / res)
-                n = interesting_length(rng, 3 * nfft, 40000)
+                n = interesting_length(rng, 3 * nfft, max(40000, 4 * nfft))
                 x = rng.standard_normal((int(rng.integers(1, 4)), n))
                 ov = float(rng.choice([0.25, 0.5, 0.75]))
                 b, pd_ = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
@@ -254,8 +256,11 @@ def main():
             elif kind == 4:    # psd
                 fs = float(rng.choice([250, 500, 1000, 4096, 173.61, 700, 1111, 3001]))
                 res = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
+                if rng.random() < 0.15:      # halves beyond the LDS (specsplit.h), some left to rocFFT
+                    fs = float(rng.choice([10240, 15000, 22050, 25000, 32768, 22000, 10007]))
+                    res = float(rng.choice([0.5, 1.0]))
                 nfft = int(fs / res)
-                n = interesting_length(rng, 3 * nfft, 120000)
+                n = interesting_length(rng, 3 * nfft, max(120000, 5 * nfft))
                 x, axis = case_array(rng, n)
                 ov = float(rng.choice([0.0, 0.25, 0.5, 0.75]))
                 det = ("constant", "linear")[int(rng.integers(0, 2))]

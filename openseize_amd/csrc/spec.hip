@@ -1294,7 +1294,11 @@ static int specmix_run(osz_spec_s *h, const double *src, int64_t ld, void *out, 
 static bool specsplit_plan(int nfft, int *r0, int *npass, int *radix) {
     if (nfft < 4 || (nfft & 1)) return false;
     const int M = nfft / 2;
-    if (M <= mix::kMaxM) return false;
+    static const int from = [] {                // (OSZ_SPLIT_FROM: halves above this many points are split, timing runs)
+        const char *e = getenv("OSZ_SPLIT_FROM");
+        return e ? atoi(e) : mix::kMaxM;
+    }();
+    if (M <= from) return false;
     static const int local_max = [] {           // (OSZ_SPLIT_LOCAL: fewer local points, more workgroups per segment)
         const char *e = getenv("OSZ_SPLIT_LOCAL");
         const int v = e ? atoi(e) : 0;
@@ -1700,7 +1704,8 @@ int osz_spec_create(osz_spec_t *h, int nwin, int nfft, int stride, const double 
         const char *em = getenv("OSZ_SPEC_MIX");
         p->dtwn = nullptr;
         p->dpos = nullptr;
-        p->mixed = !p->fused && !p->fused8 && !(em && atoi(em) == 0) &&
+        const char *ef = getenv("OSZ_SPLIT_FROM");
+        p->mixed = !p->fused && !p->fused8 && !(em && atoi(em) == 0) && !(ef && nfft / 2 > atoi(ef)) &&
                    specmix_plan(nfft, &p->mix_npass, p->mix_radix);
         // its half beyond the LDS: two of its R0 sub-transforms per workgroup (OSZ_SPEC_SPLIT=0: the staging route)
         const char *es = getenv("OSZ_SPEC_SPLIT");
