@@ -75,12 +75,13 @@ def main():
 
     # nfft = 2 fs of the reference's default resolution at fs = 500 ... 10 000 Hz:
     # the mixed-radix on-chip kernel (specmix.h) against the rocFFT staging route
-    for nf in ((10000,) if subset else (1000, 2000, 5000, 10000, 20000)):
+    # (50 000, 65 536: halves beyond the LDS, pairs of sub-transforms -- specsplit.h)
+    for nf in ((10000, 50000) if subset else (1000, 2000, 5000, 10000, 20000, 50000, 65536)):
         wn = sps.get_window("hann", nf)
         sc = float(np.sqrt(1 / (float(nf) * np.sum(wn ** 2))))
-        for route in ("specmix kernel", "rocFFT route"):
+        for route in ("specmix kernel" if nf <= 20412 else "specsplit kernel", "rocFFT route"):
             if route == "rocFFT route":
-                if subset or nf not in (1000, 10000):
+                if subset or nf not in (1000, 10000, 50000):
                     continue
                 os.environ["OSZ_SPEC_MIX"] = "0"
             spm = dev.SpecStream(nf, nf, nf // 2, wn, sc, "constant", _lib.SPEC_PSD_MEAN, CH)

@@ -116,7 +116,8 @@ __device__ __forceinline__ void dft<5>(C2 *v) {
 //   X[j], X[R-j] = (v[0] + sum_k cos(2 pi j k / R) t_k)  -/+  i sum_k sin(2 pi j k / R) d_k,
 // with the table index j k mod R folded at compile time (cos is even, sin odd about R / 2).
 // (Radix 11 and 13 passes were tried: 52 + 48 registers of operands spill under the kernel's
-// cap of 128; those lengths stay on the rocFFT route.)
+// cap of 128; those lengths stay on the rocFFT route.  So does a radix-16 pass for the powers
+// of two -- 16 points and their 15 twiddle powers: 44-86 spilled registers in the PSD kernels.)
 template <int R>
 struct OddTw;
 template <> struct OddTw<7> {
