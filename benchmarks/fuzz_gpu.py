@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 15
+        kind = it % 16
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -219,6 +219,37 @@ def main():
                 else:
                     e = float(np.max(np.abs(got_[ok] - ref_[ok])) / np.max(np.abs(ref_[ok]))) if ok.any() else 0.0
                 what = f"chain nonfinite taps={taps} C={C} cs={cs} total={total} resident={torch.is_tensor(data)}"
+            elif kind == 15:   # non-finite samples through oaconvolve alone: the reference's segments
+                taps = int(rng.choice([3, 17, 64, 65, 255, 256, 1024, 2049, 2050, 3000]))
+                total = int(rng.integers(max(4 * taps, 3000), 400000))
+                C = int(rng.choice([1, 2, 3, 7]))
+                cs = int(rng.integers(max(taps, 500), total + 100))
+                h = rng.standard_normal(taps) / np.sqrt(taps)
+                mode = ("full", "same", "valid")[int(rng.integers(0, 3))]
+                xh = rng.standard_normal((C, total))
+                for _ in range(int(rng.integers(1, 5))):
+                    c, at = int(rng.integers(0, C)), int(rng.integers(0, total))
+                    r = rng.random()
+                    if r < 0.2:
+                        xh[c, at:] = np.nan
+                    elif r < 0.3:
+                        xh[c, :at] = np.nan
+                    else:
+                        xh[c, at] = np.nan if r < 0.8 else np.inf
+                if (orc.oa_plan(total, taps, 32)[0] & 1) == 0:       # (an odd fallback nfft: the reference raises)
+                    data = torch.from_numpy(xh).cuda() if rng.random() < 0.6 else xh
+                    got_ = np.concatenate([o.cpu().numpy() if torch.is_tensor(o) else o
+                                           for o in nm.oaconvolve(producer(data, cs, -1), h, -1, mode)], -1)
+                    with np.errstate(invalid="ignore"):
+                        ref_ = np.concatenate(orc.oaconvolve(xh, h, mode), -1)
+                    ok = np.isfinite(ref_)
+                    if got_.shape != ref_.shape or not np.array_equal(ok, np.isfinite(got_)):
+                        e = float("inf")
+                    else:
+                        e = float(np.max(np.abs(got_[ok] - ref_[ok])) / np.max(np.abs(ref_[ok]))) if ok.any() else 0.0
+                else:
+                    e = 0.0
+                what = f"fir nonfinite taps={taps} C={C} cs={cs} total={total} mode={mode}"
             elif kind == 13:   # plain sosfiltfilt of a long resident stream, any layout: grouped zero-phase steps
                 ndim = int(rng.integers(1, 4))
                 axis = int(rng.integers(0, ndim))

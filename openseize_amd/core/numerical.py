@@ -102,10 +102,227 @@ def _joined_resident(source, layout, gmax):
         yield held, False, sizes
 
 
+_PROBE_AT = {}
+_PROBE_SLOTS = 8192            # pinned slots of one oaconvolve stream's probes (far more than it ever has pending)
+_PROBE_POOL = []               # (pinned slots, side stream) of finished streams
+
+
+def _probe_sum(v):
+    """Sum of one sample in 2048 along the last axis and of the last one: non-finite if one of
+    them is (a block of the kernels' transforms is non-finite as a whole).  Two launches."""
+    import torch
+    n, key = v.shape[-1], (v.shape[-1], v.device)
+    idx = _PROBE_AT.get(key)
+    if idx is None:
+        if len(_PROBE_AT) > 32:
+            _PROBE_AT.clear()
+        at = list(range(0, n, 2048))
+        if at[-1] != n - 1:
+            at.append(n - 1)
+        idx = _PROBE_AT[key] = torch.tensor(at, dtype=torch.int64, device=v.device)
+    return torch.index_select(v, -1, idx).sum()
+
+
+class _Tee:
+    """A producer as ``_oaconvolve_stream`` sees it (shape, chunksize, iteration) that remembers the
+    chunks it hands on: ``seen`` gets (first sample, samples, chunk) -- references, no copies."""
+
+    def __init__(self, pro, axis, seen):
+        self.pro, self.axis, self.seen = pro, axis, seen
+        self.shape = pro.shape
+        self.chunksize = int(getattr(pro, "chunksize", 1 << 20))
+
+    def __iter__(self):
+        at = 0
+        for chunk in self.pro:
+            n = chunk.shape[self.axis]
+            if n:
+                self.seen.append((at, n, chunk))
+            at += n
+            yield chunk
+
+
 @dev.chain_aware
 def oaconvolve(pro, window, axis, mode, nfft_factor=32):
     """Streaming overlap-add convolution of a producer with a 1-D window
-    (core/numerical.py:158-298) on the device (K1, ``osz_fir_*``).
+    (core/numerical.py:158-298) on the device (K1, ``osz_fir_*``): ``_oaconvolve_stream`` below,
+    and around it the REACH of non-finite input samples as the reference has it.
+
+    The reference transforms segments of ``step = nfft - wlen + 1`` input samples (nfft =
+    8 * 2^ceil(log2 wlen) * 32, :202-217); a non-finite sample makes the whole output of ITS
+    segment non-finite -- 'full' samples [k step, (k + 1) step + wlen - 1) -- and nothing else
+    (:258-283).  The kernels here transform blocks of a few thousand samples, so their own
+    non-finite runs are shorter and start elsewhere.  The pieces are therefore held back until
+    the inputs that can still reach them have gone by (one segment: two pieces at chunks of 2^20
+    and 1024 taps), every piece is probed -- one output sample in 2048; a block of the kernels is
+    non-finite as a whole -- and only when a probe trips: the exact non-finite inputs are looked
+    up in the chunks kept by reference (``_Tee``), samples that are non-finite here but finite in
+    the reference are computed again from a cleaned copy, and the reference's segments are laid
+    over the piece.  ``OSZ_FIR_REACH=0``: the kernels' own reach (rounds 1-4).
+    """
+    if os.environ.get("OSZ_FIR_REACH", "1") == "0":
+        yield from _oaconvolve_stream(pro, window, axis, mode)
+        return
+    import torch
+    taps = np.asarray(window, dtype=np.float64)
+    nsamples = pro.shape[axis]
+    if taps.ndim != 1 or nsamples < len(taps):
+        yield from _oaconvolve_stream(pro, window, axis, mode)      # (raises, in its own words)
+        return
+    wlen = len(taps)
+    lcut, _ = _oa_cuts(wlen, mode)
+    step = _oa_reference_step(nsamples, wlen)
+    layout = dev.Layout(pro.shape, axis)
+    seen = deque()
+    inner = _oaconvolve_stream(_Tee(pro, axis, seen), window, axis, mode, probed=True)
+    pending = deque()                 # [piece, its first sample ('full' numbering), samples, probe]
+    produced = lcut                   # 'full' sample behind the last piece produced
+    flagged_to = 0                    # 'full' sample behind the last piece whose probe tripped
+
+    def probe(arr):
+        """Does the piece hold a non-finite sample?  One sample in 2048 and the last one (a
+        block of the kernels' transforms is non-finite as a whole): their sum, a 0-d CUDA tensor
+        nobody waits for yet -- the stream's own, over the whole buffer a piece is a view of, where
+        it made one (``_probe_sum``) -- or, for an ndarray, a bool."""
+        if dev.is_tensor(arr):
+            held = getattr(arr, "_osz_probe", None)
+            return held if held is not None else _probe_sum(torch.movedim(arr, axis, -1))
+        v = np.moveaxis(arr, axis, -1)
+        return not math.isfinite(float(v[..., ::2048].sum()) + float(v[..., -1].sum()))
+
+    # A probe is looked at through a pinned slot filled on a side stream behind the probe alone:
+    # `float(tensor)` would queue its copy behind the pushes launched since and park the host
+    # until they are done -- a bubble per piece (4 % at 256 channels x 2^20).
+    nslots = _PROBE_SLOTS
+    ring, side, watch, slot_of = None, None, {}, [0]
+
+    def watched(t):
+        """Key of the probe `t` (pieces of one buffer share theirs), its copy to the host started."""
+        nonlocal ring, side
+        key = id(t)
+        if key in watch:
+            return key
+        if ring is None:
+            # (pinned memory and a stream cost a third of a millisecond to make: kept for the process)
+            ring, side = _PROBE_POOL.pop() if _PROBE_POOL else (
+                torch.empty(nslots, dtype=torch.float64, pin_memory=True), torch.cuda.Stream())
+        while len(watch) >= nslots:
+            watch.pop(next(iter(watch)))                     # (long handed on: twice the pieces ever pending)
+        slot = slot_of[0] = (slot_of[0] + 1) % nslots
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            ring[slot:slot + 1].copy_(t.reshape(1), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        t.record_stream(side)
+        watch[key] = [t, slot, done, None]                   # (the tensor kept: its id stays its own)
+        return key
+
+    def tripped(rec):
+        if not isinstance(rec[3], bool):
+            w = watch.get(rec[3])
+            if w is None:                                    # (dropped from the watch: never the case for a pending piece)
+                raise RuntimeError("oaconvolve: a pending piece lost its probe")
+            if w[3] is None:
+                w[2].synchronize()
+                w[3] = not math.isfinite(float(ring[w[1]]))
+            rec[3] = w[3]
+        return rec[3]
+
+    def segments(a, n):
+        """The reference's segments that reach 'full' samples [a, a + n): first, last."""
+        return max((a - wlen + 1) // step, 0), (a + n - 1) // step
+
+    def gather(i0, i1):
+        parts = []
+        for at, n, chunk in seen:
+            lo, hi = max(i0 - at, 0), min(i1 - at, n)
+            if lo < hi:
+                parts.append(layout.to2d(chunk)[0][:, lo:hi])
+        return torch.cat(parts, 1)
+
+    def settle(arr, a, n):
+        """The piece as the reference leaves it (the rare path)."""
+        b = a + n
+        k_lo, k_hi = segments(a, n)
+        i0, i1 = k_lo * step, min(max((k_hi + 1) * step, b), nsamples)
+        X = gather(i0, i1)
+        bad_in = ~torch.isfinite(X)
+        y2d, host = layout.to2d(arr)
+        mine = ~torch.isfinite(y2d)
+        if not bool(bad_in.any()) and not bool(mine.any()):
+            return arr              # (the probe that tripped was another piece's)
+        # (no non-finite input in reach and non-finite here all the same: a block of the kernels
+        # that began before the reference's segment did)
+        nseg = k_hi - k_lo + 1
+        pad = nseg * step - X.shape[1]
+        seg_bad = torch.nn.functional.pad(bad_in, (0, max(pad, 0)))[:, :nseg * step]
+        seg_bad = seg_bad.reshape(seg_bad.shape[0], nseg, step).any(2)            # (channels, segments)
+        at = torch.arange(a, b, device=X.device)
+        k1 = torch.div(at, step, rounding_mode="floor")
+        lost = seg_bad[:, (k1 - k_lo).clamp(0, nseg - 1)]
+        behind = ((at - k1 * step) < wlen - 1) & (k1 - 1 >= k_lo)                  # the previous segment's overhang
+        lost = lost | (seg_bad[:, (k1 - 1 - k_lo).clamp(0, nseg - 1)] & behind[None, :])
+        if bool((mine & ~lost).any()):
+            # non-finite here, finite there: once more, from a cleaned copy
+            clean = torch.where(bad_in, torch.zeros((), dtype=X.dtype, device=X.device), X)
+            s, e = max(a - (wlen - 1), 0), min(b, nsamples)
+            again = dev.FirStream(taps, layout.nch)
+            try:
+                parts = []
+                if e > s:
+                    parts.append(again.push(clean[:, s - i0:e - i0].contiguous(), min(a - s, e - s)))
+                if b > nsamples:
+                    parts.append(again.flush(X.device, skip=max(a - nsamples, 0), drop=nsamples + wlen - 1 - b))
+                y2d = torch.where(mine, torch.cat(parts, 1), y2d)
+            finally:
+                again.close()
+        y2d = y2d.masked_fill(lost, float("nan"))
+        return layout.from2d(y2d, host)
+
+    def release(final):
+        nonlocal flagged_to
+        while pending:
+            arr, a, n, _ = pending[0]
+            k_lo, k_hi = segments(a, n)
+            need = min((k_hi + 1) * step, nsamples)            # inputs that can still reach the piece
+            if not final and (produced < need or pending[-1][1] < need or len(pending) < 2):
+                return              # (the newest piece's probe is still on its way: not waited for)
+            rec = pending.popleft()
+            hit = flagged_to > k_lo * step or tripped(rec)
+            for other in pending:
+                if hit or other[1] >= need:
+                    break
+                hit = tripped(other)
+            if tripped(rec):
+                flagged_to = max(flagged_to, a + n)
+            yield settle(arr, a, n) if hit else arr
+            # inputs no pending piece can want any more
+            keep = segments(pending[0][1], pending[0][2])[0] * step if pending else segments(produced, 1)[0] * step
+            while seen and seen[0][0] + seen[0][1] <= keep:
+                seen.popleft()
+
+    try:
+        for piece in inner:
+            n = piece.shape[axis]
+            if n == 0:
+                continue
+            flag = probe(piece)
+            pending.append([piece, produced, n, flag if isinstance(flag, bool) else watched(flag)])
+            produced += n
+            yield from release(False)
+        yield from release(True)
+    finally:
+        inner.close()
+        if ring is not None:
+            side.synchronize()
+            _PROBE_POOL.append((ring, side))
+
+
+def _oaconvolve_stream(pro, window, axis, mode, nfft_factor=32, probed=False):
+    """The stream of ``oaconvolve`` as the kernels produce it.
 
     Yields one piece per produced chunk plus the final overhang; concatenated
     they are the ``np.convolve(x, window, mode)`` of every channel, i.e. what
@@ -180,11 +397,16 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
         if len(cuts) <= 1:
             yield layout.from2d(buf if cols == buf.shape[1] else buf[:, :cols], host)
             return
+        # (one probe for the whole buffer, oaconvolve's reach: its pieces carry it along)
+        held = _probe_sum(buf[:, :cols]) if probed and not host else None
         at = 0
         for m in cuts:                       # (a last buffer may be short of its end: mode 'valid')
             if at >= cols:
                 break
-            yield layout.from2d(buf[:, at:min(at + m, cols)], host)
+            piece = layout.from2d(buf[:, at:min(at + m, cols)], host)
+            if held is not None and dev.is_tensor(piece):
+                piece._osz_probe = held
+            yield piece
             at += m
 
     try:

@@ -312,3 +312,84 @@ def test_fir_chain_nan_reach_is_the_references(nm, fed, taps_n, cs):
 def dev_module():
     from openseize_amd import _device
     return _device
+
+
+def _fir_case(seed, C, n, where):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((C, n))
+    for c, at, kind in where:
+        if kind == "tail":
+            x[c, at:] = np.nan
+        elif kind == "all":
+            x[c, :] = np.nan
+        else:
+            x[c, at] = np.inf if kind == "inf" else np.nan
+    return x
+
+
+@pytest.mark.parametrize("fed", ["resident", "host"])
+@pytest.mark.parametrize("taps_n, n, cs", [(256, 300_000, 30_000), (65, 100_001, 20_000), (101, 5000, 1000),
+                                            (1024, 1_200_000, 1 << 18), (3001, 700_000, 100_000),
+                                            (3, 15_967, 1107), (1024, 5166, 4865)])
+def test_oaconvolve_nan_reach_is_the_references(nm, fed, taps_n, n, cs):
+    """``oaconvolve`` alone: a non-finite input sample costs the reference the whole output of
+    the SEGMENT it sits in (core/numerical.py:202-217, 258-283) -- and so it does here: the same
+    samples non-finite, the others as the oracle has them, in every mode, resident and host-fed,
+    for samples at the stream's ends, runs to the end, a channel without a finite sample and a
+    block of this library's transforms that straddles a segment boundary or begins whole segments
+    before the sample (three taps: segments of 1022 samples, blocks of 7000)."""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    h = sps.firwin(taps_n, 0.2)
+    _, step = orc.oa_plan(n, taps_n, 32)
+    C = 5
+    where = [(0, 0, "nan"), (1, n - 1, "inf"), (2, min(step, n) - 1, "nan"), (2, min(2 * step + 7, n - 2), "nan"),
+             (3, (n * 2) // 3, "tail")]
+    if n > 3 * step:
+        where.append((1, 3 * step, "nan"))           # the first sample of a segment
+    x = _fir_case(taps_n + n, C, n, where)
+    x[4, :] = np.nan if taps_n == 65 else x[4, :]    # (a dead channel in one of the cases)
+    for mode in ("same", "full", "valid"):
+        want = np.concatenate(orc.oaconvolve(x, h, mode), -1)
+        src = torch.from_numpy(x).cuda() if fed == "resident" else x
+        got = [p.cpu().numpy() if torch.is_tensor(p) else p
+               for p in nm.oaconvolve(producer(src, cs, -1), h, -1, mode)]
+        got = np.concatenate(got, -1)
+        assert got.shape == want.shape, (mode, got.shape, want.shape)
+        ok = np.isfinite(want)
+        assert np.array_equal(ok, np.isfinite(got)), (mode, np.argwhere(ok != np.isfinite(got))[:5])
+        scale = np.max(np.abs(want[ok]))
+        assert np.max(np.abs(got[ok] - want[ok])) < RTOL * scale, mode
+
+
+def test_oaconvolve_reach_holds_nothing_back_for_ever(nm):
+    """A clean stream comes out piece for piece as before, two pieces late at most, and the
+    class API (FIR.__call__) inherits the reach."""
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd.filtering.fir import Kaiser
+    x = _fir_case(5, 3, 400_000, [(1, 123_456, "nan")])
+    filt = Kaiser(fpass=500, fstop=600, fs=5000)
+    y = filt(x, chunksize=50_000, axis=-1, mode="same")
+    want = np.concatenate(orc.oaconvolve(x, filt.coeffs, "same"), -1)
+    assert np.array_equal(np.isfinite(want), np.isfinite(y))
+    ok = np.isfinite(want)
+    assert np.max(np.abs(y[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
+    # pieces arrive in order, chunk-sized, while the source is still being read
+    xs = torch.from_numpy(np.random.default_rng(0).standard_normal((2, 600_000))).cuda()
+    pulled, lens = [], []
+
+    def source():
+        for k in range(0, 600_000, 100_000):
+            pulled.append(k)
+            yield xs[:, k:k + 100_000].clone()       # (buffers of their own: adjacent views would be joined per push)
+
+    taps = filt.coeffs
+    src = producer(source, 100_000, -1, shape=(2, 600_000))
+    first_after = None
+    for piece in nm.oaconvolve(src, taps, -1, "same"):
+        if first_after is None:
+            first_after = len(pulled)
+        lens.append(piece.shape[-1])
+    assert sum(lens) == 600_000 and first_after <= 5, (lens, first_after)
