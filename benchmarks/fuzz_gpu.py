@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 16
+        kind = it % 17
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -250,6 +250,34 @@ def main():
                 else:
                     e = 0.0
                 what = f"fir nonfinite taps={taps} C={C} cs={cs} total={total} mode={mode}"
+            elif kind == 16:   # non-finite samples through FIR -> sosfilt on the fused launch: lost from the segment's start
+                taps = int(rng.choice([17, 65, 255, 256, 1024, 2049]))
+                cs = int(rng.integers(65536, 90000))
+                nch_ = int(rng.integers(3, 8))
+                total = cs * (nch_ - 1) + int(rng.integers(max(taps, 600), cs + 1))
+                C = int(rng.choice([1, 2, 5]))
+                h = rng.standard_normal(taps) / np.sqrt(taps)
+                sos = designs[int(rng.integers(0, 4))]
+                xh = rng.standard_normal((C, total))
+                for _ in range(int(rng.integers(0, 4))):
+                    c, at = int(rng.integers(0, C)), int(rng.integers(0, total))
+                    r = rng.random()
+                    if r < 0.2:
+                        xh[c, at:] = np.nan
+                    else:
+                        xh[c, at] = np.nan if r < 0.8 else np.inf
+                data = torch.from_numpy(xh).cuda() if rng.random() < 0.6 else xh
+                src = producer(data, cs, -1)
+                fir_ = producer(partial(nm.oaconvolve, src, h, -1, "same"), cs, -1, shape=src.shape)
+                got_ = np.concatenate([o.cpu().numpy() if torch.is_tensor(o) else o for o in nm.sosfilt(fir_, sos, -1)], -1)
+                with np.errstate(invalid="ignore"):
+                    ref_ = orc.sosfilt(np.concatenate(orc.oaconvolve(xh, h, "same"), -1), sos, cs)[0]
+                ok = np.isfinite(ref_)
+                if got_.shape != ref_.shape or not np.array_equal(ok, np.isfinite(got_)):
+                    e = float("inf")
+                else:
+                    e = float(np.max(np.abs(got_[ok] - ref_[ok])) / np.max(np.abs(ref_[ok]))) if ok.any() else 0.0
+                what = f"fir->sosfilt nonfinite taps={taps} C={C} cs={cs} total={total} resident={torch.is_tensor(data)}"
             elif kind == 13:   # plain sosfiltfilt of a long resident stream, any layout: grouped zero-phase steps
                 ndim = int(rng.integers(1, 4))
                 axis = int(rng.integers(0, ndim))

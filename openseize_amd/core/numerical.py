@@ -123,6 +123,59 @@ def _probe_sum(v):
     return torch.index_select(v, -1, idx).sum()
 
 
+class _ProbeWatch:
+    """Probes (0-d CUDA tensors, ``_probe_sum``) looked at from the host without waiting for anything
+    but the probe: each is copied into a pinned slot on a side stream behind an event recorded
+    right after it -- ``float(tensor)`` would queue its copy behind the pushes launched since and
+    park the host until they are done (a bubble per piece: 4 % at 256 channels x 2^20)."""
+
+    def __init__(self):
+        self.ring = self.side = None
+        self.watch, self.slot = {}, 0
+
+    def add(self, t):
+        """Key of the probe `t` (pieces of one buffer share theirs), its copy to the host started."""
+        import torch
+        key = id(t)
+        if key in self.watch:
+            return key
+        if self.ring is None:
+            # (pinned memory and a stream cost a third of a millisecond to make: kept for the process)
+            self.ring, self.side = _PROBE_POOL.pop() if _PROBE_POOL else (
+                torch.empty(_PROBE_SLOTS, dtype=torch.float64, pin_memory=True), torch.cuda.Stream())
+        while len(self.watch) >= _PROBE_SLOTS:
+            self.watch.pop(next(iter(self.watch)))           # (long handed on: far more slots than pieces ever pending)
+        slot = self.slot = (self.slot + 1) % _PROBE_SLOTS
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            self.ring[slot:slot + 1].copy_(t.reshape(1), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        t.record_stream(self.side)
+        self.watch[key] = [t, slot, done, None]              # (the tensor kept: its id stays its own)
+        return key
+
+    def tripped(self, key):
+        """Is the probe non-finite?  Waits for the probe's own copy, nothing else."""
+        if isinstance(key, bool):
+            return key
+        w = self.watch.get(key)
+        if w is None:                                        # (never the case for a pending piece)
+            raise RuntimeError("a pending piece lost its probe")
+        if w[3] is None:
+            w[2].synchronize()
+            w[3] = not math.isfinite(float(self.ring[w[1]]))
+        return w[3]
+
+    def close(self):
+        if self.ring is not None:
+            self.side.synchronize()
+            _PROBE_POOL.append((self.ring, self.side))
+            self.ring = self.side = None
+
+
 class _Tee:
     """A producer as ``_oaconvolve_stream`` sees it (shape, chunksize, iteration) that remembers the
     chunks it hands on: ``seen`` gets (first sample, samples, chunk) -- references, no copies."""
@@ -190,45 +243,10 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
         v = np.moveaxis(arr, axis, -1)
         return not math.isfinite(float(v[..., ::2048].sum()) + float(v[..., -1].sum()))
 
-    # A probe is looked at through a pinned slot filled on a side stream behind the probe alone:
-    # `float(tensor)` would queue its copy behind the pushes launched since and park the host
-    # until they are done -- a bubble per piece (4 % at 256 channels x 2^20).
-    nslots = _PROBE_SLOTS
-    ring, side, watch, slot_of = None, None, {}, [0]
-
-    def watched(t):
-        """Key of the probe `t` (pieces of one buffer share theirs), its copy to the host started."""
-        nonlocal ring, side
-        key = id(t)
-        if key in watch:
-            return key
-        if ring is None:
-            # (pinned memory and a stream cost a third of a millisecond to make: kept for the process)
-            ring, side = _PROBE_POOL.pop() if _PROBE_POOL else (
-                torch.empty(nslots, dtype=torch.float64, pin_memory=True), torch.cuda.Stream())
-        while len(watch) >= nslots:
-            watch.pop(next(iter(watch)))                     # (long handed on: twice the pieces ever pending)
-        slot = slot_of[0] = (slot_of[0] + 1) % nslots
-        ready = torch.cuda.Event()
-        ready.record()
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            ring[slot:slot + 1].copy_(t.reshape(1), non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(side)
-        t.record_stream(side)
-        watch[key] = [t, slot, done, None]                   # (the tensor kept: its id stays its own)
-        return key
+    watch = _ProbeWatch()
 
     def tripped(rec):
-        if not isinstance(rec[3], bool):
-            w = watch.get(rec[3])
-            if w is None:                                    # (dropped from the watch: never the case for a pending piece)
-                raise RuntimeError("oaconvolve: a pending piece lost its probe")
-            if w[3] is None:
-                w[2].synchronize()
-                w[3] = not math.isfinite(float(ring[w[1]]))
-            rec[3] = w[3]
+        rec[3] = watch.tripped(rec[3])
         return rec[3]
 
     def segments(a, n):
@@ -310,15 +328,13 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
             if n == 0:
                 continue
             flag = probe(piece)
-            pending.append([piece, produced, n, flag if isinstance(flag, bool) else watched(flag)])
+            pending.append([piece, produced, n, flag if isinstance(flag, bool) else watch.add(flag)])
             produced += n
             yield from release(False)
         yield from release(True)
     finally:
         inner.close()
-        if ring is not None:
-            side.synchronize()
-            _PROBE_POOL.append((ring, side))
+        watch.close()
 
 
 def _oaconvolve_stream(pro, window, axis, mode, nfft_factor=32, probed=False):
@@ -603,6 +619,7 @@ def _sosfilt_after_fir(pro, source, taps, sos, zi):
         layout = dev.Layout(pro.shape, axis)
         C = layout.nch
         fir, iir = dev.FirStream(taps, C), dev.SosStream(sos, C)
+        watch = _ProbeWatch()
         try:
             dev.chain_zp_tolerance(fir, iir, dev.zp_tolerance())   # (the forward link's cut too)
             if zi is not None:
@@ -612,7 +629,7 @@ def _sosfilt_after_fir(pro, source, taps, sos, zi):
             pipe = None if resident else dev.HostPipe(layout)
             at = {"k": 0, "open": None}                # chunks taken; the buffer of the last piece
 
-            def op(x2d):
+            def fused(x2d):
                 """Input chunk k in; output chunk k - 1 (complete now) out."""
                 k, m = at["k"], x2d.shape[1]
                 if k >= nchunks or m != (cs if k < nchunks - 1 else last):
@@ -629,6 +646,147 @@ def _sosfilt_after_fir(pro, source, taps, sos, zi):
                     prev[:, cs:cs + lcut].copy_(cur[:, :lcut])
                 return prev[:, lcut:cs + lcut]
 
+            # ---- the reference FIR's reach of a non-finite sample (oaconvolve's docstring): its
+            # whole SEGMENT of `step` samples is lost, and behind a cascade the channel from the
+            # segment's start on.  Pieces are held back (inside `op`: a host-fed stream's results
+            # stay in HBM until they are final) until the inputs of their last segment have gone by,
+            # each is probed, the pushes they came from are kept by reference with the handles'
+            # states before them (device snapshots) -- and when a probe trips the stream goes on, from
+            # the oldest piece still here, the slow exact way: FIR of the cleaned chunk, the
+            # reference's segments laid over its output, the cascade behind that (which loses the
+            # channel by itself).  OSZ_CHAIN_REACH=0: the kernels' own reach.
+            reach = os.environ.get("OSZ_CHAIN_REACH", "1") != "0"
+            step = _oa_reference_step(total, wlen)
+            pend, kept = deque(), deque()              # [j, piece, first 'full' sample, probe]; [k, chunk, states before it]
+            slow = {"on": False, "out": deque(), "queue": deque(), "seen": 0, "parts": [], "have": 0,
+                    "piece": 0, "skip": 0, "drop": 0, "bad": None}
+
+            def lost(a, b):
+                """'full' samples [a, b) the reference's FIR has lost, per channel."""
+                at_ = torch.arange(a, b, device=device)
+                k1 = torch.div(at_, step, rounding_mode="floor")
+                bad = slow["bad"]
+                hit = bad[:, k1.clamp(max=bad.shape[1] - 1)]
+                behind = ((at_ - k1 * step) < wlen - 1) & (k1 >= 1)
+                return hit | (bad[:, (k1 - 1).clamp(min=0)] & behind[None, :])
+
+            def slow_emit(f, a):
+                """Cascade output for 'full' samples from `a` on -> whole output chunks."""
+                if slow["skip"]:
+                    f = f[:, slow["skip"]:]
+                    slow["skip"] = 0
+                slow["parts"].append(f)
+                slow["have"] += f.shape[1]
+                while True:
+                    j = slow["piece"]
+                    want = cs if j < nchunks - 1 else last
+                    if j >= nchunks or slow["have"] < want:
+                        return
+                    cat = slow["parts"][0] if len(slow["parts"]) == 1 else torch.cat(slow["parts"], 1)
+                    if slow["drop"] > 0:           # (handed on before the trip, from the fused launches)
+                        slow["drop"] -= 1
+                    else:
+                        slow["out"].append(cat[:, :want])
+                    slow["parts"] = [cat[:, want:]] if cat.shape[1] > want else []
+                    slow["have"] -= want
+                    slow["piece"] = j + 1
+
+            def slow_drain(final):
+                while slow["queue"]:
+                    a, u = slow["queue"][0]
+                    b = a + u.shape[1]
+                    if not final and slow["seen"] < min(((b - 1) // step + 1) * step, total):
+                        return
+                    slow["queue"].popleft()
+                    slow_emit(iir.forward(u.masked_fill(lost(a, b), float("nan"))), a)
+
+            def slow_feed(k, x2d):
+                m = x2d.shape[1]
+                bad = ~torch.isfinite(x2d)
+                where_ = torch.nonzero(bad)
+                if where_.shape[0]:
+                    slow["bad"][where_[:, 0], torch.div(k * cs + where_[:, 1], step, rounding_mode="floor")] = True
+                    x2d = torch.where(bad, torch.zeros((), dtype=x2d.dtype, device=x2d.device), x2d)
+                u = fir.push(x2d.contiguous(), lcut if k == 0 else 0)
+                slow["queue"].append((lcut if k == 0 else k * cs, u))
+                slow["seen"] = k * cs + m
+                slow_drain(False)
+
+            def go_slow():
+                j0 = pend[0][0]
+                trim_kept(j0)
+                if not kept or kept[0][0] > j0 or kept[0][2] is None:
+                    raise RuntimeError("sosfilt after oaconvolve: the pushes of the pending pieces are gone")
+                ks = kept[0][0]                    # the last push at or before j0 with the states before it
+                fir.restore(kept[0][2][0])
+                iir.restore(kept[0][2][1])
+                slow.update(on=True, piece=ks, skip=lcut if ks > 0 else 0, drop=j0 - ks,
+                            bad=torch.zeros((C, -(-(total + wlen) // step) + 1), dtype=torch.bool, device=device))
+                pend.clear()
+                pushes = list(kept)
+                kept.clear()
+                for k, xk, _ in pushes:
+                    slow_feed(k, xk)
+
+            def trim_kept(j0):
+                """Pushes before the last one at or before j0 that has the states before it are let go."""
+                keep_from = None
+                for rec in kept:
+                    if rec[0] > j0:
+                        break
+                    if rec[2] is not None:
+                        keep_from = rec[0]
+                while kept and keep_from is not None and kept[0][0] < keep_from:
+                    kept.popleft()
+
+            def release(final):
+                """The oldest piece if it is final (None: not yet)."""
+                if slow["on"]:
+                    return slow["out"].popleft() if slow["out"] else None
+                if not pend:
+                    return None
+                j, piece, a, _ = pend[0]
+                need = min(((a + piece.shape[1] - 1) // step + 1) * step, total)
+                if not final and pend[-1][2] < need:
+                    return None          # (and the newest piece's probe is still on its way: not waited for)
+                for rec in pend:
+                    if rec[2] >= need and rec is not pend[0]:
+                        break
+                    if watch.tripped(rec[3]):
+                        go_slow()
+                        return slow["out"].popleft() if slow["out"] else None
+                pend.popleft()
+                trim_kept(pend[0][0] if pend else at["k"] - 1)     # (the next piece's body is the last push's)
+                return piece
+
+            def op(x2d):
+                k = at["k"]
+                if slow["on"]:
+                    if k >= nchunks or x2d.shape[1] != (cs if k < nchunks - 1 else last):
+                        raise RuntimeError("sosfilt after oaconvolve: an inner chunk of the source "
+                                           f"is not chunksize = {cs} long")
+                    at["k"] = k + 1
+                    slow_feed(k, x2d)
+                    return release(False)
+                if not reach:
+                    return fused(x2d)
+                # (a host-fed chunk sits in a staging buffer that is written again: a copy is kept.  The
+                # handles' states before every fourth push: reading them makes the forward link settle its
+                # carry into them -- five small launches -- and the slow way can start a few chunks early)
+                kept.append([k, x2d if resident else x2d.clone(),
+                             (fir.snapshot(), iir.snapshot()) if k % 4 == 0 else None])
+                y = fused(x2d)
+                if y is not None:
+                    pend.append([k - 1, y, (k - 1) * cs + lcut, watch.add(_probe_sum(y))])
+                return release(False)
+
+            def hand_on(y):
+                if resident or dev.emit_resident():
+                    return layout.from2d(y, False)
+                out, done = pipe.download(y)
+                done.synchronize()
+                return pipe.restore(out)
+
             seq = (c for c in _chain_first(first, chunks) if c.shape[axis] > 0)
             if resident:
                 for arr in seq:
@@ -640,17 +798,31 @@ def _sosfilt_after_fir(pro, source, taps, sos, zi):
             if at["k"] != nchunks:
                 raise RuntimeError(f"sosfilt after oaconvolve: {at['k']} of {nchunks} chunks")
             # ---- the overhang of the convolution, behind the last piece
-            cur = at["open"]
-            if lcut:
-                iir.forward(fir.flush(device, skip=0, drop=rcut), out=cur[:, last:last + lcut])
-            y = cur[:, lcut:last + lcut]
-            if resident or dev.emit_resident():
-                yield layout.from2d(y, False)
-            else:
-                out, done = pipe.download(y)
-                done.synchronize()
-                yield pipe.restore(out)
+            if not slow["on"]:
+                cur = at["open"]
+                if lcut:
+                    iir.forward(fir.flush(device, skip=0, drop=rcut), out=cur[:, last:last + lcut])
+                y = cur[:, lcut:last + lcut]
+                if not reach:
+                    yield hand_on(y)
+                    return
+                pend.append([nchunks - 1, y, (nchunks - 1) * cs + lcut, watch.add(_probe_sum(y))])
+                while pend and not slow["on"]:
+                    y = release(True)
+                    if y is not None:
+                        yield hand_on(y)
+            if slow["on"]:
+                # (the slow way's own end: what is queued, the overhang with the segments over it, the rest)
+                slow_drain(True)
+                if lcut:
+                    slow["queue"].append((total, fir.flush(device, skip=0, drop=rcut)))
+                    slow_drain(True)
+                while slow["out"]:
+                    yield hand_on(slow["out"].popleft())
+                if slow["piece"] != nchunks:
+                    raise RuntimeError(f"sosfilt after oaconvolve: {slow['piece']} of {nchunks} output chunks")
         finally:
+            watch.close()
             fir.close()
             iir.close()
 

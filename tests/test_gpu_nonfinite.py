@@ -393,3 +393,50 @@ def test_oaconvolve_reach_holds_nothing_back_for_ever(nm):
             first_after = len(pulled)
         lens.append(piece.shape[-1])
     assert sum(lens) == 600_000 and first_after <= 5, (lens, first_after)
+
+
+@pytest.mark.parametrize("fed", ["resident", "host"])
+@pytest.mark.parametrize("taps_n, cs, nchunks", [(256, 65664, 7), (1024, 1 << 17, 9), (65, 70000, 5)])
+def test_fir_sosfilt_chain_nan_reach_is_the_references(nm, fed, taps_n, cs, nchunks):
+    """``sosfilt(oaconvolve(x, 'same'))`` on the fused launch (osz_chain_forward): a non-finite
+    input sample costs the reference the channel from the START of the FIR's segment that holds it
+    (core/numerical.py:202-217 into :334) -- and so it does here, resident and host-fed: the same
+    samples non-finite as in the oracle's restatement, the others equal; a clean stream still takes
+    one fused launch per chunk."""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    sos = sps.butter(4, [0.05, 0.3], "bandpass", output="sos")
+    h = sps.firwin(taps_n, 0.2)
+    total = cs * (nchunks - 1) + cs // 3 + 17
+    _, step = orc.oa_plan(total, taps_n, 32)
+    C = 6
+    where = [(0, 3 * cs + 8000, "nan"), (1, total - 5, "inf"), (2, min(2 * step + 7, total - 9), "nan"),
+             (3, (total * 2) // 3, "tail"), (4, 0, "nan")]
+    x = _fir_case(taps_n + cs, C, total, where)
+    launches, plain = [], dev.chain_forward
+    dev.chain_forward = lambda *a, **k: (launches.append(1), plain(*a, **k))[1]
+    try:
+        def through(data):
+            src = producer(data, cs, -1)
+            fir = producer(partial(nm.oaconvolve, src, h, -1, "same"), cs, -1, shape=src.shape)
+            return np.concatenate([p.cpu().numpy() if torch.is_tensor(p) else p for p in nm.sosfilt(fir, sos, -1)], -1)
+
+        got = through(torch.from_numpy(x).cuda() if fed == "resident" else x)
+        assert launches, "the fused launch did not run"
+        with np.errstate(invalid="ignore"):
+            want = orc.sosfilt(np.concatenate(orc.oaconvolve(x, h, "same"), -1), sos, cs)[0]
+        ok = np.isfinite(want)
+        assert got.shape == want.shape
+        assert np.array_equal(ok, np.isfinite(got)), np.argwhere(ok != np.isfinite(got))[:5]
+        assert np.max(np.abs(got[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
+        # a clean stream: every chunk but the first on the fused launch, nothing recomputed
+        del launches[:]
+        xc = np.random.default_rng(1).standard_normal((C, total))
+        got = through(torch.from_numpy(xc).cuda() if fed == "resident" else xc)
+        assert len(launches) == nchunks - 1
+        want = orc.sosfilt(np.concatenate(orc.oaconvolve(xc, h, "same"), -1), sos, cs)[0]
+        assert np.max(np.abs(got - want)) < RTOL * np.max(np.abs(want))
+    finally:
+        dev.chain_forward = plain
