@@ -4,9 +4,10 @@ One JSON line per (filter, setting):
 
     PYTHONPATH=. python benchmarks/zp_coverage.py > profiles/rNN_zp_coverage.jsonl
 
-  chain        1024-tap FIR -> the cascade's sosfiltfilt (the headline's shape): `zp` = ONE kernel per
+  chain        1024-tap FIR -> the cascade's sosfiltfilt (the headline's shape) at the C ABI: `zp` = ONE kernel per
                chunk (osz_chain_zp_step + seal), else `chain_step` = the fused FIR + forward kernel
-               with the backward pass beside it (osz_chain_step: `forward_kernel` names which fused
+               with the backward pass beside it (the public generators run FIR and cascade APART there
+               since round 5: no slower, and the reference FIR's NaN reach; osz_chain_step: `forward_kernel` names which fused
                kernel it is, the spectral one or the time-domain one)
   sosfiltfilt  the cascade alone: `zp` (the identity as the FIR) or `dual` (osz_sosfiltfilt_step)
 Filters: the headline; Butter(fpass=[8, 30], fstop=[3, 60], fs=500) (SURVEY 8d's class-API cfg-3);

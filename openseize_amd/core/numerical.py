@@ -871,14 +871,24 @@ def _sosfiltfilt_after_fir(pro, source, taps, sos):
             if warm > cs - lcut:                       # the warm-up would need samples not yet there
                 yield None
                 return
+            dev.chain_zp_tolerance(fir, iir, dev.zp_tolerance())
+            lag = dev.chain_zp_lag(fir, iir)
+            one_kernel = (lag >= 0 and nchunks >= 6 and os.environ.get("OSZ_CHAIN_ZP", "1") != "0"
+                          and cs >= max(4 * (lcut + lag), warm + lcut + lag, 2 * dev.chain_zp_min_chunk(fir, iir)))
+            if not one_kernel and os.environ.get("OSZ_CHAIN_ZP", "1") != "0":
+                # Streams and cascades the one-kernel route does not take: the two generators apart.
+                # They carry the reference FIR's NaN reach (oaconvolve's docstring), which the
+                # two-kernel step below does not, and since round 5 (chunks joined per push, the
+                # cascade's own zero-phase route) they are no slower on resident data: 3.3 against
+                # 3.9 ms per 256 x 2^20 chunk on a five-chunk stream, 4.5 against 4.8 behind nine
+                # sections.  OSZ_CHAIN_ZP=0 asks for the two-kernel step (A/B runs, tests).
+                yield None
+                return
             yield True
             device = first.device if resident else "cuda"
             pipe = None if resident else dev.HostPipe(layout)
             flying = deque()
-            dev.chain_zp_tolerance(fir, iir, dev.zp_tolerance())
-            lag = dev.chain_zp_lag(fir, iir)
-            if (lag >= 0 and nchunks >= 6 and os.environ.get("OSZ_CHAIN_ZP", "1") != "0"
-                    and cs >= max(4 * (lcut + lag), warm + lcut + lag, 2 * dev.chain_zp_min_chunk(fir, iir))):
+            if one_kernel:
                 # (the reference FIR's NaN reach, segment by segment; OSZ_ZP_REACH=0: the kernels' own,
                 # from the sample itself)
                 reach = 0 if os.environ.get("OSZ_ZP_REACH") == "0" else _oa_reference_step(total, wlen)

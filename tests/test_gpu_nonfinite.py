@@ -172,8 +172,9 @@ def test_nonfinite_reach_fused_chain(nm, zero_phase):
 
 
 def test_nonfinite_reach_at_the_headline_geometry(nm):
-    """cfg-3's own geometry (256 channels x 2^20-sample chunks through osz_chain_step, two
-    fused runs and three backward segments per channel): one NaN in one channel of chunk 2
+    """cfg-3's own geometry (256 channels x 2^20-sample chunks through osz_chain_step -- the
+    two-kernel step, asked for with OSZ_CHAIN_ZP=0 --, two fused runs and three backward segments
+    per channel): one NaN in one channel of chunk 2
     leaves every other channel bit-identical to the clean run, and that channel NaN from
     chunk 1 on (the chunk before the NaN: its backward warm-up runs over it)."""
     import scipy.signal as sps
@@ -196,7 +197,12 @@ def test_nonfinite_reach_at_the_headline_geometry(nm):
         sums, nanmask = [], []
         plain_step = dev.chain_step
         dev.chain_step = lambda *a, **k: (steps.append(1), plain_step(*a, **k))[1]
-        outs = nm.sosfiltfilt(fir, sos, -1)
+        import os
+        os.environ["OSZ_CHAIN_ZP"] = "0"          # (the two-kernel step is what this test is about)
+        try:
+            outs = list(nm.sosfiltfilt(fir, sos, -1))
+        finally:
+            del os.environ["OSZ_CHAIN_ZP"]
         for out in outs:
             bad = torch.isnan(out).any(dim=1)
             allbad = torch.isnan(out).all(dim=1)
@@ -481,3 +487,40 @@ def test_resample_nan_reach_is_local(nm, LM):
             assert differs.sum() <= 32 * (len(flips) + 2)
             both = ok & np.isfinite(got)
             assert np.max(np.abs(got[both] - want[both])) < RTOL * np.max(np.abs(want[both]))
+
+
+@pytest.mark.parametrize("fed", ["resident", "host"])
+@pytest.mark.parametrize("kind", ["five chunks", "nine sections"])
+def test_fir_sosfiltfilt_off_the_one_kernel_route_keeps_the_references_reach(nm, fed, kind):
+    """FIR -> sosfiltfilt where the one-kernel route does not apply (a stream of five chunks; a
+    cascade it refuses): the two generators apart since round 5 -- the reference FIR's segments
+    and the cascade's own reach, sample for sample the oracle's masks; the two-kernel step
+    (osz_chain_step, whose FIR loses only its own 4096-point blocks) runs when asked for only."""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd import _device as dev
+    h = sps.firwin(256, 0.2)
+    if kind == "five chunks":
+        sos, cs, nchunks = sps.butter(6, [0.05, 0.3], "bandpass", output="sos"), 70_000, 5
+    else:
+        sos, cs, nchunks = sps.cheby1(9, 0.5, [0.01, 0.1], "bandpass", output="sos"), 70_000, 8
+    total = cs * (nchunks - 1) + 12_345
+    x = _fir_case(11, 4, total, [(0, 3 * cs + 100, "nan"), (1, total - 3, "inf"), (2, 150_000, "nan")])
+    ran, plain_step, plain_zp = [], dev.chain_step, dev.chain_zp_step
+    dev.chain_step = lambda *a, **k: (ran.append("step"), plain_step(*a, **k))[1]
+    dev.chain_zp_step = lambda *a, **k: (ran.append("zp"), plain_zp(*a, **k))[1]
+    try:
+        src = producer(torch.from_numpy(x).cuda() if fed == "resident" else x, cs, -1)
+        fir = producer(partial(nm.oaconvolve, src, h, -1, "same"), cs, -1, shape=src.shape)
+        got = np.concatenate([p.cpu().numpy() if torch.is_tensor(p) else p for p in nm.sosfiltfilt(fir, sos, -1)], -1)
+    finally:
+        dev.chain_step, dev.chain_zp_step = plain_step, plain_zp
+    assert "step" not in ran, ran
+    with np.errstate(invalid="ignore"):
+        want = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(x, h, "same"), -1), sos, cs)
+    ok = np.isfinite(want)
+    assert np.array_equal(ok, np.isfinite(got)), np.argwhere(ok != np.isfinite(got))[:4]
+    assert ok[3].all() and not ok[0].all()
+    tol = RTOL if kind == "five chunks" else 1e-7        # (nine narrow-band sections: the cascade's own conditioning)
+    assert np.max(np.abs(got[ok] - want[ok])) < tol * np.max(np.abs(want[ok]))

@@ -1137,12 +1137,11 @@ def test_fir_then_sosfiltfilt_through_the_api_fused(osz):
             got = chain(x, taps, cs, -1)
         finally:
             dev.chain_step, dev.chain_zp_step = plain_step, plain_zp
-        # a fused path DID run: the zero-phase kernel (six chunks or more, filters it takes:
-        # every chunk but the last two, plus the head of the next for the seam) or the
-        # two-kernel step (every chunk but the first two)
+        # the zero-phase kernel ran where it applies (six chunks or more, filters it takes: every
+        # chunk but the last two, plus the head of the next for the seam); a shorter stream goes
+        # through the two generators apart (round 5: no slower, and the reference FIR's NaN reach)
         nchunks = -(-total // cs)
-        assert steps in (["zp"] * (nchunks - 2), ["step"] * (nchunks - 2)), (taps_n, steps)
-        assert (steps[0] == "zp") == (nchunks >= 6), (taps_n, nchunks)      # (five chunks: the two-kernel step)
+        assert steps == (["zp"] * (nchunks - 2) if nchunks >= 6 else []), (taps_n, steps)
         os.environ["OSZ_CHAIN_API"] = "0"
         try:
             ref = chain(x, taps, cs, -1)
