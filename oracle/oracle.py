@@ -386,7 +386,36 @@ def polyphase_resample(x, L, M, h):
     for c in range(flat.shape[0]):
         _lib().osz_ref_resample(_dp(flat[c]), n, _dp(h), len(h), L, M,
                                 _dp(y[c]), nout)
+    bad = ~np.isfinite(flat)
+    if bad.any():
+        y[resample_lost(bad, L, M, len(h))] = np.nan
     return y.reshape(x.shape[:-1] + (nout,))
+
+
+def resample_lost(bad, L, M, ntaps):
+    """Outputs a non-finite input sample costs scipy.signal.resample_poly -- and so the reference,
+    whatever its chunking (core/numerical.py:590-632; pinned by tests/golden/g20): SciPy pads the
+    window with zeros in front (n_pre_pad = M - half % M) and behind (n_post_pad, until the output
+    is long enough) and upfirdn pads every phase to the same count of taps, K = ceil(padded / L);
+    0 x NaN is NaN there, so output j is lost iff one of the K samples
+    x[((j + n_pre_remove) M) // L - k], k < K, is non-finite.  bad: (..., n) bool -> (..., nout)."""
+    n = bad.shape[-1]
+    nout = -(-n * L // M)
+    half = (ntaps - 1) // 2
+    pre = M - half % M
+    remove = (half + pre) // M
+
+    def upfirdn_len(len_h):                    # scipy.signal._upfirdn._output_len
+        return ((n - 1) * L + len_h - 1) // M + 1
+
+    post = 0
+    while upfirdn_len(ntaps + pre + post) < nout + remove:
+        post += 1
+    K = -(-(ntaps + pre + post) // L)
+    count = np.concatenate([np.zeros(bad.shape[:-1] + (1,), dtype=np.int64), np.cumsum(bad, axis=-1)], axis=-1)
+    top = ((np.arange(nout) + remove) * M) // L                       # the newest sample an output touches
+    lo, hi = np.clip(top - K + 1, 0, n), np.clip(top + 1, 0, n)
+    return (count[..., hi] - count[..., lo]) > 0
 
 
 # ---------------------------------------------------------------------------

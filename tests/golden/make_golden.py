@@ -658,6 +658,35 @@ def g19_fir_chain_nonfinite():
          taps=np.int64(taps_n), total=np.int64(total), step=np.int64(step), lost_chunks=lost)
 
 
+# --------------------------------------------------------------------------
+# G20 how far a non-finite input sample reaches in the reference's resampler (core/numerical.py:523-632:
+# scipy.signal.resample_poly chunk by chunk): the outputs whose taps touch it -- SciPy's zero padding
+# of the window included (0 x NaN is NaN) -- whatever the chunking.  Per ratio: the reference's output
+# for one input with samples at the stream's ends, at a chunk boundary, an Inf and a run to the end.
+# --------------------------------------------------------------------------
+def g20_resample_nonfinite():
+    n = 20_011
+    x = g20_input(n)
+    out = {"n": np.int64(n)}
+    for (L, M) in ((1, 5), (3, 2), (2, 1), (1, 25), (2, 7)):
+        for cs in (5_000, 7_321):
+            y = ref_rs.resample(x, L, M, 5000, chunksize=cs, axis=-1)
+            out[f"lost_L{L}_M{M}_cs{cs}"] = np.packbits(~np.isfinite(y), axis=-1)      # (a mask: where, not what)
+            out[f"nout_L{L}_M{M}"] = np.int64(y.shape[-1])
+    save("g20_resample_nonfinite.npz", **out)
+
+
+def g20_input(n):
+    """The input of G20 (tests/test_oracle.py rebuilds it: the masks depend on where the bad samples are)."""
+    x = np.random.default_rng(2020).standard_normal((4, n))
+    x[0, 0] = np.nan
+    x[0, 10_000] = np.nan            # a chunk boundary of chunksize 5 000
+    x[1, n - 1] = np.inf
+    x[1, 13_333] = np.nan
+    x[2, 17_000:] = np.nan
+    return x
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1:                      # regenerate the named blocks only
@@ -683,3 +712,4 @@ if __name__ == "__main__":
     g17_responses()
     g18_chain_long()
     g19_fir_chain_nonfinite()
+    g20_resample_nonfinite()

@@ -237,3 +237,33 @@ def test_oracle_nonfinite_reach_through_the_fir(golden):
         y = orc.sosfiltfilt(np.concatenate(orc.oaconvolve(x, h, "same"), axis=-1), sos, cs)
     lost = np.array([[bool((~np.isfinite(y[c, k * cs:(k + 1) * cs])).all()) for k in range(nchunks)] for c in range(C)])
     assert np.array_equal(lost, g["lost_chunks"])
+
+
+def test_oracle_resample_nonfinite_reach_is_the_references(golden):
+    """A non-finite sample through the reference's resampler (g20: its own outputs' masks for
+    samples at the stream's ends, at a chunk boundary, an Inf, a run to the end; five ratios,
+    two chunkings): the outputs SciPy's PADDED window touches -- `oracle.resample_lost` -- and
+    the finite ones still the definition's."""
+    import scipy.signal as sps
+    g = golden("g20_resample_nonfinite.npz")
+    n = int(g["n"])
+    x = np.random.default_rng(2020).standard_normal((4, n))       # (g20_input of make_golden.py)
+    x[0, 0] = np.nan
+    x[0, 10_000] = np.nan
+    x[1, n - 1] = np.inf
+    x[1, 13_333] = np.nan
+    x[2, 17_000:] = np.nan
+    for (L, M) in ((1, 5), (3, 2), (2, 1), (1, 25), (2, 7)):
+        h = orc.resample_filter(L, M, 5000)
+        nout = int(g[f"nout_L{L}_M{M}"])
+        with np.errstate(invalid="ignore"):
+            y = orc.polyphase_resample(x, L, M, h)
+        assert y.shape[-1] == nout
+        for cs in (5_000, 7_321):
+            lost = np.unpackbits(g[f"lost_L{L}_M{M}_cs{cs}"], axis=-1)[:, :nout].astype(bool)
+            assert np.array_equal(~np.isfinite(y), lost), (L, M, cs)
+        clean = np.where(np.isfinite(x), x, 0.0)
+        ok = np.isfinite(y)
+        ref = sps.resample_poly(clean, L, M, axis=-1, window=h)
+        # (a finite output touches no non-finite sample: the cleaned stream gives the same number)
+        assert np.max(np.abs(y[ok] - ref[ok])) < 1e-12 * np.max(np.abs(ref))
