@@ -1,7 +1,12 @@
-"""Polyphase resampler alone, 256 ch x 2^20 resident: /5 (cfg-5's first stage), /10, /25, 3/2, 2/3.
-    PYTHONPATH=. python benchmarks/poly_rates.py"""
+"""Polyphase resampler alone, 256 ch x 2^20 resident: /5 (cfg-5's first stage), /10, /25, 3/2, 2/3 --
+the window as the generator hands it over (SciPy's zero padding around it, numerical._resample_padded)
+and bare.
+    python benchmarks/poly_rates.py"""
 import json
+import sys
 import time
+
+sys.path.insert(0, ".")
 
 import torch
 
@@ -27,9 +32,19 @@ for L, M, fs in ((1, 5, 20480), (1, 10, 5000), (1, 25, 5000), (3, 2, 5000), (2, 
     cut = fs / (2 * max(L, M))
     h = Kaiser(cut - cut / 10, cut + cut / 10, fs, gpass=0.1, gstop=40).coeffs
     xin = x if L == 1 else x[:, : N // 2].contiguous()
-    poly = dev.PolyStream(h, L, M, CH)
-    dt = timed(lambda: poly.push(xin, final=False))
+    from openseize_amd.core import numerical as nm
     n = xin.shape[1]
-    print(json.dumps({"L": L, "M": M, "taps": len(h), "ms": dt * 1e3, "G_input_samples_s": CH * n / dt / 1e9,
-                      "algorithmic_TBps": (8 + 8 * L / M) * CH * n / dt / 1e12}), flush=True)
-    poly.close()
+    row = {"L": L, "M": M, "taps": len(h)}
+    for name in ("padded", "bare", "padded", "bare"):
+        if name == "padded":
+            taps, centre = nm._resample_padded(h, L, M, 96 * n)
+            poly = dev.PolyStream(taps, L, M, CH, centre=centre)
+            row["taps_padded"] = len(taps)
+        else:
+            poly = dev.PolyStream(h, L, M, CH)
+        dt = timed(lambda: poly.push(xin, final=False))
+        row.setdefault(f"ms_{name}", []).append(round(dt * 1e3, 4))
+        if name == "padded":
+            row.update(G_input_samples_s=round(CH * n / dt / 1e9, 1), algorithmic_TBps=round((8 + 8 * L / M) * CH * n / dt / 1e12, 3))
+        poly.close()
+    print(json.dumps(row), flush=True)

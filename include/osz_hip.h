@@ -307,6 +307,14 @@ int osz_chain_zp_finish(osz_fir_t fir, osz_sos_t sos, const double *x, int64_t l
  */
 int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M,
                     int nch);
+/* The same with the tap that lines up with an output named (`half` above = centre): what
+ * resample_poly does to the window before it filters -- zeros in front (n_pre_pad) and behind
+ * (n_post_pad, every phase to one count of taps; scipy/signal/_signaltools.py, resample_poly) --
+ * handed in as taps.  The kernels multiply every tap they are given, zero-valued ones included,
+ * and no other: a non-finite sample is lost to exactly the outputs SciPy (and so the reference,
+ * core/numerical.py:610,631) loses it to.  osz_poly_create(taps, n) = ..._centred(taps, n, (n-1)/2). */
+int osz_poly_create_centred(osz_poly_t *h, const double *taps, int ntaps, int centre, int L, int M,
+                            int nch);
 int osz_poly_destroy(osz_poly_t h);
 int osz_poly_reset(osz_poly_t h, void *stream);
 /* Checkpoint / resume: [samples consumed, samples produced, input history]

@@ -632,6 +632,8 @@ class SosStream(_Handle):
             self.h, ptr(x2d), x2d.stride(0), col, stream_ptr()))
 
     def forward(self, x2d, out=None):
+        if x2d.dim() != 2 or x2d.shape[0] != self.nch:
+            raise ValueError(f"SosStream.forward: {tuple(x2d.shape)} is not ({self.nch}, n)")
         y = torch.empty_like(x2d) if out is None else out
         _lib.check(self.lib.osz_sos_forward(
             self.h, ptr(x2d), x2d.stride(0), ptr(y), y.stride(0),
@@ -685,6 +687,8 @@ class FirStream(_Handle):
                                            self.ntaps, nch))
 
     def push(self, x2d, skip=0, out=None):
+        if x2d.dim() != 2 or x2d.shape[0] != self.nch:
+            raise ValueError(f"FirStream.push: {tuple(x2d.shape)} is not ({self.nch}, n)")
         n = x2d.shape[1]
         if not 0 <= skip <= n:
             raise ValueError(f"skip={skip} not in [0, {n}]")
@@ -832,14 +836,22 @@ class PolyStream(_Handle):
     _destroy = "osz_poly_destroy"
     _state = "osz_poly"
 
-    def __init__(self, taps, L, M, nch):
+    def __init__(self, taps, L, M, nch, centre=None):
+        """``centre``: the tap that lines up with an output (default: the middle one) -- a window
+        handed in with SciPy's zero padding around it (numerical._resample_padded)."""
         super().__init__()
         taps = np.ascontiguousarray(taps, dtype=np.float64)
         self.nch = nch
-        _lib.check(self.lib.osz_poly_create(ctypes.byref(self.h), host_dp(taps),
-                                            len(taps), L, M, nch))
+        if centre is None:
+            _lib.check(self.lib.osz_poly_create(ctypes.byref(self.h), host_dp(taps),
+                                                len(taps), L, M, nch))
+        else:
+            _lib.check(self.lib.osz_poly_create_centred(ctypes.byref(self.h), host_dp(taps),
+                                                        len(taps), int(centre), L, M, nch))
 
     def push(self, x2d, final):
+        if x2d.dim() != 2 or x2d.shape[0] != self.nch:
+            raise ValueError(f"PolyStream.push: {tuple(x2d.shape)} is not ({self.nch}, n)")
         n = x2d.shape[1]
         cnt = self.lib.osz_poly_out_count(self.h, n, int(final))
         y = torch.empty((self.nch, max(cnt, 0)), dtype=torch.float64,

@@ -103,6 +103,8 @@ SIGNATURES = {
     "osz_poly_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_dp, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int]),
+    "osz_poly_create_centred": (ctypes.c_int, [ctypes.POINTER(c_vp), c_dp, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "osz_poly_destroy": (ctypes.c_int, [c_vp]),
     "osz_poly_reset": (ctypes.c_int, [c_vp, c_vp]),
     "osz_poly_state_size": (c_i64, [c_vp]),

@@ -1461,6 +1461,28 @@ def _resample_plan(pro, L, M, fs, fir, axis, kwargs):
     return max(int(csize), 1), taps
 
 
+def _resample_padded(h, L, M, n):
+    """(taps, centre) for ``dev.PolyStream``: the window with the zeros
+    ``scipy.signal.resample_poly`` puts around it before it filters a stream of ``n`` samples
+    (the reference: core/numerical.py:610, :631) -- ``n_pre_pad = M - half % M`` in front, so that
+    the delay is whole outputs; ``n_post_pad`` behind, until upfirdn's output is long enough; every
+    phase to one count of taps.  The numbers do not change (zeros), the reach of a non-finite
+    sample does: 0 x NaN is NaN, and the kernels multiply every tap they are given."""
+    h = np.asarray(h, dtype=np.float64)
+    nh = len(h)
+    nout = -(-n * L // M)
+    half = (nh - 1) // 2
+    pre = M - half % M
+    remove = (half + pre) // M
+    post = 0
+    while ((n - 1) * L + nh + pre + post - 1) // M + 1 < nout + remove:      # (upfirdn's output length)
+        post += 1
+    K = -(-(nh + pre + post) // L)
+    taps = np.zeros(K * L)
+    taps[pre:pre + nh] = h
+    return taps, half + pre
+
+
 @dev.chain_aware
 def polyphase_resample(pro, L, M, fs, fir, axis, **kwargs):
     """Rational L/M resampling of a producer (core/numerical.py:523-632) on
@@ -1479,7 +1501,13 @@ def polyphase_resample(pro, L, M, fs, fir, axis, **kwargs):
     pro = producer(pro, csize, axis)
 
     layout = dev.Layout(pro.shape, axis)
-    stream = dev.PolyStream(h, int(L), int(M), layout.nch)
+    # the window as resample_poly filters with it: zeros in front and behind (a non-finite sample is
+    # then lost to the outputs SciPy -- the reference -- loses it to; OSZ_POLY_PAD=0: the bare window)
+    if os.environ.get("OSZ_POLY_PAD", "1") != "0":
+        taps, centre = _resample_padded(h, int(L), int(M), int(pro.shape[axis]))
+        stream = dev.PolyStream(taps, int(L), int(M), layout.nch, centre=centre)
+    else:
+        stream = dev.PolyStream(h, int(L), int(M), layout.nch)
     try:
         chunks = iter(pro)
         cur = next(chunks, None)

@@ -93,6 +93,14 @@ struct PolyBlockArgs {
 // M >= 8 or so): twice the threads on the same tile, the two halves of the
 // workgroup take the lower and the upper half of the M phase streams and their
 // partial sums meet in LDS -- the waves per CU that the large window took away.
+template <int V>
+__device__ __forceinline__ void poly_taps(double *acc, const double *g, const double *xv) {
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+#pragma unroll
+        for (int s = 0; s < kPolyR; ++s) acc[s] = fma(g[q], xv[s + q], acc[s]);
+}
+
 template <bool ONE, int NT, int EG = 1>
 __global__ __launch_bounds__(NT * EG, 3) void poly_block_kernel(PolyBlockArgs b) {
     constexpr int NJ = NT * kPolyR;
@@ -183,17 +191,34 @@ __global__ __launch_bounds__(NT * EG, 3) void poly_block_kernel(PolyBlockArgs b)
         for (int ph = ph0; ph < ph1; ++ph) {
             const double *ge = Gr + (int64_t)ph * b.apad;
             const double *xe = win + ph * b.se + 5 * t;     // poly_pad(4 t) = 5 t
-            for (int a0 = 0; a0 < b.apad; a0 += kPolyBlk) {
+            // taps of this phase stream: the others of its apad are the table's padding -- skipped, not
+            // multiplied (0 x NaN is NaN: a non-finite sample reaches the outputs whose TAPS touch it,
+            // zero-valued taps of the caller's window included, and no other)
+            const int cnt = ph < msub ? (msub - 1 - ph) / a.M + 1 : 0;
+            for (int a0 = 0; a0 < cnt; a0 += kPolyBlk) {
                 double g[kPolyBlk], xv[kPolyBlk + kPolyR - 1];
 #pragma unroll
                 for (int q = 0; q < kPolyBlk; ++q) g[q] = ge[a0 + q];      // wave-uniform
                 const double *xb = xe + (a0 + (a0 >> 2));                  // a0 multiple of 8
 #pragma unroll
                 for (int d = 0; d < kPolyBlk + kPolyR - 1; ++d) xv[d] = xb[d + (d >> 2)];
+                if (a0 + kPolyBlk <= cnt) {
 #pragma unroll
-                for (int q = 0; q < kPolyBlk; ++q)
+                    for (int q = 0; q < kPolyBlk; ++q)
 #pragma unroll
-                    for (int s = 0; s < kPolyR; ++s) acc[s] = fma(g[q], xv[s + q], acc[s]);
+                        for (int s = 0; s < kPolyR; ++s) acc[s] = fma(g[q], xv[s + q], acc[s]);
+                } else {
+                    // (the stream's last block: straight-line code per count of taps left, no branch per tap)
+                    switch (cnt - a0) {
+                        case 1: poly_taps<1>(acc, g, xv); break;
+                        case 2: poly_taps<2>(acc, g, xv); break;
+                        case 3: poly_taps<3>(acc, g, xv); break;
+                        case 4: poly_taps<4>(acc, g, xv); break;
+                        case 5: poly_taps<5>(acc, g, xv); break;
+                        case 6: poly_taps<6>(acc, g, xv); break;
+                        default: poly_taps<7>(acc, g, xv); break;
+                    }
+                }
             }
         }
         __syncthreads();                                // everyone is done with the window
@@ -259,9 +284,14 @@ static int64_t poly_end(const osz_poly_s *h, int64_t navail, int final_) {
 extern "C" {
 
 int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M, int nch) {
+    return osz_poly_create_centred(h, taps, ntaps, (ntaps - 1) / 2, L, M, nch);
+}
+
+int osz_poly_create_centred(osz_poly_t *h, const double *taps, int ntaps, int centre, int L, int M, int nch) {
     OSZ_REQUIRE(h && taps, "osz_poly_create: null argument");
     OSZ_REQUIRE(ntaps >= 1 && L >= 1 && M >= 1 && nch >= 1 && nch <= 65535,
                 "osz_poly_create: bad sizes (ntaps=%d L=%d M=%d nch=%d; nch <= 65535)", ntaps, L, M, nch);
+    OSZ_REQUIRE(centre >= 0 && centre < ntaps, "osz_poly_create_centred: centre=%d not a tap of %d", centre, ntaps);
     osz_poly_s *p = new osz_poly_s();
     p->device = 0;
     (void)hipGetDevice(&p->device);
@@ -269,7 +299,7 @@ int osz_poly_create(osz_poly_t *h, const double *taps, int ntaps, int L, int M, 
     p->L = L;
     p->M = M;
     p->nch = nch;
-    p->half = (ntaps - 1) / 2;
+    p->half = centre;
     p->H = (ntaps - 1 + L - 1) / L + 1;
     p->cur = 0;
     p->nin = p->nout = 0;

@@ -448,45 +448,52 @@ def test_fir_sosfilt_chain_nan_reach_is_the_references(nm, fed, taps_n, cs, nchu
         dev.chain_forward = plain
 
 
-@pytest.mark.parametrize("LM", [(1, 5), (3, 2), (2, 1), (1, 25)])
-def test_resample_nan_reach_is_local(nm, LM):
+@pytest.mark.parametrize("LM", [(1, 5), (3, 2), (2, 1), (1, 25), (2, 7), (1, 2)])
+def test_resample_nan_reach_is_the_references(nm, golden, LM):
     """The polyphase resampler (core/numerical.py:523-632: scipy.signal.resample_poly chunk by chunk)
-    is a sum in time: a non-finite sample reaches the outputs its taps touch and nothing else.
-    WHICH taps is where the three differ by a few samples -- a documented divergence:
-    SciPy pads the window with zeros in front and behind (n_pre_pad, n_post_pad, a multiple of L
-    per phase) and 0 x NaN is NaN there; the kernel pads every phase stream to a multiple of 8 taps;
-    the oracle's definition has no padding.  Pinned here: the kernel's non-finite outputs are SciPy's
-    give or take at most 16 at either end of a run, every other output equals SciPy's, resident and
-    host-fed, whatever the chunking."""
+    is a sum in time: a non-finite sample is lost to the outputs whose taps touch it -- the taps of
+    SciPy's PADDED window, 0 x NaN being NaN (tests/golden/g20: the reference's own masks).  The
+    generator hands the kernels that window (numerical._resample_padded, osz_poly_create_centred),
+    and they multiply every tap of it and no other: the same outputs lost, sample for sample, as
+    the reference (g20), SciPy and the oracle, resident and host-fed, whatever the chunking."""
     import scipy.signal as sps
     import torch
     from oracle import oracle as orc
     from openseize_amd.resampling.resampling import resample
     L, M = LM
+    # --- the reference's own masks (g20's input: make_golden.g20_input)
+    g = golden("g20_resample_nonfinite.npz")
+    if f"nout_L{L}_M{M}" in g:
+        n = int(g["n"])
+        x = np.random.default_rng(2020).standard_normal((4, n))
+        x[0, 0] = np.nan
+        x[0, 10_000] = np.nan
+        x[1, n - 1] = np.inf
+        x[1, 13_333] = np.nan
+        x[2, 17_000:] = np.nan
+        nout = int(g[f"nout_L{L}_M{M}"])
+        for cs in (5_000, 7_321):
+            lost = np.unpackbits(g[f"lost_L{L}_M{M}_cs{cs}"], axis=-1)[:, :nout].astype(bool)
+            for data in (x, torch.from_numpy(x).cuda()):
+                got = resample(data, L, M, 5000, chunksize=cs, axis=-1)
+                got = got.cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+                assert np.array_equal(~np.isfinite(got), lost), (LM, cs, np.argwhere(~np.isfinite(got) != lost)[:4])
+    # --- a longer stream against SciPy and the oracle
     n = 200_003
     x = _fir_case(L * 100 + M, 4, n, [(0, 0, "nan"), (0, 77_777, "inf"), (1, n - 1, "nan"), (2, 150_000, "tail")])
     h = orc.resample_filter(L, M, 5000)
     with np.errstate(invalid="ignore"):
         want = sps.resample_poly(x, L, M, axis=-1, window=h)
+        assert np.array_equal(np.isfinite(want), np.isfinite(orc.polyphase_resample(x, L, M, h)))
     ok = np.isfinite(want)
     assert ok[3].all() and not ok[0].all()
-    # outputs within 16 of an edge of SciPy's non-finite runs may go either way
-    edge = np.zeros_like(ok)
-    flips = np.argwhere(ok[:, 1:] != ok[:, :-1])
-    for c, i in flips:
-        edge[c, max(i - 16, 0):i + 18] = True
-    edge[:, :17] |= ~ok[:, :1]
-    edge[:, -17:] |= ~ok[:, -1:]
     for data in (x, torch.from_numpy(x).cuda()):
         for cs in (30_000, 70_001):
             got = resample(data, L, M, 5000, chunksize=cs, axis=-1)
             got = got.cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
             assert got.shape == want.shape
-            differs = ok != np.isfinite(got)
-            assert not (differs & ~edge).any(), (LM, cs, np.argwhere(differs & ~edge)[:4])
-            assert differs.sum() <= 32 * (len(flips) + 2)
-            both = ok & np.isfinite(got)
-            assert np.max(np.abs(got[both] - want[both])) < RTOL * np.max(np.abs(want[both]))
+            assert np.array_equal(ok, np.isfinite(got)), (LM, cs, np.argwhere(ok != np.isfinite(got))[:4])
+            assert np.max(np.abs(got[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
 
 
 @pytest.mark.parametrize("fed", ["resident", "host"])
