@@ -53,6 +53,9 @@ struct PrepArgs {
     int nwin, nfft, stride, nch, detrend;  // nwin samples per segment, zero-padded to nfft
 };
 
+__device__ __forceinline__ bool spec_finite(double v) { return __builtin_isfinite(v); }
+__device__ __forceinline__ double spec_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
 __device__ __forceinline__ double block_sum(double v, double *red) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     const int w = threadIdx.x >> 6;
@@ -365,6 +368,21 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) im[j] = 0.0;
         }
+        // A non-finite sample costs the reference ITS segment (detrend, window, rfft of a segment:
+        // core/numerical.py:691-716); here two segments ride one transform, so the one that is not
+        // finite goes in as zeros -- the other's spectrum stays what it is -- and comes out as NaN.
+        // (The average, MODE 0, is lost either way: nothing to keep apart.)
+        const bool bad_a = MODE != OSZ_SPEC_PSD_MEAN && !spec_finite(mean_a + slope_a);
+        const bool bad_b = MODE != OSZ_SPEC_PSD_MEAN && has_b && !spec_finite(mean_b + slope_b);
+        if (MODE != OSZ_SPEC_PSD_MEAN && bad_a != bad_b) {
+            if (bad_a) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) re[j] = 0.0;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) im[j] = 0.0;
+            }
+        }
         // ---- forward transform of a + i b
         int tt = t;   // opaque copy: keeps the LDS slot numbers out of loop-invariant registers
         asm volatile("" : "+v"(tt));
@@ -433,8 +451,10 @@ __global__ __launch_bounds__(256, 2) void spec_cube_kernel(FusedArgs a) {
             const int jp = t == 0 ? ((16 - j) & 15) : 15 - j;   // N - k = tp + 256 jp
             const C2 q = L[fft::cube::slot_c(tp, jp)];
             const double zr = re[r], zi = im[r], qr = q.re, qi = q.im;
-            const double ar = 0.5 * (zr + qr), ai = 0.5 * (zi - qi);
-            const double br = 0.5 * (zi + qi), bi = -0.5 * (zr - qr);
+            double ar = 0.5 * (zr + qr), ai = 0.5 * (zi - qi);
+            double br = 0.5 * (zi + qi), bi = -0.5 * (zr - qr);
+            if (bad_a) ar = ai = spec_nan();
+            if (bad_b) br = bi = spec_nan();
             const bool dbl = (k != 0) && (k != fft::N / 2);
             if (MODE == OSZ_SPEC_DFT_SEGMENTS) {
                 double *o = (double *)a.out;
@@ -669,6 +689,16 @@ __global__ __launch_bounds__(N / 8, 4) void spec8_kernel(Spec8Args a) {
                 im[r] = has_b ? (im[r] - mean_b) * win[r] : 0.0;
             }
         }
+        // (a segment that is not finite goes in as zeros and comes out as NaN: spec_cube_kernel)
+        const bool bad_a = MODE != OSZ_SPEC_PSD_MEAN && !spec_finite(mean_a + slope_a);
+        const bool bad_b = MODE != OSZ_SPEC_PSD_MEAN && has_b && !spec_finite(mean_b + slope_b);
+        if (MODE != OSZ_SPEC_PSD_MEAN && bad_a != bad_b) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (bad_a) re[r] = 0.0;
+                else im[r] = 0.0;
+            }
+        }
         // ---- forward transform of a + i b (one barrier per exchange)
         int tt = t;   // opaque copy: keeps the LDS slot numbers out of loop-invariant registers
         asm volatile("" : "+v"(tt));
@@ -692,8 +722,10 @@ __global__ __launch_bounds__(N / 8, 4) void spec8_kernel(Spec8Args a) {
             if (jj == 4 && t != 0) continue;
             const C2 z = lds8[fft8::swz_nat(k)];
             const C2 q = lds8[fft8::swz_nat((N - k) & (N - 1))];
-            const double ar = 0.5 * (z.re + q.re), ai = 0.5 * (z.im - q.im);
-            const double br = 0.5 * (z.im + q.im), bi = -0.5 * (z.re - q.re);
+            double ar = 0.5 * (z.re + q.re), ai = 0.5 * (z.im - q.im);
+            double br = 0.5 * (z.im + q.im), bi = -0.5 * (z.re - q.re);
+            if (bad_a) ar = ai = spec_nan();
+            if (bad_b) br = bi = spec_nan();
             const bool dbl = (k != 0) && (k != N / 2);
             if (MODE == OSZ_SPEC_DFT_SEGMENTS) {
                 double *o = (double *)a.out;
@@ -873,11 +905,19 @@ __global__ __launch_bounds__(N / 8, 2) void spec_blue_kernel(BlueArgs a) {
             slope_a = sxx > 0.0 ? tot[2] / sxx : 0.0;
             slope_b = sxx > 0.0 ? tot[3] / sxx : 0.0;
         }
+        // (a segment that is not finite goes in as zeros and comes out as NaN: spec_cube_kernel)
+        const bool bad_a = MODE != OSZ_SPEC_PSD_MEAN && !spec_finite(mean_a + slope_a);
+        const bool bad_b = MODE != OSZ_SPEC_PSD_MEAN && has_b && !spec_finite(mean_b + slope_b);
+        const bool drop_a = bad_a && !bad_b, drop_b = bad_b && !bad_a;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int i = NT * r + t;
             double va = (LINEAR ? re[r] - mean_a - slope_a * (i - mid) : re[r] - mean_a) * win[r];
             double vb = has_b ? (LINEAR ? im[r] - mean_b - slope_b * (i - mid) : im[r] - mean_b) * win[r] : 0.0;
+            if (MODE != OSZ_SPEC_PSD_MEAN) {
+                if (drop_a) va = 0.0;
+                if (drop_b) vb = 0.0;
+            }
             fft8::cmul(va, vb, RES ? cr[RES ? r : 0] : a.chirp[2 * i], RES ? ci[RES ? r : 0] : a.chirp[2 * i + 1]);
             re[r] = va;
             im[r] = vb;
@@ -916,8 +956,10 @@ __global__ __launch_bounds__(N / 8, 2) void spec_blue_kernel(BlueArgs a) {
             const int k = NT * r + tt;
             if (k >= NF) continue;
             const C2 z = lds8[k], q = lds8[k == 0 ? 0 : n - k];
-            const double ar = 0.5 * (z.re + q.re), ai = 0.5 * (z.im - q.im);
-            const double br_ = 0.5 * (z.im + q.im), bi_ = -0.5 * (z.re - q.re);
+            double ar = 0.5 * (z.re + q.re), ai = 0.5 * (z.im - q.im);
+            double br_ = 0.5 * (z.im + q.im), bi_ = -0.5 * (z.re - q.re);
+            if (bad_a) ar = ai = spec_nan();
+            if (bad_b) br_ = bi_ = spec_nan();
             const bool dbl = k != 0 && !(2 * k == n);
             if (MODE == OSZ_SPEC_DFT_SEGMENTS) {
                 double *o = (double *)a.out;

@@ -531,3 +531,46 @@ def test_fir_sosfiltfilt_off_the_one_kernel_route_keeps_the_references_reach(nm,
     assert ok[3].all() and not ok[0].all()
     tol = RTOL if kind == "five chunks" else 1e-7        # (nine narrow-band sections: the cascade's own conditioning)
     assert np.max(np.abs(got[ok] - want[ok])) < tol * np.max(np.abs(want[ok]))
+
+
+@pytest.mark.parametrize("nfft", [4096, 1024, 1000, 50000, 347, 4099])
+def test_spectra_nan_reach_is_the_segments(nm, nfft):
+    """Welch / STFT (core/numerical.py:635-1087): a non-finite sample costs the reference the
+    segments that hold it (detrend, window, rfft of a segment) -- the whole PSD of the channel in the
+    average, the segment's column in the STFT -- on every transform route here (cube, fft8, mixed
+    radix, pairs of sub-transforms, chirp, rocFFT staging): the same entries non-finite as the oracle's."""
+    import torch
+    from oracle import oracle as orc
+    from openseize_amd.spectra.estimators import psd, stft
+    rng = np.random.default_rng(nfft)
+    n = 7 * nfft + 123
+    x = rng.standard_normal((4, n))
+    x[0, 3 * nfft + 5] = np.nan                  # in two overlapping segments
+    x[1, n - 1] = np.inf                         # behind the last whole segment of the PSD
+    x[2, 0] = np.nan
+    for data in (x, torch.from_numpy(x).cuda()):
+        cnt, f, p = psd(data, fs=nfft, axis=-1, resolution=1.0)
+        p = p.cpu().numpy() if torch.is_tensor(p) else p
+        with np.errstate(invalid="ignore"):
+            rc, rf, rp = orc.psd(x, nfft, resolution=1.0)
+        assert cnt == rc and np.array_equal(np.isfinite(p), np.isfinite(rp))
+        ok = np.isfinite(rp)
+        assert ok[3].all() and not ok[0].any()
+        assert np.max(np.abs(p[ok] - rp[ok])) < RTOL * np.max(np.abs(rp[ok]))
+        ft, tt, X = stft(data, fs=nfft, axis=-1, resolution=1.0, overlap=0.5, boundary=True, padded=True)
+        X = X.cpu().numpy() if torch.is_tensor(X) else X
+        with np.errstate(invalid="ignore"):
+            _, _, rX = orc.stft(x, nfft, resolution=1.0)
+        assert X.shape == rX.shape and np.array_equal(np.isfinite(X), np.isfinite(rX))
+        ok = np.isfinite(rX)
+        assert np.max(np.abs(X[ok] - rX[ok])) < RTOL * np.max(np.abs(rX[ok]))
+        # segments that do not overlap: the bad one's neighbour -- its partner in a transform that
+        # carries two segments (cube, fft8, chirp kernels) -- stays what it is
+        ft, tt, X = stft(data, fs=nfft, axis=-1, resolution=1.0, overlap=0.0, boundary=False, padded=False)
+        X = X.cpu().numpy() if torch.is_tensor(X) else X
+        with np.errstate(invalid="ignore"):
+            _, _, rX = orc.stft(x, nfft, resolution=1.0, overlap=0.0, boundary=False, padded=False)
+        assert X.shape == rX.shape and np.array_equal(np.isfinite(X), np.isfinite(rX))
+        ok = np.isfinite(rX)
+        assert ok[0][:, 2].all() and not ok[0][:, 3].any() and ok[0][:, 4].all()      # (sample 3 nfft + 5: segment 3 alone)
+        assert np.max(np.abs(X[ok] - rX[ok])) < RTOL * np.max(np.abs(rX[ok]))
