@@ -187,6 +187,7 @@ __global__ __launch_bounds__(NT * EG, 3) void poly_block_kernel(PolyBlockArgs b)
 #pragma unroll
         for (int s = 0; s < kPolyR; ++s) acc[s] = 0.0;
         const double *Gr = b.G + (int64_t)r * a.M * b.apad;
+        const int cq = msub > 0 ? (msub - 1) / a.M : 0, crem = msub > 0 ? (msub - 1) - cq * a.M : -1;   // (one division per class)
         const int ph0 = EG == 1 ? 0 : (eg * a.M) / EG, ph1 = EG == 1 ? a.M : ((eg + 1) * a.M) / EG;
         for (int ph = ph0; ph < ph1; ++ph) {
             const double *ge = Gr + (int64_t)ph * b.apad;
@@ -194,30 +195,41 @@ __global__ __launch_bounds__(NT * EG, 3) void poly_block_kernel(PolyBlockArgs b)
             // taps of this phase stream: the others of its apad are the table's padding -- skipped, not
             // multiplied (0 x NaN is NaN: a non-finite sample reaches the outputs whose TAPS touch it,
             // zero-valued taps of the caller's window included, and no other)
-            const int cnt = ph < msub ? (msub - 1 - ph) / a.M + 1 : 0;
-            for (int a0 = 0; a0 < cnt; a0 += kPolyBlk) {
+#ifdef OSZ_POLY_MULPAD     // (A/B builds: the table's padding multiplied as in rounds 1-4)
+            const int cnt = b.apad;
+#else
+            const int cnt = ph <= crem ? cq + 1 : cq;      // = (msub - 1 - ph) / M + 1, or 0 behind the taps
+#endif
+            const int nfull = cnt & ~(kPolyBlk - 1);
+            for (int a0 = 0; a0 < nfull; a0 += kPolyBlk) {
                 double g[kPolyBlk], xv[kPolyBlk + kPolyR - 1];
 #pragma unroll
                 for (int q = 0; q < kPolyBlk; ++q) g[q] = ge[a0 + q];      // wave-uniform
                 const double *xb = xe + (a0 + (a0 >> 2));                  // a0 multiple of 8
 #pragma unroll
                 for (int d = 0; d < kPolyBlk + kPolyR - 1; ++d) xv[d] = xb[d + (d >> 2)];
-                if (a0 + kPolyBlk <= cnt) {
 #pragma unroll
-                    for (int q = 0; q < kPolyBlk; ++q)
+                for (int q = 0; q < kPolyBlk; ++q)
 #pragma unroll
-                        for (int s = 0; s < kPolyR; ++s) acc[s] = fma(g[q], xv[s + q], acc[s]);
-                } else {
-                    // (the stream's last block: straight-line code per count of taps left, no branch per tap)
-                    switch (cnt - a0) {
-                        case 1: poly_taps<1>(acc, g, xv); break;
-                        case 2: poly_taps<2>(acc, g, xv); break;
-                        case 3: poly_taps<3>(acc, g, xv); break;
-                        case 4: poly_taps<4>(acc, g, xv); break;
-                        case 5: poly_taps<5>(acc, g, xv); break;
-                        case 6: poly_taps<6>(acc, g, xv); break;
-                        default: poly_taps<7>(acc, g, xv); break;
-                    }
+                    for (int s = 0; s < kPolyR; ++s) acc[s] = fma(g[q], xv[s + q], acc[s]);
+            }
+            if (cnt > nfull) {
+                // the stream's last block: straight-line code per count of taps left, nothing of the
+                // table's padding multiplied
+                double g[kPolyBlk], xv[kPolyBlk + kPolyR - 1];
+#pragma unroll
+                for (int q = 0; q < kPolyBlk; ++q) g[q] = ge[nfull + q];
+                const double *xb = xe + (nfull + (nfull >> 2));
+#pragma unroll
+                for (int d = 0; d < kPolyBlk + kPolyR - 1; ++d) xv[d] = xb[d + (d >> 2)];
+                switch (cnt - nfull) {
+                    case 1: poly_taps<1>(acc, g, xv); break;
+                    case 2: poly_taps<2>(acc, g, xv); break;
+                    case 3: poly_taps<3>(acc, g, xv); break;
+                    case 4: poly_taps<4>(acc, g, xv); break;
+                    case 5: poly_taps<5>(acc, g, xv); break;
+                    case 6: poly_taps<6>(acc, g, xv); break;
+                    default: poly_taps<7>(acc, g, xv); break;
                 }
             }
         }
