@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 17
+        kind = it % 19
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -278,6 +278,63 @@ def main():
                 else:
                     e = float(np.max(np.abs(got_[ok] - ref_[ok])) / np.max(np.abs(ref_[ok]))) if ok.any() else 0.0
                 what = f"fir->sosfilt nonfinite taps={taps} C={C} cs={cs} total={total} resident={torch.is_tensor(data)}"
+            elif kind == 17:   # non-finite samples through the resampler: the outputs SciPy's padded window touches
+                L, M = [(1, 2), (1, 5), (1, 10), (1, 20), (2, 1), (3, 1), (3, 2), (2, 7), (5, 3), (4, 25), (7, 5)][int(rng.integers(0, 11))]
+                n = interesting_length(rng, 12000, 90000)
+                C = int(rng.choice([1, 2, 5]))
+                xh = rng.standard_normal((C, n))
+                for _ in range(int(rng.integers(1, 5))):
+                    c, at = int(rng.integers(0, C)), int(rng.integers(0, n))
+                    r = rng.random()
+                    if r < 0.2:
+                        xh[c, at:] = np.nan
+                    else:
+                        xh[c, at] = np.nan if r < 0.8 else np.inf
+                cs = int(rng.integers(3000, 40000))
+                data = torch.from_numpy(xh).cuda() if rng.random() < 0.5 else xh
+                y = rs.resample(data, L, M, 5000, cs, -1)
+                y = y.cpu().numpy() if torch.is_tensor(y) else np.asarray(y)
+                fc = 5000 / (2 * max(L, M))
+                h = Kaiser(fc - fc / 10, fc + fc / 10, 5000, gpass=0.1, gstop=40).coeffs
+                with np.errstate(invalid="ignore"):
+                    ref_ = sps.resample_poly(xh, L, M, axis=-1, window=h)
+                ok = np.isfinite(ref_)
+                if y.shape != ref_.shape or not np.array_equal(ok, np.isfinite(y)):
+                    e = float("inf")
+                else:
+                    e = float(np.max(np.abs(y[ok] - ref_[ok])) / np.max(np.abs(ref_[ok]))) if ok.any() else 0.0
+                what = f"resample nonfinite {L}/{M} n={n} C={C} cs={cs} resident={torch.is_tensor(data)}"
+            elif kind == 18:   # non-finite samples through the STFT: the segments that hold them, on every route
+                from openseize_amd.spectra.estimators import stft
+                fs = float(rng.choice([250, 500, 1000, 173.61, 700, 1111, 4096, 2048, 347]))
+                res = float(rng.choice([0.5, 1.0, 2.0]))
+                nfft = int(fs / res)
+                n = interesting_length(rng, 3 * nfft, max(40000, 4 * nfft))
+                C = int(rng.integers(1, 4))
+                xh = rng.standard_normal((C, n))
+                for _ in range(int(rng.integers(1, 4))):
+                    xh[int(rng.integers(0, C)), int(rng.integers(0, n))] = np.nan if rng.random() < 0.7 else np.inf
+                ov = float(rng.choice([0.0, 0.25, 0.5, 0.75]))
+                b, pd_ = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+                det = ("constant", "linear")[int(rng.integers(0, 2))]
+                with np.errstate(invalid="ignore"):
+                    rf, rt, rX = orc.stft(xh, fs, resolution=res, overlap=ov, detrend="constant", boundary=b, padded=pd_)
+                if det == "linear":
+                    # (SciPy's least-squares trend refuses non-finite data -- the reference raises -- as soon
+                    # as a segment holds such a sample: iff the constant-trend result has a lost segment)
+                    try:
+                        stft(xh, fs, axis=-1, resolution=res, overlap=ov, detrend=det, boundary=b, padded=pd_)
+                        e = 0.0 if np.isfinite(rX).all() else float("inf")
+                    except ValueError as exc:
+                        e = 0.0 if "infs or NaNs" in str(exc) and not np.isfinite(rX).all() else float("inf")
+                else:
+                    f, t, X = stft(xh, fs, axis=-1, resolution=res, overlap=ov, detrend=det, boundary=b, padded=pd_)
+                    ok = np.isfinite(rX)
+                    if X.shape != rX.shape or not np.array_equal(ok, np.isfinite(X)):
+                        e = float("inf")
+                    else:
+                        e = float(np.max(np.abs(X[ok] - rX[ok])) / np.max(np.abs(rX[ok]))) if ok.any() else 0.0
+                what = f"stft nonfinite fs={fs} res={res} n={n} C={C} ov={ov} boundary={b} padded={pd_} {det}"
             elif kind == 13:   # plain sosfiltfilt of a long resident stream, any layout: grouped zero-phase steps
                 ndim = int(rng.integers(1, 4))
                 axis = int(rng.integers(0, ndim))

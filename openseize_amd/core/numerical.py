@@ -1545,6 +1545,28 @@ def _window_and_scale(window, nwin, fs, scaling):
     return coeffs, float(np.sqrt(norm))
 
 
+def _linear_trend_refuses(out, detrend):
+    """``scipy.signal.detrend(type='linear')`` is a least-squares fit, and SciPy's ``lstsq`` REFUSES
+    non-finite data: the reference raises ``ValueError: array must not contain infs or NaNs`` at
+    core/numerical.py:691 when a segment of any channel holds such a sample (type='constant'
+    subtracts a mean: NaN goes through, there and here).  The kernels give such a segment back as
+    NaN; this looks at one bin per segment and channel of what a push produced -- linear trend
+    only -- and returns the index of the first segment the reference would have refused (None: none).
+    ``out``: (segments, channels, bins)."""
+    if detrend != "linear" or out.shape[0] == 0:
+        return None
+    probe = out[..., 0]                                  # (segments, channels): a lost segment is lost in every bin
+    if dev.is_tensor(out):
+        import torch
+        bad = ~torch.isfinite(probe).reshape(out.shape[0], -1).all(1)
+        return int(torch.nonzero(bad)[0, 0]) if bool(bad.any()) else None
+    bad = ~np.isfinite(probe).reshape(out.shape[0], -1).all(1)
+    return int(np.flatnonzero(bad)[0]) if bad.any() else None
+
+
+_REFUSED = "array must not contain infs or NaNs"
+
+
 def _one_shot(arr, fs, nfft, window, axis, detrend, scaling, mode):
     axis = normalize_axis(axis, arr.ndim)
     nsamples = arr.shape[axis]
@@ -1566,6 +1588,8 @@ def _one_shot(arr, fs, nfft, window, axis, detrend, scaling, mode):
     try:
         x2d, host = layout.to2d(arr)
         out = spec.push(x2d)          # (1, nch, nfreq)
+        if _linear_trend_refuses(out, detrend) is not None:
+            raise ValueError(_REFUSED)
         res = layout.from2d(out[0], host)
     finally:
         spec.close()
@@ -1673,11 +1697,14 @@ def _spectra_estimatives(pro, fs, nfft, window, overlap, axis, detrend,
             nseg = out.shape[0]
             if nseg == 0:
                 continue
+            refused = _linear_trend_refuses(out, detrend)      # (nseg, nch, nfreq): before the axes move
             out = out.reshape((nseg,) + layout.other + (out.shape[-1],))
             out = out.movedim(-1, layout.axis + 1)
             out = out.cpu().numpy() if host else out
-            for s in range(nseg):
+            for s in range(nseg if refused is None else refused):
                 yield out[s]
+            if refused is not None:
+                raise ValueError(_REFUSED)
     finally:
         spec.close()
 

@@ -50,6 +50,9 @@ def psd(data, fs, axis=-1, resolution=0.5, window="hann", overlap=0.5,
         cnt, mean = spec.mean() if host else spec.mean_device()
     finally:
         spec.close()
+    if nm._linear_trend_refuses(mean[None], detrend) is not None:
+        # (a least-squares trend refuses non-finite data in the reference: core/numerical.py:691)
+        raise ValueError(nm._REFUSED)
     if cnt == 0:
         # the reference's loop variable is unbound here (estimators.py:156)
         raise UnboundLocalError(

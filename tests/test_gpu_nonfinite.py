@@ -574,3 +574,37 @@ def test_spectra_nan_reach_is_the_segments(nm, nfft):
         ok = np.isfinite(rX)
         assert ok[0][:, 2].all() and not ok[0][:, 3].any() and ok[0][:, 4].all()      # (sample 3 nfft + 5: segment 3 alone)
         assert np.max(np.abs(X[ok] - rX[ok])) < RTOL * np.max(np.abs(rX[ok]))
+
+
+def test_linear_trend_refuses_nonfinite_data_as_the_reference_does(nm):
+    """detrend='linear' is scipy.signal.detrend's least-squares fit, and SciPy's lstsq refuses
+    non-finite data: the reference raises ValueError('array must not contain infs or NaNs') at
+    core/numerical.py:691 as soon as a segment of ANY channel holds such a sample (the segments
+    before it have been handed on).  So does this library, on every entry point; a constant trend
+    lets the NaN through (test_spectra_nan_reach_is_the_segments)."""
+    import scipy.signal as sps
+    import torch
+    from openseize_amd.spectra.estimators import psd, stft
+    nfft = 1000
+    x = np.random.default_rng(3).standard_normal((3, 9 * nfft))
+    x[1, 5 * nfft + 7] = np.nan
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        sps.detrend(x[:, 5 * nfft:6 * nfft], axis=-1, type="linear")          # what the reference calls
+    for data in (x, torch.from_numpy(x).cuda()):
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            psd(data, fs=nfft, axis=-1, resolution=1.0, detrend="linear")
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            stft(data, fs=nfft, axis=-1, resolution=1.0, detrend="linear")
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            nm.periodogram(data[:, 5 * nfft:6 * nfft], fs=nfft, nfft=nfft, detrend="linear")
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            nm.modified_dft(data[:, 5 * nfft:6 * nfft], nfft, nfft, "hann", -1, "linear", "density")
+        # the per-segment generator hands on the segments before the refused one (no overlap: five)
+        freqs, pro = nm.welch(producer(data, 2 * nfft, -1), nfft, nfft, "hann", 0.0, -1, "linear", "density")
+        got = []
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            for seg in pro:
+                got.append(seg)
+        assert len(got) == 5
+        # finite data: nothing refused
+        psd(data[:, :5 * nfft], fs=nfft, axis=-1, resolution=1.0, detrend="linear")
