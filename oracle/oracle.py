@@ -427,6 +427,10 @@ def _detrend(x, kind):
     if kind == "constant":
         return x - x.mean(axis=-1, keepdims=True)
     if kind == "linear":
+        if not np.isfinite(x).all():
+            # scipy.signal.detrend(type='linear') fits by scipy.linalg.lstsq, which refuses
+            # non-finite data: the reference raises here (core/numerical.py:691)
+            raise ValueError("array must not contain infs or NaNs")
         n = x.shape[-1]
         t = np.arange(1, n + 1, dtype=np.float64) / n
         A = np.stack([t, np.ones(n)], axis=1)

@@ -267,3 +267,18 @@ def test_oracle_resample_nonfinite_reach_is_the_references(golden):
         ref = sps.resample_poly(clean, L, M, axis=-1, window=h)
         # (a finite output touches no non-finite sample: the cleaned stream gives the same number)
         assert np.max(np.abs(y[ok] - ref[ok])) < 1e-12 * np.max(np.abs(ref))
+
+
+def test_oracle_linear_trend_refuses_nonfinite_data():
+    """scipy.signal.detrend(type='linear') -- what the reference calls at core/numerical.py:691 --
+    raises on non-finite data (scipy.linalg.lstsq's check); so does the oracle, and a constant
+    trend lets the NaN through."""
+    import scipy.signal as sps
+    x = np.random.default_rng(0).standard_normal((2, 3000))
+    x[0, 1500] = np.nan
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        sps.detrend(x, axis=-1, type="linear")
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        orc.psd(x, 1000, resolution=1.0, detrend="linear")
+    cnt, f, p = orc.psd(x, 1000, resolution=1.0, detrend="constant")
+    assert np.isnan(p[0]).all() and np.isfinite(p[1]).all()
