@@ -18,7 +18,7 @@ python benchmarks/tutorial_shape.py > $O/tutorial_shape.jsonl 2> $O/e11.log
 python benchmarks/bench_kernels.py > $O/secondary_kernels.jsonl 2> $O/e12.log
 python benchmarks/dc_probe.py > $O/dc_probe.txt 2> $O/e13.log
 python benchmarks/large_nfft.py > $O/large_nfft.jsonl 2> $O/e14.log
-python benchmarks/fuzz_gpu.py 4200 505 > $O/fuzz.txt 2>&1
+python tests/fuzz_gpu.py 4200 505 > $O/fuzz.txt 2>&1
 tail -3 $O/fuzz.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 tail -2 $O/smoke.txt

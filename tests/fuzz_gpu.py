@@ -4,7 +4,7 @@
 lengths around block / tile / chunk boundaries, odd chunk sizes, long filters,
 ragged last chunks, every mode and axis position.
 
-    python benchmarks/fuzz_gpu.py [iterations] [seed]
+    python tests/fuzz_gpu.py [iterations] [seed]
 """
 import os
 import sys

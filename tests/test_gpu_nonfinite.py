@@ -235,7 +235,7 @@ def test_nan_reach_is_decided_by_the_sample_not_by_the_block(nm):
     is per CHUNK (core/numerical.py:397-411: a chunk is NaN as a whole when the forward stream is
     NaN in it or in the chunk after it).  A NaN tail that begins 2579 samples into chunk 3 lies in
     a block that begins in chunk 2: the kernel records the SAMPLE (zp_exact_nanpos, chain_zp.h),
-    chunk 1 stays finite as in the reference (found by benchmarks/fuzz_gpu.py, seed 505)."""
+    chunk 1 stays finite as in the reference (found by tests/fuzz_gpu.py, seed 505)."""
     import scipy.signal as sps
     import torch
     from oracle import oracle as orc

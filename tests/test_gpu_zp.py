@@ -453,7 +453,7 @@ def test_few_channels_take_several_chunks_per_launch(dev):
         want = orc.sosfiltfilt(u, BP, cs)
         assert np.max(np.abs(y[pick].cpu().numpy() - want)) < RTOL * np.max(np.abs(want))
     # a single channel as a 1-D array (its chunk views carry a row pitch of their own length: the
-    # joined view must not inherit it -- found by benchmarks/fuzz_gpu.py)
+    # joined view must not inherit it -- found by tests/fuzz_gpu.py)
     x1 = x[3, :cs * 9 + 99].contiguous()
     sizes, plain = [], dev.chain_zp_step
     dev.chain_zp_step = lambda *a, **k: (sizes.append(a[2].shape[1] // cs), plain(*a, **k))[1]
