@@ -55,7 +55,7 @@ def main():
                sps.cheby1(5, 1, 0.3, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad = 0
     for it in range(cases):
-        kind = it % 6
+        kind = it % 10
         C = int(rng.integers(1, 4))
         msg = None
         try:
@@ -106,7 +106,52 @@ def main():
                 what = f"psd fs={fs} res={res} n={n} ov={ov}"
                 oc, of, op = orc.psd(x, fs, resolution=res, overlap=ov)
                 msg = same(op, p) if oc == cnt else f"count {oc} vs {cnt}"
-            else:
+            elif kind == 6:     # transfer-function filters (b, a), forward
+                n = int(rng.integers(300, 40000))
+                x = poison(rng, rng.standard_normal((C, n)))
+                coeffs = [sps.butter(2, 0.3), sps.iirnotch(0.24, 8.0), sps.butter(4, [0.1, 0.4], "bandpass"),
+                          sps.cheby1(3, 1, 0.25)][int(rng.integers(0, 4))]
+                cs = int(rng.integers(50, n + 50))
+                want = np.concatenate(list(ref.lfilter(producer(x, cs, -1), coeffs, -1)), -1)
+                what = f"lfilter order={len(coeffs[1]) - 1} n={n} cs={cs}"
+                msg = same(orc.lfilter(x, coeffs, cs)[0], want, 1e-8)
+            elif kind == 7:     # ... forward-backward
+                n = int(rng.integers(600, 40000))
+                x = poison(rng, rng.standard_normal((C, n)))
+                coeffs = [sps.butter(2, 0.3), sps.iirnotch(0.24, 8.0), sps.butter(4, [0.1, 0.4], "bandpass")][int(rng.integers(0, 3))]
+                cs = int(rng.integers(200, n + 50))
+                want = np.concatenate(list(ref.filtfilt(producer(x, cs, -1), coeffs, -1)), -1)
+                what = f"filtfilt order={len(coeffs[1]) - 1} n={n} cs={cs}"
+                msg = same(orc.filtfilt(x, coeffs, cs), want, 1e-8)
+            elif kind == 8:     # periodogram: padding and cropping, both trends on finite data, windows, scalings
+                n = int(rng.integers(50, 3000))
+                x = rng.standard_normal((C, n)) + rng.standard_normal()
+                det = ("constant", "linear")[int(rng.integers(0, 2))]
+                if det == "constant":
+                    x = poison(rng, x, 0.4)
+                nfft = [None, n, n + int(rng.integers(1, 500)), max(n - int(rng.integers(1, 40)), 8)][int(rng.integers(0, 4))]
+                win = ("hann", "hamming", "boxcar", "blackman")[int(rng.integers(0, 4))]
+                sc = ("density", "spectrum")[int(rng.integers(0, 2))]
+                f, p = ref.periodogram(x, 500.0, nfft=nfft, window=win, axis=-1, detrend=det, scaling=sc)
+                what = f"periodogram n={n} nfft={nfft} {win} {det} {sc}"
+                of, op = orc.periodogram(x, 500.0, nfft=nfft, window=win, detrend=det, scaling=sc)
+                msg = same(op, p) or (None if np.allclose(of, f) else "freqs differ")
+            elif kind == 9:     # the per-segment Welch producer
+                fs = float(rng.choice([250, 500, 173.61]))
+                nfft = int(fs / float(rng.choice([0.5, 1.0, 2.0])))
+                n = int(rng.integers(3 * nfft, 10 * nfft))
+                x = poison(rng, rng.standard_normal((C, n)), 0.5)
+                ov = float(rng.choice([0.0, 0.25, 0.5, 0.75]))
+                win = ("hann", "hamming", "boxcar")[int(rng.integers(0, 3))]
+                sc = ("density", "spectrum")[int(rng.integers(0, 2))]
+                cs = int(rng.integers(nfft, 4 * nfft))
+                freqs, pro = ref.welch(producer(x, cs, -1), fs, nfft, win, ov, -1, "constant", sc)
+                want = np.stack(list(pro), -1)
+                what = f"welch segments fs={fs} nfft={nfft} n={n} ov={ov} {win} {sc} cs={cs}"
+                got = orc.welch_segments(x, fs, nfft, win, ov, "constant", sc)
+                got = got[1] if isinstance(got, tuple) else got
+                msg = same(np.asarray(got), want) if np.asarray(got).shape == want.shape else same(np.moveaxis(np.asarray(got), 0, -1), want)
+            elif kind == 5:
                 fs = float(rng.choice([250, 500, 173.61, 1000]))
                 res = float(rng.choice([0.5, 1.0, 2.0]))
                 nfft = int(fs / res)
