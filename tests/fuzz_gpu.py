@@ -61,7 +61,7 @@ def main():
                sps.butter(8, 0.02, output="sos"), sps.butter(3, 0.6, "highpass", output="sos")]
     bad, t0 = 0, time.time()
     for it in range(iters):
-        kind = it % 19
+        kind = it % 21
         try:
             if kind == 0:      # FIR
                 taps = int(rng.choice([2, 3, 17, 76, 255, 256, 257, 511, 1023, 1024, 1025, 2049, 2050, 3000, 4097]))
@@ -141,6 +141,51 @@ def main():
                 z = np.concatenate(list(nm.filtfilt(producer(x, cs, -1), (b_, a_), -1)), -1)
                 e2 = rel(z, orc.filtfilt(x, (b_, a_), cs))
                 e, what = max(e1 / 10, e2 / 100), f"ba order={order} n={n} cs={cs} (lfilter {e1:.1e}, filtfilt {e2:.1e})"
+            elif kind == 19:   # non-finite samples through the transfer-function filters: as far as in the reference
+                n = interesting_length(rng, 1000, 60000)
+                C = int(rng.integers(1, 4))
+                x = rng.standard_normal((C, n))
+                for _ in range(int(rng.integers(1, 4))):
+                    x[int(rng.integers(0, C)), int(rng.integers(0, n))] = np.nan if rng.random() < 0.7 else np.inf
+                order = int(rng.choice([1, 2, 4]))
+                b_, a_ = sps.butter(order, float(rng.uniform(0.05, 0.6)))
+                cs = int(rng.integers(300, n + 10))
+                dev_in = rng.random() < 0.5
+                src = torch.from_numpy(x).cuda() if dev_in else x
+                y = np.concatenate([o.cpu().numpy() if dev_in else o for o in nm.lfilter(producer(src, cs, -1), (b_, a_), -1)], -1)
+                z = np.concatenate([o.cpu().numpy() if dev_in else o for o in nm.filtfilt(producer(src, cs, -1), (b_, a_), -1)], -1)
+                with np.errstate(invalid="ignore"):
+                    ry, rz = orc.lfilter(x, (b_, a_), cs)[0], orc.filtfilt(x, (b_, a_), cs)
+                e = 0.0
+                for got_, ref_ in ((y, ry), (z, rz)):
+                    ok = np.isfinite(ref_)
+                    if got_.shape != ref_.shape or not np.array_equal(ok, np.isfinite(got_)):
+                        e = float("inf")
+                    elif ok.any():
+                        e = max(e, float(np.max(np.abs(got_[ok] - ref_[ok])) / np.max(np.abs(ref_[ok]))) / 100)
+                what = f"ba nonfinite order={order} n={n} C={C} cs={cs} dev={dev_in}"
+            elif kind == 20:   # non-finite samples through the per-segment Welch producer
+                fs = float(rng.choice([250, 500, 1000, 173.61, 4096, 347]))
+                nfft = int(fs / float(rng.choice([0.5, 1.0, 2.0])))
+                n = interesting_length(rng, 3 * nfft, max(30000, 5 * nfft))
+                C = int(rng.integers(1, 4))
+                x = rng.standard_normal((C, n))
+                for _ in range(int(rng.integers(1, 4))):
+                    x[int(rng.integers(0, C)), int(rng.integers(0, n))] = np.nan if rng.random() < 0.7 else np.inf
+                ov = float(rng.choice([0.0, 0.25, 0.5, 0.75]))
+                cs = int(rng.integers(nfft, 4 * nfft))
+                dev_in = rng.random() < 0.5
+                src = torch.from_numpy(x).cuda() if dev_in else x
+                freqs, pro_ = nm.welch(producer(src, cs, -1), fs, nfft, "hann", ov, -1, "constant", "density")
+                got_ = np.stack([o.cpu().numpy() if dev_in else o for o in pro_], 0)
+                with np.errstate(invalid="ignore"):
+                    ref_ = np.stack(orc.welch_segments(x, fs, nfft, "hann", ov, "constant", "density")[1], 0)
+                ok = np.isfinite(ref_)
+                if got_.shape != ref_.shape or not np.array_equal(ok, np.isfinite(got_)):
+                    e = float("inf")
+                else:
+                    e = float(np.max(np.abs(got_[ok] - ref_[ok])) / np.max(np.abs(ref_[ok]))) if ok.any() else 0.0
+                what = f"welch segments nonfinite fs={fs} nfft={nfft} n={n} C={C} ov={ov} cs={cs} dev={dev_in}"
             elif kind == 8:    # sosfilt with a user zi, chunked == whole
                 n = interesting_length(rng, 300, 50000)
                 x = rng.standard_normal((int(rng.integers(1, 4)), n))
