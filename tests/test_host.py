@@ -573,3 +573,32 @@ def test_host_copy_pool_survives_fork():
     p.join(timeout=60)
     assert p.exitcode == 0
     assert big_copy()                          # and the parent's is unharmed
+
+
+def test_resample_window_is_padded_as_scipy_pads_it():
+    """numerical._resample_padded (host logic, no GPU): the window the resampler's kernels get is
+    the one scipy.signal.resample_poly filters with -- zeros in front so that the delay is whole
+    outputs, zeros behind, every phase to one count of taps -- so that filtering with EVERY tap
+    of it (scipy.signal.upfirdn does, as the kernels do) gives resample_poly's numbers and, with
+    non-finite samples, resample_poly's masks (0 x NaN is NaN), for any ratio and length."""
+    import scipy.signal as sps
+    from openseize_amd.core import numerical as nm
+    from oracle import oracle as orc
+    rng = np.random.default_rng(12)
+    for L, M in ((1, 5), (3, 2), (2, 1), (1, 25), (2, 7), (5, 3), (4, 25), (7, 5)):
+        for n in (997, 20_011):
+            x = rng.standard_normal(n)
+            x[n // 3] = np.nan
+            x[n - 1] = np.inf
+            h = orc.resample_filter(L, M, 5000)
+            taps, centre = nm._resample_padded(h, L, M, n)
+            assert len(taps) % L == 0 and centre % M == 0 and np.count_nonzero(taps) == np.count_nonzero(h)
+            nout = -(-n * L // M)
+            with np.errstate(invalid="ignore"):
+                want = sps.resample_poly(x, L, M, window=h)
+                full = sps.upfirdn(L * taps, x, L, M)
+            got = full[centre // M:centre // M + nout]
+            assert got.shape == want.shape == (nout,)
+            ok = np.isfinite(want)
+            assert np.array_equal(ok, np.isfinite(got)), (L, M, n)
+            assert np.max(np.abs(got[ok] - want[ok])) < 1e-12 * np.max(np.abs(want[ok]))
