@@ -602,3 +602,15 @@ def test_resample_window_is_padded_as_scipy_pads_it():
             ok = np.isfinite(want)
             assert np.array_equal(ok, np.isfinite(got)), (L, M, n)
             assert np.max(np.abs(got[ok] - want[ok])) < 1e-12 * np.max(np.abs(want[ok]))
+
+
+def test_reference_segment_length_is_the_oracles():
+    """numerical._oa_reference_step -- where the reach of a non-finite sample through the FIR is
+    counted from -- is the step of the reference's overlap-add plan (core/numerical.py:202-217,
+    oracle.oa_plan) for every length and window."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(4)
+    for _ in range(2000):
+        wlen = int(rng.integers(2, 5000))
+        n = int(rng.integers(wlen, 3_000_000))
+        assert nm._oa_reference_step(n, wlen) == max(orc.oa_plan(n, wlen, 32)[1], 1), (n, wlen)
