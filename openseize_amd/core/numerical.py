@@ -104,7 +104,7 @@ def _joined_resident(source, layout, gmax):
 
 _PROBE_AT = {}
 _PROBE_SLOTS = 8192            # pinned slots of one oaconvolve stream's probes (far more than it ever has pending)
-_PROBE_POOL = []               # (pinned slots, side stream) of finished streams
+_PROBE_POOL = {}               # device -> [(pinned slots, side stream)] of finished streams
 
 
 def _probe_sum(v):
@@ -141,7 +141,9 @@ class _ProbeWatch:
             return key
         if self.ring is None:
             # (pinned memory and a stream cost a third of a millisecond to make: kept for the process)
-            self.ring, self.side = _PROBE_POOL.pop() if _PROBE_POOL else (
+            self.device = torch.cuda.current_device()          # (a stream belongs to its device)
+            pool = _PROBE_POOL.setdefault(self.device, [])
+            self.ring, self.side = pool.pop() if pool else (
                 torch.empty(_PROBE_SLOTS, dtype=torch.float64, pin_memory=True), torch.cuda.Stream())
         while len(self.watch) >= _PROBE_SLOTS:
             self.watch.pop(next(iter(self.watch)))           # (long handed on: far more slots than pieces ever pending)
@@ -172,7 +174,7 @@ class _ProbeWatch:
     def close(self):
         if self.ring is not None:
             self.side.synchronize()
-            _PROBE_POOL.append((self.ring, self.side))
+            _PROBE_POOL.setdefault(self.device, []).append((self.ring, self.side))
             self.ring = self.side = None
 
 
