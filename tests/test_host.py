@@ -614,3 +614,17 @@ def test_reference_segment_length_is_the_oracles():
         wlen = int(rng.integers(2, 5000))
         n = int(rng.integers(wlen, 3_000_000))
         assert nm._oa_reference_step(n, wlen) == max(orc.oa_plan(n, wlen, 32)[1], 1), (n, wlen)
+
+
+def test_linear_trend_refusal_is_found_per_segment():
+    """numerical._linear_trend_refuses (host logic): the first segment of a push's output that holds
+    a non-finite entry in any channel -- what scipy.signal.detrend(type='linear') refuses in the
+    reference -- and nothing under a constant trend."""
+    out = np.random.default_rng(0).standard_normal((6, 3, 17))
+    assert nm._linear_trend_refuses(out, "linear") is None
+    out[4, 1, :] = np.nan
+    out[5, 0, :] = np.inf
+    assert nm._linear_trend_refuses(out, "linear") == 4
+    assert nm._linear_trend_refuses(out, "constant") is None
+    assert nm._linear_trend_refuses(out[:0], "linear") is None
+    assert nm._linear_trend_refuses(out.astype(np.complex128), "linear") == 4
