@@ -261,6 +261,8 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
             lo, hi = max(i0 - at, 0), min(i1 - at, n)
             if lo < hi:
                 parts.append(layout.to2d(chunk)[0][:, lo:hi])
+        if not parts:
+            return torch.zeros((layout.nch, 0), dtype=torch.float64, device="cuda")
         return torch.cat(parts, 1)
 
     def settle(arr, a, n):
@@ -269,6 +271,8 @@ def oaconvolve(pro, window, axis, mode, nfft_factor=32):
         k_lo, k_hi = segments(a, n)
         i0, i1 = k_lo * step, min(max((k_hi + 1) * step, b), nsamples)
         X = gather(i0, i1)
+        if X.shape[1] < i1 - i0:          # (a MaskedProducer's shape may name more samples than it yields)
+            X = torch.nn.functional.pad(X, (0, i1 - i0 - X.shape[1]))
         bad_in = ~torch.isfinite(X)
         y2d, host = layout.to2d(arr)
         mine = ~torch.isfinite(y2d)
