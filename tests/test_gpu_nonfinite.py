@@ -608,3 +608,30 @@ def test_linear_trend_refuses_nonfinite_data_as_the_reference_does(nm):
         assert len(got) == 5
         # finite data: nothing refused
         psd(data[:, :5 * nfft], fs=nfft, axis=-1, resolution=1.0, detrend="linear")
+
+
+@pytest.mark.parametrize("fed", ["resident", "host"])
+def test_oaconvolve_reach_behind_a_masked_producer(nm, fed):
+    """A MaskedProducer in front (its shape names the kept samples; core/producer.py:399-408): the
+    reach of a non-finite sample is counted in the samples the FIR sees, as in the reference."""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    rng = np.random.default_rng(17)
+    n, cs = 400_000, 30_000
+    x = rng.standard_normal((3, n))
+    mask = rng.random(n) > 0.3
+    kept = np.flatnonzero(mask)
+    x[0, kept[100_000]] = np.nan
+    x[1, kept[-1]] = np.inf
+    x[2, kept[5] + 1 if not mask[kept[5] + 1] else kept[5]] = np.nan      # (a dropped sample's NaN must not matter when it is dropped)
+    h = sps.firwin(256, 0.2)
+    src = torch.from_numpy(x).cuda() if fed == "resident" else x
+    got = np.concatenate([p.cpu().numpy() if torch.is_tensor(p) else p
+                          for p in nm.oaconvolve(producer(src, cs, -1, mask=mask), h, -1, "same")], -1)
+    with np.errstate(invalid="ignore"):
+        want = np.concatenate(orc.oaconvolve(x[:, mask], h, "same"), -1)
+    assert got.shape == want.shape
+    ok = np.isfinite(want)
+    assert np.array_equal(ok, np.isfinite(got)), np.argwhere(ok != np.isfinite(got))[:4]
+    assert np.max(np.abs(got[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
