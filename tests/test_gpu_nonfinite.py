@@ -635,3 +635,32 @@ def test_oaconvolve_reach_behind_a_masked_producer(nm, fed):
     ok = np.isfinite(want)
     assert np.array_equal(ok, np.isfinite(got)), np.argwhere(ok != np.isfinite(got))[:4]
     assert np.max(np.abs(got[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
+
+
+@pytest.mark.parametrize("fed", ["resident", "host"])
+def test_oaconvolve_reach_on_any_axis(nm, fed):
+    """The sample axis first, and in the middle of three: the pieces the reach is laid over are
+    the caller's N-D arrays."""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    rng = np.random.default_rng(23)
+    h = sps.firwin(65, 0.25)
+    for shape, axis in (((150_000, 3), 0), ((2, 90_001, 3), 1)):
+        x = rng.standard_normal(shape)
+        idx = [slice(None)] * len(shape)
+        idx[axis] = 60_000
+        x[tuple(idx)].flat[0] = np.nan                      # one channel, one sample
+        idx[axis] = shape[axis] - 2
+        x[tuple(idx)].flat[-1] = np.inf
+        src = torch.from_numpy(x).cuda() if fed == "resident" else x
+        got = np.concatenate([p.cpu().numpy() if torch.is_tensor(p) else p
+                              for p in nm.oaconvolve(producer(src, 20_000, axis), h, axis, "same")], axis)
+        x2 = np.moveaxis(x, axis, -1)
+        with np.errstate(invalid="ignore"):
+            want = np.concatenate(orc.oaconvolve(x2.reshape(-1, shape[axis]), h, "same"), -1)
+        want = np.moveaxis(want.reshape(x2.shape[:-1] + (-1,)), -1, axis)
+        assert got.shape == want.shape
+        ok = np.isfinite(want)
+        assert not ok.all() and np.array_equal(ok, np.isfinite(got)), (shape, np.argwhere(ok != np.isfinite(got))[:4])
+        assert np.max(np.abs(got[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
