@@ -664,3 +664,26 @@ def test_oaconvolve_reach_on_any_axis(nm, fed):
         ok = np.isfinite(want)
         assert not ok.all() and np.array_equal(ok, np.isfinite(got)), (shape, np.argwhere(ok != np.isfinite(got))[:4])
         assert np.max(np.abs(got[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
+
+
+def test_fir_sosfilt_chain_reach_with_the_sample_axis_first(nm):
+    """The fused FIR -> sosfilt launch with (samples, channels) data: the reach is laid over 2-D
+    pieces inside the step, the caller gets its own layout back."""
+    import scipy.signal as sps
+    import torch
+    from oracle import oracle as orc
+    sos = sps.butter(4, [0.05, 0.3], "bandpass", output="sos")
+    h = sps.firwin(256, 0.2)
+    cs, total = 70_000, 70_000 * 5 + 999
+    x = np.random.default_rng(29).standard_normal((total, 3))
+    x[200_000, 1] = np.nan
+    for data in (x, torch.from_numpy(x).cuda()):
+        src = producer(data, cs, 0)
+        fir = producer(partial(nm.oaconvolve, src, h, 0, "same"), cs, 0, shape=src.shape)
+        got = np.concatenate([p.cpu().numpy() if torch.is_tensor(p) else p for p in nm.sosfilt(fir, sos, 0)], 0)
+        with np.errstate(invalid="ignore"):
+            want = orc.sosfilt(np.concatenate(orc.oaconvolve(np.ascontiguousarray(x.T), h, "same"), -1), sos, cs)[0].T
+        ok = np.isfinite(want)
+        assert got.shape == want.shape and not ok[:, 1].all() and ok[:, 0].all()
+        assert np.array_equal(ok, np.isfinite(got))
+        assert np.max(np.abs(got[ok] - want[ok])) < RTOL * np.max(np.abs(want[ok]))
